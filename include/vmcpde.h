@@ -1,0 +1,166 @@
+/*
+ * vmcpde.h -- C ABI of libvmcpde.so: the MI355X (gfx950) TDVP / stochastic-reconfiguration hot path.
+ *
+ * The reference (RehMoritz/vmc_pde, /root/reference/vmc_fluids) has no FFI layer: its boundary is the
+ * Python object protocol stepper <-> TDVP <-> (VarState, EvolutionEquation, Sampler).  The Python classes in
+ * vmc_pde_amd/ keep that protocol; every compiled ("kernel-like") callable of the reference (SURVEY.md 2.2,
+ * J1..J15) is replaced by one entry point below.  Each entry point cites the reference lines it replaces.
+ *
+ * Conventions
+ *   - every pointer marked [dev] is a device pointer (HBM); [host] is host memory.  The caller (PyTorch) owns
+ *     all buffers including the explicit workspaces; nothing here allocates per call, nothing synchronises the
+ *     host, every launch goes to the hipStream_t passed as `stream` (void* so that no HIP header is needed).
+ *   - return value 0 = success, <0 = error; vmcpde_last_error() gives a thread-local message.
+ *   - all arithmetic is IEEE fp64 (reference: global_defs.py:8 tReal = float64, main.py:2 jax_enable_x64).
+ *   - sample arrays are row-major [N][d]; the per-sample parameter Jacobian is stored PARAMETER-MAJOR:
+ *     JT[p * ldj + n] = d logp(x_n) / d theta_p  (the reference's (1,N,P) array is a strided view of it).
+ */
+#ifndef VMCPDE_H
+#define VMCPDE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMCPDE_MAX_DIM 16
+#define VMCPDE_MAX_DEPTH 16
+#define VMCPDE_MAX_HIDDEN_LAYERS 3
+#define VMCPDE_MAX_DIRS 136 /* d(d+1)/2 at d = 16 */
+
+#define VMCPDE_GRAM_TILE 128 /* S is produced in 128x128 tiles of the lower triangle */
+
+/* coupling variants of SingleBlock, net.py:69-72, 90-109 */
+enum { VMCPDE_COUPLING_NO_ADD = 0, VMCPDE_COUPLING_DIFFERENT_ADD = 1, VMCPDE_COUPLING_JAC_EQ_1 = 2, VMCPDE_COUPLING_PLAIN = 3 };
+/* latent densities, net.py:10-36 */
+enum { VMCPDE_LATENT_GAUSS = 0, VMCPDE_LATENT_STUDENT_T = 1 };
+/* PDE right-hand sides, evolutionEq.py:54-60 */
+enum {
+  VMCPDE_EQ_DIFFUSION = 0,            /* evolutionEq.py:84-87  */
+  VMCPDE_EQ_DIFFUSION_DRIFT = 1,      /* evolutionEq.py:89-94  */
+  VMCPDE_EQ_DIFFUSION_ANISOTROPIC = 2,/* evolutionEq.py:96-100 */
+  VMCPDE_EQ_ADVECTION_PAPER = 3,      /* evolutionEq.py:102-105 with :23-27 */
+  VMCPDE_EQ_ADVECTION_HAMILTONIAN = 4,/* evolutionEq.py:102-105 with :30-45 */
+  VMCPDE_EQ_ADVECTION_HAMILTONIAN_WDISS = 5 /* evolutionEq.py:107-119 */
+};
+
+typedef struct vmcpde_model vmcpde_model; /* opaque handle: one per (network, GPU) */
+
+/* Static description of net.INNwProb as built by VarState.init_net (var_state.py:110-124, net.py:185-207). */
+typedef struct {
+  int32_t dim;                                /* d */
+  int32_t depth;                              /* number of SingleBlock's (net.py:166) */
+  int32_t n_hidden;                           /* len(intmediate) (net.py:45,54) */
+  int32_t hidden[VMCPDE_MAX_HIDDEN_LAYERS];   /* intmediate */
+  int32_t coupling;                           /* VMCPDE_COUPLING_* */
+  int32_t latent;                             /* VMCPDE_LATENT_*   */
+  int32_t n_up;                               /* len(ind_up) = dim/2 (var_state.py:116) */
+  const int32_t* inds_up;   /* [host] depth * n_up          (var_state.py:116, order preserved) */
+  const int32_t* inds_down; /* [host] depth * (dim - n_up)  (var_state.py:117) */
+  const double* offset;     /* [host] dim, network_args["offset"] (net.py:192,212) */
+} vmcpde_model_desc;
+
+/* constants of one EvolutionEquation (evolutionEq.py:61-77); unused fields are ignored by `kind` */
+typedef struct {
+  int32_t kind;     /* VMCPDE_EQ_* */
+  double D;         /* diffusion, diffusion_drift */
+  double mu;        /* diffusion_drift */
+  double m, omega, lam, T, gamma; /* hamiltonian fields; T is also the period of advection_paper */
+} vmcpde_eq_consts;
+
+const char* vmcpde_last_error(void);
+int vmcpde_abi_version(void);
+
+/* ---- model -------------------------------------------------------------------------------------------- */
+/* var_state.py:110-124 + :25-27: builds the flat-parameter layout (JAX pytree order = sorted keys) on the GPU. */
+int vmcpde_create(const vmcpde_model_desc* desc, vmcpde_model** out);
+int vmcpde_destroy(vmcpde_model* m);
+int vmcpde_num_parameters(const vmcpde_model* m);                 /* var_state.py:27 */
+/* offset of a leaf in the flat vector (var_state.py:94-108). block<0 selects the latent leaves:
+ * trafo 0='L',1='L_diag',2='dist_params',3='mu'. Otherwise trafo 0='s1',1='s2',2='t1',3='t2';
+ * leaf 0='bias',1='kernel' of Dense_<layer>. Returns -1 if absent. */
+int vmcpde_param_offset(const vmcpde_model* m, int block, int trafo, int layer, int leaf);
+/* bytes of LDS one wave needs / samples per wave chosen for flow_eval with n_dirs directions (diagnostic) */
+int vmcpde_flow_eval_config(const vmcpde_model* m, int n_dirs, int* lanes, int* lds_bytes);
+
+/* ---- sampler.py ---------------------------------------------------------------------------------------- */
+/* sampler.py:25-34,72-74,85-86 + util.py:21-26: z_n = mu + chol(L L^T) n_n (* sqrt(nu/chi2_nu)) + offset,
+ * Philox4x32-10 counter RNG: sample n of call `stream_id` (< 2^32) uses counter (n, stream_id), key = seed. z: [dev] N*d. */
+int vmcpde_sample_latent(vmcpde_model* m, const double* theta, uint64_t seed, uint64_t stream_id,
+                         int64_t first_sample, int64_t n_samples, double* z, void* stream);
+/* the same map with the random draws injected (parity tests, H4): normals [dev] N*d, chi2 [dev] N or NULL */
+int vmcpde_latent_from_normals(vmcpde_model* m, const double* theta, const double* normals, const double* chi2,
+                               int64_t n_samples, double* z, void* stream);
+/* sampler.py:37-45,88-111 (+ target :20-22): independence-Metropolis on a 2-D disc, one chain per lane.
+ * states [dev] chains*2 in/out, out [dev] steps*chains*2 (step-major as the scan emits), n_acc [dev] 1,
+ * offset2 [host] 2 (mcmc_info["offset"]). */
+int vmcpde_mcmc(uint64_t seed, uint64_t stream_id, int32_t chains, int32_t steps, double bound, const double* offset2,
+                double* states, double* out, unsigned long long* n_acc, void* stream);
+/* the same scan with injected uniforms u_r,u_phi,u_acc: [dev] steps*chains each */
+int vmcpde_mcmc_from_uniforms(const double* u_r, const double* u_phi, const double* u_acc, int32_t chains, int32_t steps,
+                              double bound, const double* offset2, double* states, double* out,
+                              unsigned long long* n_acc, void* stream);
+
+/* ---- net.py / var_state.py ----------------------------------------------------------------------------- */
+/* var_state.py:33,79 (J5): latent z -> (x, logp) = INNwProb(evaluate=False, inv=True) net.py:214-217,176-180,120-153.
+ * inv=0 runs the forward direction instead (main.py:81,87,93: apply(..., evaluate=False, inv=False)). */
+int vmcpde_flow_sample(vmcpde_model* m, const double* theta, const double* z, int64_t n_samples, int inv,
+                       double* x, double* logp, void* stream);
+/* var_state.py:29,31,32,34 (J1,J3,J4,J6): per sample logp, grad_x logp, directional second derivatives
+ * hv[n][k] = v_k^T (Hessian_x logp) v_k for n_dirs caller-given directions dirs[k][d], and the parameter Jacobian.
+ * Any of logp,g,hv,JT may be NULL (skipped).  JT: [dev] P * ldj, parameter-major.  dirs: [dev] n_dirs*d. */
+int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const double* x, int64_t n_samples,
+                     const double* dirs, int32_t n_dirs, double* logp, double* g, double* hv,
+                     double* JT, int64_t ldj, void* stream);
+
+/* ---- evolutionEq.py ------------------------------------------------------------------------------------ */
+/* evolutionEq.py:84-119 epilogue: Eloc_n from x, g and the directional second derivatives (J14 + eager einsums).
+ * hv columns expected: diffusion(_drift): e_0..e_{d-1}; anisotropic: columns of chol(D), and Dmat [dev] d*d;
+ * hamiltonian_wDiss: e_1,e_3,...  (momentum axes); advection: none. */
+int vmcpde_rhs(const vmcpde_eq_consts* c, int32_t dim, const double* x, const double* g, const double* hv, int32_t n_dirs,
+               const double* Dmat, double t, int64_t n_samples, double* eloc, void* stream);
+
+/* ---- tdvp.py:36-52 + mpi_wrapper.py:61-63,21-25 -------------------------------------------------------- */
+/* sums[0..3] = sum E, sum E^2, sum |E|, max E over the local samples (tdvp.py:37-39,150). sums: [dev] 4. */
+int vmcpde_eloc_stats(const double* eloc, int64_t n_samples, double* sums, void* stream);
+/* per parameter row p: rowsum[p] = sum_n (JT[p][n]-c[p]),  rowdot[p] = sum_n (JT[p][n]-c[p])*(E_n-cE)
+ * (tdvp.py:41,44-45 in shifted one-pass form; c may be NULL = 0).  cE is read from cE_dev[0] if non-NULL. */
+int vmcpde_row_moments(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, const double* eloc,
+                       const double* c, const double* cE_dev, double* rowsum, double* rowdot, void* stream);
+/* number of 128x128 lower-triangle tiles / doubles of the packed Gram buffer for P parameters */
+int64_t vmcpde_gram_packed_doubles(int32_t P);
+/* bytes of split-K workspace vmcpde_gram needs for (P, n_samples) */
+int64_t vmcpde_gram_workspace_bytes(int32_t P, int64_t n_samples);
+/* the Gram ("syrk") contraction, tdvp.py:46-47 / mpi_wrapper.py:21-25 (J13) on fp64 MFMA:
+ * packed[tile(i,j)][r][s] = sum_n w_n (JT[i*128+r][n]-c[..]) (JT[j*128+s][n]-c[..]),  j<=i,  w=NULL -> 1.
+ * w = logp^2 gives SExp (tdvp.py:33,47); w = Etilde^2 gives the SNR Gram (tdvp.py:68-70). */
+int vmcpde_gram(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, const double* c, const double* w,
+                double* packed, void* workspace, int64_t workspace_bytes, void* stream);
+/* tdvp.py:45-46,50-51: S[i][j] = packed/Ntot - delta_i delta_j (full symmetric, both triangles written),
+ * A_shifted = S + diag(diagonal_shift * diag S) (optional second copy for the in-place Cholesky, may be NULL),
+ * F = rowdot/Ntot - delta*deltaE, mean = c + delta, with delta = rowsum/Ntot, deltaE = sums[0]/Ntot - cE.
+ * S: [dev] P*lds, A_shifted: [dev] P*lda.  All inputs may already be all-reduced over ranks (Ntot = global count). */
+int vmcpde_gram_finalize(const double* packed, const double* rowsum, const double* rowdot, const double* sums,
+                         const double* c, const double* cE_dev, int32_t P, double n_total, double diagonal_shift,
+                         double* S, int64_t lds, double* A_shifted, int64_t lda, double* F, double* mean, void* stream);
+
+/* ---- tdvp.py:57-94 solve ------------------------------------------------------------------------------- */
+/* in-place lower Cholesky of A (P x P, leading dim lda); rows with a non-positive pivot are pinned to the unit
+ * row (H7, dead/padded parameters).  info: [dev] 1, number of pinned pivots.  workspace >= vmcpde_chol_workspace_bytes */
+int64_t vmcpde_chol_workspace_bytes(int32_t P);
+int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info, void* workspace, int64_t workspace_bytes, void* stream);
+/* u = (L L^T)^{-1} F with the factor from vmcpde_cholesky. u may alias F. */
+int vmcpde_chol_solve(const double* L, int64_t lda, int32_t P, const double* F, double* u,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+/* y = A x for symmetric full-storage A (tdvp.py:66,91,93,94 mat-vecs); trans=1 uses A^T (V^T F) */
+int vmcpde_gemv(const double* A, int64_t lda, int32_t rows, int32_t cols, int trans, const double* x, double* y, void* stream);
+/* tdvp.py:82-91: coef_k = invEv_k * regularizer_k * VtF_k with the hard 1e-14 and soft svdTol cut-offs,
+ * optional SNR factor (snr NULL = off).  ev ascending (eigh). */
+int vmcpde_pinv_coeffs(const double* ev, const double* VtF, const double* snr, int32_t P, double svdTol, double snrTol,
+                       double* coef, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMCPDE_H */

@@ -1,0 +1,92 @@
+// Shared definitions of libvmcpde (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/vmcpde.h"
+
+namespace vmcpde {
+
+void set_error(const char* fmt, ...);
+
+#define VMC_CHECK_HIP(expr)                                                                    \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      ::vmcpde::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return -2;                                                                               \
+    }                                                                                          \
+  } while (0)
+
+#define VMC_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::vmcpde::set_error(__VA_ARGS__);   \
+      return -1;                          \
+    }                                     \
+  } while (0)
+
+constexpr int MAX_DIM = VMCPDE_MAX_DIM;
+constexpr int MAX_HALF = VMCPDE_MAX_DIM;          // a half-step conditions on / transforms at most d coordinates
+constexpr int MAX_LAYERS = VMCPDE_MAX_HIDDEN_LAYERS + 1;  // hidden Dense layers + output Dense
+constexpr int MAX_HALFSTEPS = 2 * VMCPDE_MAX_DEPTH;
+
+// One nn.Dense of a SingleTrafo (net.py:55-56, 60-61); offsets index the flat parameter vector.
+struct DenseLayer {
+  int32_t n_in, n_out;
+  int32_t off_bias, off_kernel;  // kernel is (in,out) row-major
+};
+
+// One SingleTrafo (net.py:44-62): n_layers-1 tanh hidden layers + alpha*tanh output layer.
+struct Trafo {
+  int32_t n_layers;
+  int32_t n_in, n_out;
+  int32_t sum_hidden;   // sum of hidden widths
+  int32_t max_width;    // max over all layer widths incl. input/output
+  DenseLayer layer[MAX_LAYERS];
+};
+
+// One coupling half-step (half of SingleBlock.__call__, net.py:84-118): y_c = c*exp(s(a)) [+ t(a)], a unchanged.
+struct HalfStep {
+  int32_t n_a, n_c;
+  int32_t idx_a[MAX_HALF];  // coordinates fed to the conditioner
+  int32_t idx_c[MAX_HALF];  // coordinates that get transformed
+  int32_t has_t;
+  Trafo s, t;
+};
+
+// Whole INNwProb (net.py:185-217) in forward (real space -> latent space) order.
+struct FlowProgram {
+  int32_t dim, n_half, coupling, latent;
+  int32_t P;
+  int32_t off_L, off_Ldiag, off_dist, off_mu;
+  int32_t max_width;     // widest MLP layer (incl. inputs/outputs)
+  int32_t max_sum_act;   // max over trafos of (n_in + sum_hidden)
+  double alpha;          // SingleTrafo.alpha = 10 (net.py:50)
+  double offset[MAX_DIM];
+  HalfStep hs[MAX_HALFSTEPS];
+};
+
+// Per-parameter-vector latent cache written by latent_prepare_kernel (flow.hip):
+// U = strict-upper(L_para) + diag(exp(L_diag)) (util.py:21-26), C = chol_lower(U U^T), and the Student-t constants.
+struct LatentCache {
+  double U[MAX_DIM * MAX_DIM];
+  double C[MAX_DIM * MAX_DIM];
+  double mu[MAX_DIM];
+  double logdetS;     // log det(U U^T) = 2 sum L_diag
+  double nu;          // exp(dist_params[0]) + 1 (net.py:32)
+  double lognorm;     // all x-independent terms of the log pdf
+  double dlognorm_dtau;  // d lognorm / d dist_params[0] (Student-t only)
+};
+
+}  // namespace vmcpde
+
+struct vmcpde_model {
+  vmcpde::FlowProgram host;
+  vmcpde::FlowProgram* dev = nullptr;
+  vmcpde::LatentCache* cache = nullptr;   // device
+  void* layout = nullptr;                 // host-side LayoutTable (model.hip)
+  int device = 0;
+};

@@ -1,0 +1,762 @@
+// Coupling-flow kernels: batched INNwProb forward / inverse, per-sample input gradient, directional second
+// derivatives and the per-sample parameter Jacobian (stored parameter-major), plus the PDE right-hand sides.
+//
+// Replaces the jitted closures J1, J3, J4, J5, J6, J14 of the reference:
+//   var_state.py:29-34, net.py:44-62 (SingleTrafo), net.py:84-153 (SingleBlock fwd/inv, all four coupling
+//   variants), net.py:168-182 (INN), net.py:209-217 (INNwProb), net.py:10-36 (Gauss / Student_t),
+//   util.py:21-26 (covariance factor), evolutionEq.py:23-45, 84-119.
+//
+// Execution model (gfx950): ONE SAMPLE PER LANE, one 64-lane wave per workgroup.  Every per-sample vector
+// (state, MLP activations, tangents, adjoints) lives in LDS as [unit][lane] (lane-contiguous doubles, so each
+// ds_read_b64/ds_write_b64 is conflict-free); MLP weights are wave-uniform and are read through the scalar
+// cache (s_load) straight from the flat parameter vector; the output-blocked (JB=8) accumulators live in VGPRs.
+// The Jacobian is written as JT[p][n]: for a fixed parameter p the 64 lanes store 64 consecutive doubles
+// (one 512-B coalesced store per parameter per wave) -- no transposition pass is needed, and the Gram kernel
+// consumes exactly this K-contiguous layout.
+//
+// Derivatives are hand-derived (the oracle uses autodiff, so the two are independent):
+//   * second derivatives: forward Taylor mode -- (value, d/de, d2/de2) along x + e v is pushed through every
+//     layer; v^T H v = d2/de2 logp.  One pass per direction.
+//   * grad_x and grad_theta: reverse sweep from the latent end, walking the flow backwards with the exact
+//     inverse of each coupling half-step so that only one MLP's activations are alive at a time.
+#include "common.hpp"
+
+using namespace vmcpde;
+
+namespace {
+
+constexpr int JB = 8;  // output block held in registers by the dense-layer loops
+
+struct Regions {
+  // persistent
+  int X;    // state, 3 components of stride d (value, first, second Taylor coefficient)
+  int G;    // adjoint of the state (d)
+  // Taylor phase
+  int A, B; // ping-pong MLP buffers, 3 components of stride cs
+  int SOUT; // stash of s (3 x d) while t is evaluated (different_add)
+  int LAT;  // latent residual / whitened residual (3 x d)
+  // reverse phase (aliases the Taylor phase)
+  int ACT;  // inputs of every layer of the current MLP (n_in + sum hidden)
+  int OUTS, OUTT;  // s and t outputs (d each)
+  int DW;   // cotangent of the MLP outputs (d)
+  int DEL0, DEL1, EPS;  // delta ping-pong and W*delta accumulator (cs each)
+  int GAM;  // input gradient of the MLPs (d)
+  int Y, Q; // whitened residual y = U^-1 r and q = U^-T y (d each)
+  int cs;   // component stride of A/B = widest layer
+  int total;
+};
+
+Regions make_regions(const FlowProgram& fp) {
+  Regions r;
+  const int d = fp.dim, W = fp.max_width;
+  r.cs = W;
+  int u = 0;
+  r.X = u; u += 3 * d;
+  r.G = u; u += d;
+  const int base = u;
+  // Taylor phase
+  r.A = u; u += 3 * W;
+  r.B = u; u += 3 * W;
+  r.SOUT = u; u += 3 * d;
+  r.LAT = u; u += 3 * d;
+  const int end_taylor = u;
+  // reverse phase
+  u = base;
+  r.ACT = u; u += fp.max_sum_act;
+  r.OUTS = u; u += d;
+  r.OUTT = u; u += d;
+  r.DW = u; u += d;
+  r.DEL0 = u; u += W;
+  r.DEL1 = u; u += W;
+  r.EPS = u; u += W;
+  r.GAM = u; u += d;
+  r.Y = u; u += d;
+  r.Q = u; u += d;
+  r.total = (u > end_taylor) ? u : end_taylor;
+  return r;
+}
+
+struct Ctx {
+  double* lds;
+  int lanes;
+  int lane;
+  const double* __restrict__ th;
+  const FlowProgram* __restrict__ fp;
+};
+
+#define LD(u) (c.lds[(u) * c.lanes + c.lane])
+
+// y = tanh-layer(x): z_j = b_j + sum_i W[i][j] a_i (net.py:55-61), with NC Taylor components.
+template <int NC>
+__device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, int uin, int uout, int cs, double scale) {
+  const int n_in = L.n_in, n_out = L.n_out;
+  const double* __restrict__ W = c.th + L.off_kernel;
+  const double* __restrict__ Bv = c.th + L.off_bias;
+  for (int j0 = 0; j0 < n_out; j0 += JB) {
+    double acc[NC][JB];
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) {
+      acc[0][jj] = (j0 + jj < n_out) ? Bv[j0 + jj] : 0.0;
+#pragma unroll
+      for (int cc = 1; cc < NC; ++cc) acc[cc][jj] = 0.0;
+    }
+    for (int i = 0; i < n_in; ++i) {
+      double a[NC];
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) a[cc] = LD(uin + cc * cs + i);
+      const double* __restrict__ wr = W + i * n_out + j0;
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) {
+        const double w = (j0 + jj < n_out) ? wr[jj] : 0.0;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) acc[cc][jj] = fma(w, a[cc], acc[cc][jj]);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) {
+      if (j0 + jj < n_out) {
+        const double h = tanh(acc[0][jj]);
+        LD(uout + j0 + jj) = scale * h;
+        if (NC == 3) {
+          const double hp = 1.0 - h * h;
+          const double z1 = acc[1][jj], z2 = acc[2][jj];
+          LD(uout + cs + j0 + jj) = scale * hp * z1;
+          LD(uout + 2 * cs + j0 + jj) = scale * hp * (z2 - 2.0 * h * z1 * z1);
+        }
+      }
+    }
+  }
+}
+
+// SingleTrafo forward (net.py:53-61), ping-pong between buffers uA (holding the input) and uB. Returns output base.
+template <int NC>
+__device__ __forceinline__ int mlp_forward(const Ctx& c, const Trafo& T, int uA, int uB, int cs) {
+  int cur = uA, nxt = uB;
+  for (int k = 0; k < T.n_layers; ++k) {
+    dense_layer<NC>(c, T.layer[k], cur, nxt, cs, (k == T.n_layers - 1) ? c.fp->alpha : 1.0);
+    const int t = cur; cur = nxt; nxt = t;
+  }
+  return cur;
+}
+
+// One coupling half-step in the forward direction (real -> latent), net.py:86-113, with NC Taylor components.
+template <int NC>
+__device__ __forceinline__ void halfstep_forward(const Ctx& c, const HalfStep& h, const Regions& r, double* lj) {
+  const int d = c.fp->dim, cs = r.cs;
+  for (int i = 0; i < h.n_a; ++i)
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) LD(r.A + cc * cs + i) = LD(r.X + cc * d + h.idx_a[i]);
+  int us = mlp_forward<NC>(c, h.s, r.A, r.B, cs);
+  int ut = 0;
+  const int coupling = c.fp->coupling;
+  if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) {
+    for (int k = 0; k < h.n_c; ++k)
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) LD(r.SOUT + cc * d + k) = LD(us + cc * cs + k);
+    for (int i = 0; i < h.n_a; ++i)
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) LD(r.A + cc * cs + i) = LD(r.X + cc * d + h.idx_a[i]);
+    ut = mlp_forward<NC>(c, h.t, r.A, r.B, cs);
+  }
+  for (int k = 0; k < h.n_c; ++k) {
+    double s[3] = {0, 0, 0}, t[3] = {0, 0, 0}, cv[3] = {0, 0, 0}, y[3] = {0, 0, 0};
+    const int ix = h.idx_c[k];
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) {
+        s[cc] = LD(r.SOUT + cc * d + k);
+        t[cc] = LD(ut + cc * cs + k);
+      } else {
+        s[cc] = LD(us + cc * cs + k);
+      }
+      cv[cc] = LD(r.X + cc * d + ix);
+    }
+    if (coupling == VMCPDE_COUPLING_JAC_EQ_1) {  // net.py:90-92: v = u + s, log-jacobian 0
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) y[cc] = cv[cc] + s[cc];
+    } else {
+      const double E = exp(s[0]);
+      y[0] = cv[0] * E;
+      if (NC == 3) {
+        const double E1 = E * s[1];
+        const double E2 = E * (s[2] + s[1] * s[1]);
+        y[1] = cv[1] * E + cv[0] * E1;
+        y[2] = cv[2] * E + 2.0 * cv[1] * E1 + cv[0] * E2;
+      }
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) {
+        if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) y[cc] += t[cc];   // net.py:94
+        if (coupling == VMCPDE_COUPLING_PLAIN) y[cc] += s[cc];           // net.py:98
+        lj[cc] += s[cc];                                                 // net.py:118
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) LD(r.X + cc * d + ix) = y[cc];
+  }
+}
+
+// One coupling half-step in the inverse direction (latent -> real), values only, net.py:121-148.
+__device__ __forceinline__ void halfstep_inverse(const Ctx& c, const HalfStep& h, const Regions& r, double& lj) {
+  const int cs = r.cs;
+  for (int i = 0; i < h.n_a; ++i) LD(r.A + i) = LD(r.X + h.idx_a[i]);
+  int us = mlp_forward<1>(c, h.s, r.A, r.B, cs);
+  int ut = 0;
+  const int coupling = c.fp->coupling;
+  if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) {
+    for (int k = 0; k < h.n_c; ++k) LD(r.SOUT + k) = LD(us + k);
+    for (int i = 0; i < h.n_a; ++i) LD(r.A + i) = LD(r.X + h.idx_a[i]);
+    ut = mlp_forward<1>(c, h.t, r.A, r.B, cs);
+  }
+  for (int k = 0; k < h.n_c; ++k) {
+    const int ix = h.idx_c[k];
+    const double v = LD(r.X + ix);
+    double u;
+    if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) {
+      const double s = LD(r.SOUT + k);
+      u = (v - LD(ut + k)) * exp(-s);   // net.py:129,140
+      lj -= s;
+    } else {
+      const double s = LD(us + k);
+      if (coupling == VMCPDE_COUPLING_JAC_EQ_1) {
+        u = v - s;                      // net.py:126,137
+      } else if (coupling == VMCPDE_COUPLING_NO_ADD) {
+        u = v * exp(-s);                // net.py:131,142
+        lj -= s;
+      } else {
+        u = (v - s) * exp(-s);          // net.py:133,144
+        lj -= s;
+      }
+    }
+    LD(r.X + ix) = u;
+  }
+}
+
+// Latent log-density (net.py:10-36) of the state in X with NC Taylor components; returns logp components in lp[].
+// r = z - offset - mu; y = U^-1 r (U upper triangular, U U^T = S, util.py:21-26); Q = |y|^2 = r^T S^-1 r.
+template <int NC>
+__device__ __forceinline__ void latent_forward(const Ctx& c, const LatentCache* __restrict__ lc, const Regions& r, int ux, double* lp) {
+  const int d = c.fp->dim;
+  double Q[3] = {0, 0, 0};
+  for (int i = d - 1; i >= 0; --i) {
+    double y[3];
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      y[cc] = LD(ux + cc * d + i);
+      if (cc == 0) y[0] -= c.fp->offset[i] + lc->mu[i];
+    }
+    for (int j = i + 1; j < d; ++j) {
+      const double uij = lc->U[i * MAX_DIM + j];
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) y[cc] -= uij * LD(r.LAT + cc * d + j);
+    }
+    const double inv = 1.0 / lc->U[i * MAX_DIM + i];
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      y[cc] *= inv;
+      LD(r.LAT + cc * d + i) = y[cc];
+    }
+    Q[0] += y[0] * y[0];
+    if (NC == 3) {
+      Q[1] += 2.0 * y[0] * y[1];
+      Q[2] += 2.0 * (y[1] * y[1] + y[0] * y[2]);
+    }
+  }
+  if (c.fp->latent == VMCPDE_LATENT_GAUSS) {
+    lp[0] = lc->lognorm - 0.5 * Q[0];   // net.py:18-20
+    if (NC == 3) { lp[1] = -0.5 * Q[1]; lp[2] = -0.5 * Q[2]; }
+  } else {
+    const double nu = lc->nu, p = (double)d;   // net.py:32-36
+    const double hnp = 0.5 * (nu + p);
+    lp[0] = lc->lognorm - hnp * log1p(Q[0] / nu);
+    if (NC == 3) {
+      const double f1 = -hnp / (nu + Q[0]);
+      const double f2 = hnp / ((nu + Q[0]) * (nu + Q[0]));
+      lp[1] = f1 * Q[1];
+      lp[2] = f1 * Q[2] + f2 * Q[1] * Q[1];
+    }
+  }
+}
+
+// SingleTrafo forward keeping every layer input in ACT (input already in ACT[0..n_in)); outputs go to uOUT.
+__device__ __forceinline__ void mlp_forward_store(const Ctx& c, const Trafo& T, int uACT, int uOUT) {
+  int in = uACT;
+  for (int k = 0; k < T.n_layers; ++k) {
+    const DenseLayer& L = T.layer[k];
+    const bool last = (k == T.n_layers - 1);
+    const int out = last ? uOUT : in + L.n_in;
+    dense_layer<1>(c, L, in, out, 0, last ? c.fp->alpha : 1.0);
+    in = out;
+  }
+}
+
+// Reverse pass through one SingleTrafo with output cotangent in uW: writes the parameter-gradient rows of this
+// sample into JT (bias: delta_j, kernel: a_i delta_j) and accumulates the input gradient into GAM.
+__device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const Regions& r, int uOUT, int uW,
+                                             double* __restrict__ JT, int64_t ldj, int64_t n, bool active) {
+  const double alpha = c.fp->alpha;
+  const int nl = T.n_layers;
+  {
+    const DenseLayer& L = T.layer[nl - 1];
+    for (int j = 0; j < L.n_out; ++j) {
+      const double th = LD(uOUT + j) / alpha;
+      LD(r.DEL0 + j) = LD(uW + j) * alpha * (1.0 - th * th);
+    }
+  }
+  int in_off = T.n_in + T.sum_hidden;  // one past the last layer input
+  int cur = r.DEL0, nxt = r.DEL1;
+  for (int k = nl - 1; k >= 0; --k) {
+    const DenseLayer& L = T.layer[k];
+    const int n_in = L.n_in, n_out = L.n_out;
+    in_off -= n_in;
+    const int uin = r.ACT + in_off;
+    const double* __restrict__ W = c.th + L.off_kernel;
+    for (int i = 0; i < n_in; ++i) LD(r.EPS + i) = 0.0;
+    for (int j0 = 0; j0 < n_out; j0 += JB) {
+      double dl[JB];
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) dl[jj] = (j0 + jj < n_out) ? LD(cur + j0 + jj) : 0.0;
+      if (JT != nullptr && active) {
+        double* __restrict__ jb = JT + (int64_t)(L.off_bias + j0) * ldj + n;
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj)
+          if (j0 + jj < n_out) jb[(int64_t)jj * ldj] = dl[jj];
+      }
+      for (int i = 0; i < n_in; ++i) {
+        const double a = LD(uin + i);
+        const double* __restrict__ wr = W + i * n_out + j0;
+        double e = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+          const double w = (j0 + jj < n_out) ? wr[jj] : 0.0;
+          e = fma(w, dl[jj], e);
+        }
+        LD(r.EPS + i) += e;
+        if (JT != nullptr && active) {
+          double* __restrict__ jk = JT + (int64_t)(L.off_kernel + i * n_out + j0) * ldj + n;
+#pragma unroll
+          for (int jj = 0; jj < JB; ++jj)
+            if (j0 + jj < n_out) jk[(int64_t)jj * ldj] = a * dl[jj];
+        }
+      }
+    }
+    if (k > 0) {
+      for (int i = 0; i < n_in; ++i) {
+        const double a = LD(uin + i);
+        LD(nxt + i) = (1.0 - a * a) * LD(r.EPS + i);
+      }
+      const int t = cur; cur = nxt; nxt = t;
+    } else {
+      for (int i = 0; i < n_in; ++i) LD(r.GAM + i) += LD(r.EPS + i);
+    }
+  }
+}
+
+// Reverse sweep through one coupling half-step: on entry X holds the half-step's OUTPUT y and G = dlogp/dy;
+// on exit X holds its INPUT and G = dlogp/d(input).
+__device__ __forceinline__ void halfstep_backward(const Ctx& c, const HalfStep& h, const Regions& r,
+                                                  double* __restrict__ JT, int64_t ldj, int64_t n, bool active) {
+  const int coupling = c.fp->coupling;
+  for (int i = 0; i < h.n_a; ++i) LD(r.GAM + i) = 0.0;
+  if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) {
+    // t enters additively (net.py:94): its output cotangent is G_c itself
+    for (int i = 0; i < h.n_a; ++i) LD(r.ACT + i) = LD(r.X + h.idx_a[i]);
+    mlp_forward_store(c, h.t, r.ACT, r.OUTT);
+    for (int k = 0; k < h.n_c; ++k) LD(r.DW + k) = LD(r.G + h.idx_c[k]);
+    mlp_backward(c, h.t, r, r.OUTT, r.DW, JT, ldj, n, active);
+  }
+  for (int i = 0; i < h.n_a; ++i) LD(r.ACT + i) = LD(r.X + h.idx_a[i]);
+  mlp_forward_store(c, h.s, r.ACT, r.OUTS);
+  for (int k = 0; k < h.n_c; ++k) {
+    const int ix = h.idx_c[k];
+    const double s = LD(r.OUTS + k);
+    const double y = LD(r.X + ix);
+    const double gk = LD(r.G + ix);
+    double cin, w, gnew;
+    if (coupling == VMCPDE_COUPLING_JAC_EQ_1) {
+      cin = y - s; w = gk; gnew = gk;
+    } else {
+      const double E = exp(s);
+      double ces;  // c * exp(s)
+      if (coupling == VMCPDE_COUPLING_NO_ADD) ces = y;
+      else if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) ces = y - LD(r.OUTT + k);
+      else ces = y - s;
+      cin = ces / E;
+      w = gk * ces + 1.0;                                   // d/ds [ G_c c e^s + s ]
+      if (coupling == VMCPDE_COUPLING_PLAIN) w += gk;       // + G_c d(s)/ds of the additive s (net.py:98)
+      gnew = gk * E;
+    }
+    LD(r.DW + k) = w;
+    LD(r.X + ix) = cin;
+    LD(r.G + ix) = gnew;
+  }
+  mlp_backward(c, h.s, r, r.OUTS, r.DW, JT, ldj, n, active);
+  for (int i = 0; i < h.n_a; ++i) LD(r.G + h.idx_a[i]) += LD(r.GAM + i);
+}
+
+// Adjoint of the latent log-density: G = dlogp/dz and the latent-parameter rows of JT (L, L_diag, dist_params, mu).
+__device__ __forceinline__ void latent_backward(const Ctx& c, const LatentCache* __restrict__ lc, const Regions& r,
+                                                double* __restrict__ JT, int64_t ldj, int64_t n, bool active) {
+  const FlowProgram& fp = *c.fp;
+  const int d = fp.dim;
+  double Q = 0.0;
+  for (int i = d - 1; i >= 0; --i) {   // y = U^-1 r
+    double y = LD(r.X + i) - fp.offset[i] - lc->mu[i];
+    for (int j = i + 1; j < d; ++j) y -= lc->U[i * MAX_DIM + j] * LD(r.Y + j);
+    y /= lc->U[i * MAX_DIM + i];
+    LD(r.Y + i) = y;
+    Q += y * y;
+  }
+  for (int i = 0; i < d; ++i) {        // q = U^-T y = S^-1 r
+    double q = LD(r.Y + i);
+    for (int j = 0; j < i; ++j) q -= lc->U[j * MAX_DIM + i] * LD(r.Q + j);
+    q /= lc->U[i * MAX_DIM + i];
+    LD(r.Q + i) = q;
+  }
+  // logp_latent = lognorm + f(Q):  Gauss f = -Q/2,  Student-t f = -(nu+p)/2 log(1+Q/nu)
+  double m2f1;  // -2 f'(Q)
+  const bool gauss = (fp.latent == VMCPDE_LATENT_GAUSS);
+  const double nu = lc->nu, p = (double)d;
+  if (gauss) m2f1 = 1.0;
+  else m2f1 = (nu + p) / (nu + Q);
+  for (int i = 0; i < d; ++i) LD(r.G + i) = -m2f1 * LD(r.Q + i);
+  if (JT != nullptr && active) {
+    int k = 0;
+    for (int i = 0; i < d; ++i) {
+      const double qi = LD(r.Q + i);
+      for (int j = i + 1; j < d; ++j, ++k)   // dQ/dU_ij = -2 q_i y_j ; row-major strict upper triangle (util.py:23-24)
+        JT[(int64_t)(fp.off_L + k) * ldj + n] = m2f1 * qi * LD(r.Y + j);
+      // U_ii = exp(L_diag_i); Gauss also carries -1/2 log det S = -sum L_diag (net.py:20)
+      JT[(int64_t)(fp.off_Ldiag + i) * ldj + n] = m2f1 * qi * LD(r.Y + i) * lc->U[i * MAX_DIM + i] - (gauss ? 1.0 : 0.0);
+      JT[(int64_t)(fp.off_mu + i) * ldj + n] = m2f1 * qi;
+    }
+    if (!gauss) {
+      const double dnu = -0.5 * log1p(Q / nu) + 0.5 * (nu + p) * Q / (nu * (nu + Q));
+      JT[(int64_t)fp.off_dist * ldj + n] = lc->dlognorm_dtau + (nu - 1.0) * dnu;   // nu = exp(tau)+1 (net.py:32)
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void flow_eval_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
+                                                      const double* __restrict__ th, const double* __restrict__ x,
+                                                      int64_t N, const double* __restrict__ dirs, int n_dirs,
+                                                      double* __restrict__ logp, double* __restrict__ g,
+                                                      double* __restrict__ hv, double* __restrict__ JT, int64_t ldj,
+                                                      int lanes, Regions r) {
+  extern __shared__ double lds[];
+  Ctx c;
+  c.lds = lds;
+  c.lanes = lanes;
+  c.lane = threadIdx.x;
+  c.th = th;
+  c.fp = fp;
+  if ((int)threadIdx.x >= lanes) return;  // no barriers are used: one wave per workgroup
+  const int d = fp->dim;
+  const int64_t n = (int64_t)blockIdx.x * lanes + threadIdx.x;
+  const bool active = n < N;
+  const int64_t nn = active ? n : (N - 1);
+
+  double lp_val = 0.0;
+  if (n_dirs > 0 && hv != nullptr) {
+    for (int k = 0; k < n_dirs; ++k) {
+      for (int i = 0; i < d; ++i) {
+        LD(r.X + i) = x[nn * d + i];
+        LD(r.X + d + i) = dirs[k * d + i];
+        LD(r.X + 2 * d + i) = 0.0;
+      }
+      double lj[3] = {0, 0, 0}, lp[3];
+      for (int s = 0; s < fp->n_half; ++s) halfstep_forward<3>(c, fp->hs[s], r, lj);
+      latent_forward<3>(c, lc, r, r.X, lp);
+      lp_val = lp[0] + lj[0];
+      if (active) hv[n * n_dirs + k] = lp[2] + lj[2];
+    }
+  } else {
+    for (int i = 0; i < d; ++i) LD(r.X + i) = x[nn * d + i];
+    double lj[1] = {0}, lp[1];
+    for (int s = 0; s < fp->n_half; ++s) halfstep_forward<1>(c, fp->hs[s], r, lj);
+    latent_forward<1>(c, lc, r, r.X, lp);
+    lp_val = lp[0] + lj[0];
+  }
+  if (logp != nullptr && active) logp[n] = lp_val;
+  if (g == nullptr && JT == nullptr) return;
+
+  // reverse sweep: X currently holds z
+  latent_backward(c, lc, r, JT, ldj, n, active);
+  for (int s = fp->n_half - 1; s >= 0; --s) halfstep_backward(c, fp->hs[s], r, JT, ldj, n, active);
+  if (g != nullptr && active)
+    for (int i = 0; i < d; ++i) g[n * d + i] = LD(r.G + i);
+}
+
+// var_state.py:33 / net.py:214-217: (y, latent(x_in - offset) - log_jac) for either direction.
+__global__ __launch_bounds__(64) void flow_sample_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
+                                                        const double* __restrict__ th, const double* __restrict__ zin,
+                                                        int64_t N, int inv, double* __restrict__ xout,
+                                                        double* __restrict__ logp, int lanes, Regions r) {
+  extern __shared__ double lds[];
+  Ctx c;
+  c.lds = lds;
+  c.lanes = lanes;
+  c.lane = threadIdx.x;
+  c.th = th;
+  c.fp = fp;
+  if ((int)threadIdx.x >= lanes) return;
+  const int d = fp->dim;
+  const int64_t n = (int64_t)blockIdx.x * lanes + threadIdx.x;
+  const bool active = n < N;
+  const int64_t nn = active ? n : (N - 1);
+  for (int i = 0; i < d; ++i) LD(r.X + i) = zin[nn * d + i];
+  double lp[1];
+  latent_forward<1>(c, lc, r, r.X, lp);   // density of the INPUT point (net.py:215)
+  double lj = 0.0;
+  if (inv) {
+    for (int s = fp->n_half - 1; s >= 0; --s) halfstep_inverse(c, fp->hs[s], r, lj);
+  } else {
+    double ljv[1] = {0};
+    for (int s = 0; s < fp->n_half; ++s) halfstep_forward<1>(c, fp->hs[s], r, ljv);
+    lj = ljv[0];
+  }
+  if (active) {
+    for (int i = 0; i < d; ++i) xout[n * d + i] = LD(r.X + i);
+    if (logp != nullptr) logp[n] = lp[0] - lj;   // net.py:217
+  }
+}
+
+__device__ double digamma(double x) {
+  double r = 0.0;
+  while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+  const double f = 1.0 / (x * x);
+  // asymptotic series: ln x - 1/2x - sum B_2k / (2k x^2k)
+  const double t = f * (-1.0 / 12.0 + f * (1.0 / 120.0 + f * (-1.0 / 252.0 + f * (1.0 / 240.0 + f * (-1.0 / 132.0
+                   + f * (691.0 / 32760.0 + f * (-1.0 / 12.0)))))));
+  return r + log(x) - 0.5 / x + t;
+}
+
+// util.py:21-26 + net.py:18-20, 32-36: everything that depends on theta but not on the sample.
+__global__ void latent_prepare_kernel(const FlowProgram* __restrict__ fp, const double* __restrict__ th, LatentCache* __restrict__ lc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int d = fp->dim;
+  int k = 0;
+  double logdet = 0.0;
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < d; ++j) lc->U[i * MAX_DIM + j] = 0.0;
+  for (int i = 0; i < d; ++i) {
+    for (int j = i + 1; j < d; ++j, ++k) lc->U[i * MAX_DIM + j] = th[fp->off_L + k];
+    lc->U[i * MAX_DIM + i] = exp(th[fp->off_Ldiag + i]);
+    logdet += 2.0 * th[fp->off_Ldiag + i];
+    lc->mu[i] = th[fp->off_mu + i];
+  }
+  // S = U U^T, C = lower Cholesky factor of S (what jax.random.multivariate_normal(method='cholesky') applies, sampler.py:26)
+  for (int i = 0; i < d; ++i) {
+    for (int j = 0; j <= i; ++j) {
+      double s = 0.0;
+      for (int m = 0; m < d; ++m) s += lc->U[i * MAX_DIM + m] * lc->U[j * MAX_DIM + m];
+      for (int m = 0; m < j; ++m) s -= lc->C[i * MAX_DIM + m] * lc->C[j * MAX_DIM + m];
+      lc->C[i * MAX_DIM + j] = (i == j) ? sqrt(s) : s / lc->C[j * MAX_DIM + j];
+    }
+    for (int j = i + 1; j < d; ++j) lc->C[i * MAX_DIM + j] = 0.0;
+  }
+  lc->logdetS = logdet;
+  const double p = (double)d;
+  if (fp->latent == VMCPDE_LATENT_GAUSS) {
+    lc->nu = 0.0;
+    lc->lognorm = -0.5 * (p * log(2.0 * M_PI) + logdet);
+    lc->dlognorm_dtau = 0.0;
+  } else {
+    const double nu = exp(th[fp->off_dist]) + 1.0;
+    lc->nu = nu;
+    lc->lognorm = lgamma(0.5 * (nu + p)) - lgamma(0.5 * nu) - 0.5 * p * log(nu * M_PI);
+    lc->dlognorm_dtau = (nu - 1.0) * (0.5 * digamma(0.5 * (nu + p)) - 0.5 * digamma(0.5 * nu) - 0.5 * p / nu);
+  }
+}
+
+// sampler.py:25-34,86 with injected draws: z = mu + C n (* sqrt(nu/chi2)) + offset
+__global__ void latent_from_normals_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
+                                           const double* __restrict__ normals, const double* __restrict__ chi2,
+                                           int64_t N, double* __restrict__ z) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int d = fp->dim;
+  double scale = 1.0;
+  if (fp->latent == VMCPDE_LATENT_STUDENT_T) scale = sqrt(lc->nu / chi2[n]);
+  for (int i = 0; i < d; ++i) {
+    double y = 0.0;
+    for (int j = 0; j <= i; ++j) y += lc->C[i * MAX_DIM + j] * normals[n * d + j];
+    z[n * d + i] = scale * y + lc->mu[i] + fp->offset[i];
+  }
+}
+
+// evolutionEq.py:84-119.  hv column conventions are documented in vmcpde.h.
+__global__ void rhs_kernel(vmcpde_eq_consts c, int d, const double* __restrict__ x, const double* __restrict__ g,
+                           const double* __restrict__ hv, int n_dirs, const double* __restrict__ Dmat, double t,
+                           int64_t N, double* __restrict__ eloc) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const double* xn = x + n * d;
+  const double* gn = g + n * d;
+  const double* hn = hv ? hv + n * n_dirs : nullptr;
+  double e = 0.0;
+  switch (c.kind) {
+    case VMCPDE_EQ_DIFFUSION:
+    case VMCPDE_EQ_DIFFUSION_DRIFT: {
+      double g2 = 0.0, tr = 0.0, gs = 0.0;
+      for (int i = 0; i < d; ++i) { g2 += gn[i] * gn[i]; tr += hn[i]; gs += gn[i]; }
+      e = c.D * (g2 + tr);                                        // :86
+      if (c.kind == VMCPDE_EQ_DIFFUSION_DRIFT) e += c.mu * gs;    // :91-92
+    } break;
+    case VMCPDE_EQ_DIFFUSION_ANISOTROPIC: {
+      double q = 0.0, tr = 0.0;
+      for (int i = 0; i < d; ++i) {
+        double r = 0.0;
+        for (int j = 0; j < d; ++j) r += Dmat[i * d + j] * gn[j];
+        q += gn[i] * r;
+      }
+      for (int k = 0; k < n_dirs; ++k) tr += hn[k];   // tr(H D) = sum_k l_k^T H l_k with D = L L^T
+      e = q + tr;                                      // :98-99
+    } break;
+    case VMCPDE_EQ_ADVECTION_PAPER: {                 // :23-27, :104
+      const double cs = cos(M_PI * t / c.T);
+      const double X = xn[0], Y = xn[1];
+      const double sx = sin(M_PI * X), sy = sin(M_PI * Y);
+      const double v0 = -sx * sx * sin(2.0 * M_PI * Y) * cs;
+      const double v1 = sy * sy * sin(2.0 * M_PI * X) * cs;
+      e = -(gn[0] * v0 + gn[1] * v1);
+    } break;
+    case VMCPDE_EQ_ADVECTION_HAMILTONIAN:
+    case VMCPDE_EQ_ADVECTION_HAMILTONIAN_WDISS: {
+      // v = kron(I,[[0,1],[-1,0]]) grad H, H = m w^2/2 sum x^2 + sum p^2/(2m) + lam sum x^4 (:30-45, uncoupled)
+      double adv = 0.0;
+      for (int i = 0; i + 1 < d; i += 2) {
+        const double q = xn[i], p = xn[i + 1];
+        const double dHdq = c.m * c.omega * c.omega * q + 4.0 * c.lam * q * q * q;
+        const double dHdp = p / c.m;
+        adv += gn[i] * dHdp + gn[i + 1] * (-dHdq);
+      }
+      e = -adv;                                        // :79
+      if (c.kind == VMCPDE_EQ_ADVECTION_HAMILTONIAN_WDISS) {
+        double g2 = 0.0, tr = 0.0, xg = 0.0;
+        int k = 0;
+        for (int i = 1; i < d; i += 2, ++k) { g2 += gn[i] * gn[i]; tr += hn[k]; xg += xn[i] * gn[i]; }
+        e += c.m * c.gamma * c.T * (g2 + tr) + c.gamma * xg;   // :113-117
+      }
+    } break;
+    default: break;
+  }
+  eloc[n] = e;
+}
+
+int pick_lanes(int total_units, int* lds_bytes) {
+  // largest power-of-two sample count per wave whose per-lane vectors fit in LDS; prefer two waves per CU
+  const int LDS_CU = 160 * 1024;
+  int lanes = 64;
+  while (lanes > 8 && (int64_t)total_units * lanes * 8 > LDS_CU / 2) lanes >>= 1;
+  while (lanes > 1 && (int64_t)total_units * lanes * 8 > LDS_CU) lanes >>= 1;
+  *lds_bytes = total_units * lanes * 8;
+  return lanes;
+}
+
+}  // namespace
+
+extern "C" int vmcpde_flow_eval_config(const vmcpde_model* m, int n_dirs, int* lanes, int* lds_bytes) {
+  VMC_REQUIRE(m, "null model");
+  (void)n_dirs;
+  Regions r = make_regions(m->host);
+  int bytes = 0;
+  int l = pick_lanes(r.total, &bytes);
+  if (lanes) *lanes = l;
+  if (lds_bytes) *lds_bytes = bytes;
+  return 0;
+}
+
+int vmcpde_prepare_latent_internal(vmcpde_model* m, const double* theta, hipStream_t st) {
+  hipLaunchKernelGGL(latent_prepare_kernel, dim3(1), dim3(64), 0, st, m->dev, theta, m->cache);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const double* x, int64_t n_samples,
+                                const double* dirs, int32_t n_dirs, double* logp, double* g, double* hv,
+                                double* JT, int64_t ldj, void* stream) {
+  VMC_REQUIRE(m && theta && x, "vmcpde_flow_eval: null argument");
+  VMC_REQUIRE(n_samples >= 0, "negative sample count");
+  VMC_REQUIRE(n_dirs >= 0 && n_dirs <= VMCPDE_MAX_DIRS, "n_dirs %d outside [0,%d]", n_dirs, VMCPDE_MAX_DIRS);
+  VMC_REQUIRE(n_dirs == 0 || (dirs && hv), "directions given without dirs/hv buffers");
+  VMC_REQUIRE(JT == nullptr || ldj >= n_samples, "ldj %lld < n_samples %lld", (long long)ldj, (long long)n_samples);
+  if (n_samples == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = vmcpde_prepare_latent_internal(m, theta, st)) return rc;
+  Regions r = make_regions(m->host);
+  int bytes = 0;
+  const int lanes = pick_lanes(r.total, &bytes);
+  VMC_REQUIRE(bytes <= 160 * 1024, "network too wide for the LDS-resident flow kernel (%d B per sample lane)", r.total * 8);
+  if (bytes > 64 * 1024)
+    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)flow_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  const int64_t grid = (n_samples + lanes - 1) / lanes;
+  hipLaunchKernelGGL(flow_eval_kernel, dim3((unsigned)grid), dim3(64), bytes, st, m->dev, m->cache, theta, x, n_samples,
+                     dirs, (hv ? n_dirs : 0), logp, g, hv, JT, ldj, lanes, r);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vmcpde_flow_sample(vmcpde_model* m, const double* theta, const double* z, int64_t n_samples, int inv,
+                                  double* x, double* logp, void* stream) {
+  VMC_REQUIRE(m && theta && z && x, "vmcpde_flow_sample: null argument");
+  if (n_samples <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = vmcpde_prepare_latent_internal(m, theta, st)) return rc;
+  Regions r = make_regions(m->host);
+  int bytes = 0;
+  const int lanes = pick_lanes(r.total, &bytes);
+  VMC_REQUIRE(bytes <= 160 * 1024, "network too wide for the LDS-resident flow kernel");
+  if (bytes > 64 * 1024)
+    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)flow_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  const int64_t grid = (n_samples + lanes - 1) / lanes;
+  hipLaunchKernelGGL(flow_sample_kernel, dim3((unsigned)grid), dim3(64), bytes, st, m->dev, m->cache, theta, z, n_samples,
+                     inv, x, logp, lanes, r);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vmcpde_latent_from_normals(vmcpde_model* m, const double* theta, const double* normals, const double* chi2,
+                                          int64_t n_samples, double* z, void* stream) {
+  VMC_REQUIRE(m && theta && normals && z, "vmcpde_latent_from_normals: null argument");
+  VMC_REQUIRE(m->host.latent != VMCPDE_LATENT_STUDENT_T || chi2, "Student-t latent needs chi2 draws");
+  if (n_samples <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = vmcpde_prepare_latent_internal(m, theta, st)) return rc;
+  const int64_t grid = (n_samples + 255) / 256;
+  hipLaunchKernelGGL(latent_from_normals_kernel, dim3((unsigned)grid), dim3(256), 0, st, m->dev, m->cache, normals, chi2,
+                     n_samples, z);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vmcpde_rhs(const vmcpde_eq_consts* c, int32_t dim, const double* x, const double* g, const double* hv,
+                          int32_t n_dirs, const double* Dmat, double t, int64_t n_samples, double* eloc, void* stream) {
+  VMC_REQUIRE(c && x && g && eloc, "vmcpde_rhs: null argument");
+  VMC_REQUIRE(dim >= 2 && dim <= VMCPDE_MAX_DIM, "bad dim");
+  switch (c->kind) {
+    case VMCPDE_EQ_DIFFUSION:
+    case VMCPDE_EQ_DIFFUSION_DRIFT:
+      VMC_REQUIRE(hv && n_dirs == dim, "diffusion needs hv along the %d coordinate axes", dim);
+      break;
+    case VMCPDE_EQ_DIFFUSION_ANISOTROPIC:
+      VMC_REQUIRE(hv && n_dirs >= 1 && Dmat, "anisotropic diffusion needs hv along the columns of chol(D) and D");
+      break;
+    case VMCPDE_EQ_ADVECTION_PAPER:
+      VMC_REQUIRE(dim == 2, "advection_paper is two-dimensional (evolutionEq.py:24)");
+      break;
+    case VMCPDE_EQ_ADVECTION_HAMILTONIAN:
+      VMC_REQUIRE(dim % 2 == 0, "phase space needs even dim");
+      break;
+    case VMCPDE_EQ_ADVECTION_HAMILTONIAN_WDISS:
+      VMC_REQUIRE(dim % 2 == 0 && hv && n_dirs == dim / 2, "Kramers needs hv along the %d momentum axes", dim / 2);
+      break;
+    default:
+      VMC_REQUIRE(false, "unknown equation kind %d", c->kind);
+  }
+  if (n_samples <= 0) return 0;
+  const int64_t grid = (n_samples + 255) / 256;
+  hipLaunchKernelGGL(rhs_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *c, dim, x, g, hv, n_dirs, Dmat, t,
+                     n_samples, eloc);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,287 @@
+// Gram matrix S = <O~ O~^T> and force vector F = <E~ O~> of the TDVP equation on fp64 MFMA.
+//
+// Replaces tdvp.py:36-52 (get_tdvp_equation), the pmapped helpers tdvp.py:30-33 (J7-J9) and the reducers
+// mpi_wrapper.py:21-25, 61-63, 129-274 (J11-J13).  The reference materialises four more N x P arrays (centred
+// O, E*O, logp*O) and runs two un-symmetrised N x P x P GEMMs; here the centring (and the optional per-sample
+// weight) is fused into the operand staging of ONE syrk-shaped kernel over the lower-triangle tiles.
+//
+// Data layout: JT[p][n] (parameter-major, K = sample index contiguous) -- both MFMA operands of
+// S[i][j] = sum_n JT[i][n] JT[j][n] are then "K-contiguous rows", i.e. a TN GEMM with A = B = JT.
+//
+// gfx950 mapping: v_mfma_f64_16x16x4_f64 (one f64 of A and of B per lane: A[i = lane&15][k = lane>>4],
+// B[k = lane>>4][j = lane&15]; C/D: col = lane&15, row = (lane>>4) + 4*reg).  Workgroup = 4 waves (2x2), tile
+// 128x128, wave tile 64x64 = 4x4 MFMA blocks = 128 accumulator VGPRs, so two workgroups are resident per CU
+// (two waves per SIMD keep the matrix pipe busy while the partner stages).  K-step 16: operands are staged
+// global -> registers (prefetched one K-step ahead, centred/weighted in flight) -> LDS rows of 18 doubles
+// (144 B pitch: the 16 rows x 2 k-columns a ds_read_b64 wave-instruction touches fall on 64 distinct banks).
+// Split-K over the sample axis gives >= 8 work units per CU-slot; partial tiles go to a workspace and are summed by
+// a deterministic second kernel (no atomics: bitwise reproducible, which the replicated multi-GPU solve relies on).
+#include "mfma_tile.hpp"
+
+using namespace vmcpde;
+
+namespace {
+
+struct GramPlan {
+  int nb;          // row blocks of 128
+  int ntiles;      // nb(nb+1)/2
+  int nsplit;      // split-K factor over samples
+  int64_t chunk;   // samples per split (multiple of BK)
+};
+
+GramPlan make_plan(int P, int64_t N) {
+  GramPlan g;
+  g.nb = (P + TILE - 1) / TILE;
+  g.ntiles = (int)tri_count(g.nb);
+  // aim at >= 8 rounds of the 512 resident workgroup slots (256 CUs x 2) so the tail round costs < 1/8,
+  // but keep each unit >= 64 K-steps so prologue/epilogue stay negligible
+  const int64_t ksteps = (N + BK - 1) / BK;
+  int64_t want = (8 * 512 + g.ntiles - 1) / g.ntiles;
+  int64_t maxsplit = ksteps / 64;
+  if (maxsplit < 1) maxsplit = 1;
+  int64_t ns = want < maxsplit ? want : maxsplit;
+  if (ns < 1) ns = 1;
+  if (ns > 64) ns = 64;
+  int64_t steps_per = (ksteps + ns - 1) / ns;
+  g.chunk = steps_per * BK;
+  g.nsplit = (int)((N + g.chunk - 1) / g.chunk);
+  if (g.nsplit < 1) g.nsplit = 1;
+  return g;
+}
+
+template <bool SCALE>
+__global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__ JT, int64_t ldj, int P, int64_t N,
+                                                      const double* __restrict__ c, const double* __restrict__ scale,
+                                                      int ntiles, int nsplit, int64_t chunk, int total_units,
+                                                      int units_per_xcd, double* __restrict__ out) {
+  extern __shared__ double lds[];
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2), so give each XCD
+  // a contiguous run of units = neighbouring tiles of the same sample chunk, whose operand panels overlap.
+  const int unit = (int)(blockIdx.x & 7) * units_per_xcd + (int)(blockIdx.x >> 3);
+  if (unit >= total_units) return;
+  const int split = unit / ntiles;
+  int ti, tj;
+  tri_decode(unit - split * ntiles, ti, tj);
+  const int64_t k0 = (int64_t)split * chunk;
+  const int64_t k1 = (k0 + chunk < N) ? (k0 + chunk) : N;
+  const int rowA0 = ti * TILE, rowB0 = tj * TILE;
+  const int rowsA = (P - rowA0 < TILE) ? (P - rowA0) : TILE;
+  const int rowsB = (P - rowB0 < TILE) ? (P - rowB0) : TILE;
+  double4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  tile_mainloop<SCALE>(acc, JT, ldj, rowA0, JT, ldj, rowB0, ti == tj, k0, k1, c, rowsA, c, rowsB, scale, lds);
+  tile_store(acc, out + ((int64_t)split * ntiles + (unit - split * ntiles)) * (TILE * TILE));
+}
+
+// packed[tile][e] = sum_split slabs[split][tile][e]   (fixed order -> deterministic)
+__global__ void reduce_splits_kernel(const double* __restrict__ slabs, int nsplit, int64_t per_split, double* __restrict__ packed) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (i >= per_split) return;
+  double2_t s = *reinterpret_cast<const double2_t*>(slabs + i);
+  for (int k = 1; k < nsplit; ++k) {
+    const double2_t v = *reinterpret_cast<const double2_t*>(slabs + (int64_t)k * per_split + i);
+    s.x += v.x;
+    s.y += v.y;
+  }
+  *reinterpret_cast<double2_t*>(packed + i) = s;
+}
+
+// tdvp.py:37-39,150: sums = { sum E, sum E^2, sum |E|, max E }
+__global__ __launch_bounds__(1024) void eloc_stats_kernel(const double* __restrict__ e, int64_t N, double* __restrict__ sums) {
+  __shared__ double sh[4][16];
+  double s = 0, s2 = 0, sa = 0, mx = -INFINITY;
+  for (int64_t i = threadIdx.x; i < N; i += blockDim.x) {
+    const double v = e[i];
+    s += v; s2 += v * v; sa += fabs(v); mx = fmax(mx, v);
+  }
+  s = wave_sum(s); s2 = wave_sum(s2); sa = wave_sum(sa);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[0][w] = s; sh[1][w] = s2; sh[2][w] = sa; sh[3][w] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, b = 0, cc = 0, m = -INFINITY;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { a += sh[0][k]; b += sh[1][k]; cc += sh[2][k]; m = fmax(m, sh[3][k]); }
+    sums[0] = a; sums[1] = b; sums[2] = cc; sums[3] = m;
+  }
+}
+
+// one workgroup per parameter row: rowsum[p] = sum_n (JT[p][n]-c[p]), rowdot[p] = sum_n (JT[p][n]-c[p]) (E_n - cE)
+__global__ __launch_bounds__(256) void row_moments_kernel(const double* __restrict__ JT, int64_t ldj, int64_t N,
+                                                         const double* __restrict__ e, const double* __restrict__ c,
+                                                         const double* __restrict__ cE_dev, double* __restrict__ rowsum,
+                                                         double* __restrict__ rowdot) {
+  __shared__ double sh[2][4];
+  const int p = blockIdx.x;
+  const double cp = c ? c[p] : 0.0;
+  const double cE = cE_dev ? cE_dev[0] : 0.0;
+  const double* __restrict__ row = JT + (int64_t)p * ldj;
+  double s = 0, sd = 0;
+  const int64_t N2 = N & ~(int64_t)1;
+  for (int64_t i = (int64_t)threadIdx.x * 2; i < N2; i += 512) {
+    const double2_t v = *reinterpret_cast<const double2_t*>(row + i);
+    const double2_t ev = *reinterpret_cast<const double2_t*>(e + i);
+    const double a = v.x - cp, b = v.y - cp;
+    s += a + b;
+    sd += a * (ev.x - cE) + b * (ev.y - cE);
+  }
+  if (threadIdx.x == 0 && N2 < N) {
+    const double a = row[N2] - cp;
+    s += a;
+    sd += a * (e[N2] - cE);
+  }
+  s = wave_sum(s); sd = wave_sum(sd);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[0][w] = s; sh[1][w] = sd; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    rowsum[p] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    rowdot[p] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+  }
+}
+
+// S[i][j] = packed/Ntot - delta_i delta_j ; optional second copy A = S + diag(shift * diag S) for the in-place Cholesky.
+// grid: (4, 4, ntiles) 32x32 sub-tiles; the mirrored block goes through an LDS transpose so both writes are coalesced.
+__global__ __launch_bounds__(256) void finalize_S_kernel(const double* __restrict__ packed, const double* __restrict__ rowsum,
+                                                        int P, double inv_n, double shift, double* __restrict__ S,
+                                                        int64_t lds_, double* __restrict__ A2, int64_t lda2) {
+  __shared__ double tr[32][33];
+  int ti, tj;
+  tri_decode(blockIdx.z, ti, tj);
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const double* __restrict__ tile = packed + (int64_t)blockIdx.z * (TILE * TILE);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = r0 + ty + 8 * q, cidx = c0 + tx;
+    const int gi = ti * TILE + r, gj = tj * TILE + cidx;
+    double v = 0.0;
+    if (gi < P && gj < P) {
+      v = tile[r * TILE + cidx] * inv_n - (rowsum[gi] * inv_n) * (rowsum[gj] * inv_n);
+      S[(int64_t)gi * lds_ + gj] = v;
+      if (A2) A2[(int64_t)gi * lda2 + gj] = (gi == gj) ? v + shift * v : v;
+    }
+    tr[ty + 8 * q][tx] = v;
+  }
+  if (ti == tj) return;   // the diagonal tile already holds both triangles (bitwise symmetric: same products, same order)
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int cidx = c0 + ty + 8 * q, r = r0 + tx;   // transposed: write S[gj][gi] with gi fastest
+    const int gi = ti * TILE + r, gj = tj * TILE + cidx;
+    if (gi < P && gj < P) {
+      const double v = tr[tx][ty + 8 * q];
+      S[(int64_t)gj * lds_ + gi] = v;
+      if (A2) A2[(int64_t)gj * lda2 + gi] = v;
+    }
+  }
+}
+
+// F = rowdot/N - delta*deltaE, mean = c + delta (tdvp.py:41,45)
+__global__ void finalize_F_kernel(const double* __restrict__ rowsum, const double* __restrict__ rowdot,
+                                  const double* __restrict__ sums, const double* __restrict__ c, const double* __restrict__ cE_dev,
+                                  int P, double inv_n, double* __restrict__ F, double* __restrict__ mean) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const double cE = cE_dev ? cE_dev[0] : 0.0;
+  const double deltaE = sums[0] * inv_n - cE;
+  const double delta = rowsum[p] * inv_n;
+  if (F) F[p] = rowdot[p] * inv_n - delta * deltaE;
+  if (mean) mean[p] = (c ? c[p] : 0.0) + delta;
+}
+
+}  // namespace
+
+extern "C" int64_t vmcpde_gram_packed_doubles(int32_t P) {
+  if (P <= 0) return 0;
+  const int nb = (P + TILE - 1) / TILE;
+  return tri_count(nb) * TILE * TILE;
+}
+
+extern "C" int64_t vmcpde_gram_workspace_bytes(int32_t P, int64_t n_samples) {
+  if (P <= 0 || n_samples <= 0) return 0;
+  GramPlan g = make_plan(P, n_samples);
+  return (int64_t)g.nsplit * g.ntiles * TILE * TILE * (int64_t)sizeof(double);
+}
+
+extern "C" int vmcpde_eloc_stats(const double* eloc, int64_t n_samples, double* sums, void* stream) {
+  VMC_REQUIRE(eloc && sums, "vmcpde_eloc_stats: null argument");
+  hipLaunchKernelGGL(eloc_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, eloc, n_samples, sums);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vmcpde_row_moments(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, const double* eloc,
+                                  const double* c, const double* cE_dev, double* rowsum, double* rowdot, void* stream) {
+  VMC_REQUIRE(JT && eloc && rowsum && rowdot, "vmcpde_row_moments: null argument");
+  VMC_REQUIRE(P >= 1 && n_samples >= 1 && ldj >= n_samples && (ldj % 2) == 0, "bad shape (ldj must be even and >= N)");
+  hipLaunchKernelGGL(row_moments_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, JT, ldj, n_samples, eloc, c, cE_dev, rowsum,
+                     rowdot);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vmcpde_gram(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, const double* c, const double* w,
+                           double* packed, void* workspace, int64_t workspace_bytes, void* stream) {
+  VMC_REQUIRE(JT && packed, "vmcpde_gram: null argument");
+  VMC_REQUIRE(P >= 1 && n_samples >= 1, "bad shape");
+  VMC_REQUIRE(ldj >= n_samples && (ldj % 2) == 0 && ldj < (1 << 22), "ldj must be even, >= n_samples and < 2^22");
+  VMC_REQUIRE((reinterpret_cast<uintptr_t>(JT) & 15) == 0, "JT must be 16-byte aligned");
+  GramPlan g = make_plan(P, n_samples);
+  const int64_t need = (int64_t)g.nsplit * g.ntiles * TILE * TILE * (int64_t)sizeof(double);
+  double* out = packed;
+  if (g.nsplit > 1) {
+    VMC_REQUIRE(workspace && workspace_bytes >= need, "gram workspace too small: need %lld bytes", (long long)need);
+    out = static_cast<double*>(workspace);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int total = g.ntiles * g.nsplit;
+  const int per_xcd = (total + 7) / 8;
+  const int grid = per_xcd * 8;
+  const size_t lds_bytes = TILE_LDS_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_set = true;
+  }
+  if (w)
+    hipLaunchKernelGGL(gram_kernel<true>, dim3(grid), dim3(256), lds_bytes, st, JT, ldj, P, n_samples, c, w, g.ntiles, g.nsplit,
+                       g.chunk, total, per_xcd, out);
+  else
+    hipLaunchKernelGGL(gram_kernel<false>, dim3(grid), dim3(256), lds_bytes, st, JT, ldj, P, n_samples, c, w, g.ntiles, g.nsplit,
+                       g.chunk, total, per_xcd, out);
+  VMC_CHECK_HIP(hipGetLastError());
+  if (g.nsplit > 1) {
+    const int64_t per_split = (int64_t)g.ntiles * TILE * TILE;
+    const int64_t threads = per_split / 2;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, out, g.nsplit, per_split,
+                       packed);
+    VMC_CHECK_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+extern "C" int vmcpde_gram_finalize(const double* packed, const double* rowsum, const double* rowdot, const double* sums,
+                                    const double* c, const double* cE_dev, int32_t P, double n_total, double diagonal_shift,
+                                    double* S, int64_t lds, double* A_shifted, int64_t lda, double* F, double* mean, void* stream) {
+  VMC_REQUIRE(packed && rowsum && S, "vmcpde_gram_finalize: null argument");
+  VMC_REQUIRE(P >= 1 && lds >= P && n_total > 0, "bad shape");
+  VMC_REQUIRE(!A_shifted || lda >= P, "bad lda");
+  VMC_REQUIRE((!F && !mean) || (rowdot && sums), "F/mean need rowdot and sums");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (P + TILE - 1) / TILE;
+  const double inv_n = 1.0 / n_total;
+  hipLaunchKernelGGL(finalize_S_kernel, dim3(4, 4, (unsigned)tri_count(nb)), dim3(256), 0, st, packed, rowsum, P, inv_n,
+                     diagonal_shift, S, lds, A_shifted, lda);
+  VMC_CHECK_HIP(hipGetLastError());
+  if (F || mean) {
+    hipLaunchKernelGGL(finalize_F_kernel, dim3((P + 255) / 256), dim3(256), 0, st, rowsum, rowdot, sums, c, cE_dev, P, inv_n, F, mean);
+    VMC_CHECK_HIP(hipGetLastError());
+  }
+  return 0;
+}

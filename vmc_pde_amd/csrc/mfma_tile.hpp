@@ -1,0 +1,212 @@
+// fp64 MFMA tile engine shared by the Gram (gram.hip) and the blocked Cholesky (solve.hip) kernels.
+//
+// Computes one 128x128 tile of C = A * B^T for row-major operands whose K index is contiguous ("TN" GEMM):
+//     C[i][j] = sum_k (A[rowA0 + i][k] - shiftA[i]) * sc[k] * (B[rowB0 + j][k] - shiftB[j]) * sc[k]
+// on v_mfma_f64_16x16x4_f64 (lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; the C/D block holds
+// col = l&15, row = (l>>4) + 4*reg -- the f64 layout differs from every other MFMA dtype, cdna_hip_programming.md:159-162).
+// Workgroup = 256 threads = 4 waves as 2x2, 64x64 per wave = 4x4 MFMA blocks = 128 accumulator VGPRs, so two
+// workgroups fit per CU (two waves per SIMD: one feeds the matrix pipe while its partner stages).
+// K-step BK = 16: operands go global -> registers (issued one K-step ahead, centred / scaled in flight) -> LDS rows of
+// 18 doubles (pitch 144 B: the 16 rows x 2 k-columns one ds_read_b64 half-wave touches fall on 32 distinct bank pairs).
+//
+// Contract (checked by the host wrappers): operand matrices have all 128 rows of every tile allocated (row padding
+// is zero-filled by the owner), row pitch even (16-B aligned double2 loads), 128 * pitch * 8 < 2^32.
+#pragma once
+#include "common.hpp"
+
+namespace vmcpde {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+constexpr int TILE = VMCPDE_GRAM_TILE;  // 128
+constexpr int BK = 16;
+constexpr int LDP = BK + 2;             // LDS row pitch in doubles
+constexpr int TILE_LDS = TILE * LDP;    // doubles per staged operand tile
+constexpr int TILE_LDS_DOUBLES = 4 * TILE_LDS + 2 * TILE;   // 2 operands x 2 buffers + the two shift vectors
+constexpr size_t TILE_LDS_BYTES = TILE_LDS_DOUBLES * sizeof(double);   // 75,776 B -> two workgroups per CU
+
+__host__ __device__ inline int64_t tri_count(int nb) { return (int64_t)nb * (nb + 1) / 2; }
+
+__device__ __forceinline__ void tri_decode(int t, int& ti, int& tj) {
+  int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((int64_t)(i + 1) * (i + 2) / 2 <= t) ++i;
+  while ((int64_t)i * (i + 1) / 2 > t) --i;
+  ti = i;
+  tj = t - i * (i + 1) / 2;
+}
+
+// Global -> register staging of one 128 x BK operand tile (rows = parameters, columns = samples):
+// thread t, slot q: row = q*32 + t/8, k-pair = (t%8)*2 -- eight lanes cover one 128-B row segment.
+// `tile` is wave-uniform (row block base + k), `off` the per-thread element offset of slot 0; slots are 32 rows apart.
+// stage_load only ISSUES the loads (raw values stay in flight behind the MFMAs of the current K-step);
+// stage_store centres / scales them and writes the LDS image, so the vmcnt wait lands after the matrix work.
+struct Staged {
+  double2_t v[4];
+  double2_t sc;
+};
+
+template <bool SCALE, bool TAIL>
+__device__ __forceinline__ void stage_load(Staged& r, const double* __restrict__ tile, uint32_t off, uint32_t slot_stride,
+                                           const double* __restrict__ scale_k /* scale + k, or null */, int64_t krem) {
+  const int t = threadIdx.x;
+  const int kp = (t & 7) * 2;
+  if (SCALE) {
+    if (!TAIL) r.sc = *reinterpret_cast<const double2_t*>(scale_k + kp);
+    else { r.sc.x = (kp < krem) ? scale_k[kp] : 0.0; r.sc.y = (kp + 1 < krem) ? scale_k[kp + 1] : 0.0; }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (!TAIL) {
+      r.v[q] = *reinterpret_cast<const double2_t*>(tile + off + q * slot_stride);
+    } else {
+      const double* p = tile + off + q * slot_stride;
+      r.v[q].x = (kp < krem) ? p[0] : 0.0;
+      r.v[q].y = (kp + 1 < krem) ? p[1] : 0.0;
+    }
+  }
+}
+
+template <bool SCALE, bool TAIL>
+__device__ __forceinline__ void stage_store(const Staged& r, double* __restrict__ lds, int tile_off, const double (&sh)[4], int64_t krem) {
+  const int t = threadIdx.x;
+  const int kp = (t & 7) * 2;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = q * 32 + (t >> 3);
+    const double s = sh[q];
+    double2_t v = r.v[q];
+    v.x -= s;
+    v.y -= s;
+    if (TAIL) {   // columns beyond the sample count must contribute 0, not -shift
+      if (!(kp < krem)) v.x = 0.0;
+      if (!(kp + 1 < krem)) v.y = 0.0;
+    }
+    if (SCALE) { v.x *= r.sc.x; v.y *= r.sc.y; }
+    *reinterpret_cast<double2_t*>(lds + tile_off + row * LDP + kp) = v;
+  }
+}
+
+// acc[i][j] += A_tile(64 rows of this wave) * B_tile(64 rows of this wave)^T over one staged K-step
+__device__ __forceinline__ void mma_kstep(double4_t (&acc)[4][4], const double* __restrict__ lds, int offAs, int offBs,
+                                          int wr, int wc) {
+  const int lane = threadIdx.x & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  const double* __restrict__ ap = lds + offAs + (64 * wr + lr) * LDP + lk;
+  const double* __restrict__ bp = lds + offBs + (64 * wc + lr) * LDP + lk;
+#pragma unroll
+  for (int k4 = 0; k4 < BK / 4; ++k4) {
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = ap[16 * i * LDP + 4 * k4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = bp[16 * j * LDP + 4 * k4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+// Main loop of one tile.  alias: the B tile is the A tile (diagonal tile of a syrk) -> only A is staged.
+// shiftA/shiftB may be null (no centring); they are read for `nshift*` valid rows and zero-extended.
+// lds: TILE_LDS_DOUBLES doubles.
+template <bool SCALE>
+__device__ __forceinline__ void tile_mainloop(double4_t (&acc)[4][4], const double* __restrict__ A, int64_t lda, int rowA0,
+                                              const double* __restrict__ B, int64_t ldb, int rowB0, bool alias, int64_t k0,
+                                              int64_t k1, const double* __restrict__ shiftA, int nshiftA,
+                                              const double* __restrict__ shiftB, int nshiftB, const double* __restrict__ scale,
+                                              double* __restrict__ lds) {
+  const int t = threadIdx.x;
+  const int wave = t >> 6, wr = wave >> 1, wc = wave & 1;
+  // LDS map (doubles): A buffers at 0 and 2*TILE_LDS, B buffers at TILE_LDS and 3*TILE_LDS, shifts behind them.
+  // Offsets stay integers so every access keeps the LDS address space (pointer selects degrade to flat_*).
+  double* shA = lds + 4 * TILE_LDS;
+  double* shB = shA + TILE;
+  if (t < TILE) {
+    shA[t] = (shiftA != nullptr && t < nshiftA) ? shiftA[rowA0 + t] : 0.0;
+    shB[t] = (shiftB != nullptr && t < nshiftB) ? shiftB[rowB0 + t] : 0.0;
+  }
+  __syncthreads();
+  const double* __restrict__ tA = A + (int64_t)rowA0 * lda;
+  const double* __restrict__ tB = B + (int64_t)rowB0 * ldb;
+  const uint32_t offA = (uint32_t)(t >> 3) * (uint32_t)lda + (uint32_t)(t & 7) * 2u, strideA = 32u * (uint32_t)lda;
+  const uint32_t offB = (uint32_t)(t >> 3) * (uint32_t)ldb + (uint32_t)(t & 7) * 2u, strideB = 32u * (uint32_t)ldb;
+  const int64_t nfull = (k1 - k0) / BK;          // full K-steps
+  const int64_t tail = (k1 - k0) - nfull * BK;   // ragged remainder (N not a multiple of 16)
+  double SHA[4], SHB[4];   // this thread's four row shifts per operand, loop-invariant
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    SHA[q] = shA[q * 32 + (t >> 3)];
+    SHB[q] = shB[q * 32 + (t >> 3)];
+  }
+  const int boff = alias ? 0 : TILE_LDS;
+  Staged ra, rb;
+
+  // prologue: stage the first K-step
+  if (nfull > 0) {
+    stage_load<SCALE, false>(ra, tA + k0, offA, strideA, SCALE ? scale + k0 : nullptr, BK);
+    if (!alias) stage_load<SCALE, false>(rb, tB + k0, offB, strideB, SCALE ? scale + k0 : nullptr, BK);
+    stage_store<SCALE, false>(ra, lds, 0, SHA, BK);
+    if (!alias) stage_store<SCALE, false>(rb, lds, TILE_LDS, SHB, BK);
+  } else {
+    stage_load<SCALE, true>(ra, tA + k0, offA, strideA, SCALE ? scale + k0 : nullptr, tail);
+    if (!alias) stage_load<SCALE, true>(rb, tB + k0, offB, strideB, SCALE ? scale + k0 : nullptr, tail);
+    stage_store<SCALE, true>(ra, lds, 0, SHA, tail);
+    if (!alias) stage_store<SCALE, true>(rb, lds, TILE_LDS, SHB, tail);
+  }
+  __syncthreads();
+  int cur = 0;
+  // steady state: every step issues the next FULL step's loads, runs the 64 MFMAs of the current one, then stages
+  int64_t k = k0;
+  for (int64_t s = 0; s + 1 < nfull; ++s, k += BK) {
+    stage_load<SCALE, false>(ra, tA + k + BK, offA, strideA, SCALE ? scale + k + BK : nullptr, BK);
+    if (!alias) stage_load<SCALE, false>(rb, tB + k + BK, offB, strideB, SCALE ? scale + k + BK : nullptr, BK);
+    mma_kstep(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc);
+    __builtin_amdgcn_sched_barrier(0);   // keep the centring + ds_write (and their vmcnt wait) behind the MFMAs
+    stage_store<SCALE, false>(ra, lds, (cur ^ 1) * 2 * TILE_LDS, SHA, BK);
+    if (!alias) stage_store<SCALE, false>(rb, lds, (cur ^ 1) * 2 * TILE_LDS + TILE_LDS, SHB, BK);
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (nfull > 0) {   // last full step; the ragged tail (if any) is staged behind it
+    if (tail > 0) {
+      stage_load<SCALE, true>(ra, tA + k + BK, offA, strideA, SCALE ? scale + k + BK : nullptr, tail);
+      if (!alias) stage_load<SCALE, true>(rb, tB + k + BK, offB, strideB, SCALE ? scale + k + BK : nullptr, tail);
+    }
+    mma_kstep(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc);
+    if (tail > 0) {
+      stage_store<SCALE, true>(ra, lds, (cur ^ 1) * 2 * TILE_LDS, SHA, tail);
+      if (!alias) stage_store<SCALE, true>(rb, lds, (cur ^ 1) * 2 * TILE_LDS + TILE_LDS, SHB, tail);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (tail > 0) {
+    mma_kstep(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc);
+    __syncthreads();
+  }
+}
+
+// C/D element (i, j, reg r) of this lane sits at row 64*wr + 16*i + (lane>>4) + 4*r, col 64*wc + 16*j + (lane&15).
+__device__ __forceinline__ void tile_store(const double4_t (&acc)[4][4], double* __restrict__ out /* [128][128] */) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 64 * wr + 16 * i + (lane >> 4) + 4 * r;
+        const int col = 64 * wc + 16 * j + (lane & 15);
+        out[row * TILE + col] = acc[i][j][r];
+      }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+}  // namespace vmcpde

@@ -1,0 +1,310 @@
+"""TDVP / stochastic-reconfiguration engine (reference: vmc_fluids/tdvp.py).
+
+`TDVP(useSNR, snrTol, svdTol, diagonalShift, diagonalizeOnDevice)` and `__call__(netParameters, t, psi, evolutionEq,
+**rhsArgs) -> (update, info)` keep the reference's call surface (tdvp.py:20-26, 96-164) and publish the same
+attributes (S0, F0, SExp, S, ev, V, VtF, snr, rhoVar, ElocMean, ElocMeanAbs, ElocVar, solverResidual, tdvp_error).
+
+What runs underneath (all on the GPU, all fp64):
+  * Eloc statistics, row moments, ONE fp64-MFMA syrk with fused centring (csrc/gram.hip) instead of the reference's
+    four N x P temporaries and two full GEMMs (tdvp.py:40-47);
+  * multi-GPU: every rank processes its shard of the samples and ONE packed buffer
+    [ Gram tiles | sum O | sum E~O | sum E, sum E^2, sum |E| | n ] is all-reduced (RCCL) per step; the solve is replicated;
+  * solve: `solver="cholesky"` -- in-place blocked Cholesky of S + diagonalShift*diag(S) on the MFMA tile engine
+    (csrc/solve.hip); `solver="eigh"` -- the reference's spectral pseudo-inverse (tdvp.py:57-94), with eigh from
+    LAPACK on the host (diagonalizeOnDevice=False, as tdvp.py:61-64) or rocSOLVER on the device.
+  * `SExp`, `rhoVar`, `snr` are evaluated lazily from the retained Jacobian (weighted Gram), since only AdaptiveHeun
+    (stepper.py:71) and useSNR / the driver's logging (main.py:187) read them.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from . import global_defs
+from . import mpi_wrapper as mpi
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+@dataclass
+class TDVP:
+    useSNR: bool = False
+    snrTol: float = 2e0
+    svdTol: float = 1e-11
+    diagonalShift: float = 0
+    diagonalizeOnDevice: bool = False
+    solver: str = "auto"          # "eigh" (reference pseudo-inverse), "cholesky", or "auto" (cholesky iff diagonalShift > 1e-10)
+    centering: str = "auto"       # "exact": global means before the Gram (one extra tiny all-reduce when world_size > 1)
+                                  # "lagged": previous call's global mean as shift -> a single all-reduce per step
+
+    def __post_init__(self):
+        self._buf = {}
+        self._c_prev = None
+        self._lazy = None
+        self._SExp = self._rhoVar = self._snr = self._S = None
+        self.ev = self.V = self.VtF = None
+
+    # ---- buffers ------------------------------------------------------------------------------------------------
+    def _buffers(self, P, device):
+        b = self._buf.get((P, str(device)))
+        if b is None:
+            Ppad = _round_up(P, nat.GRAM_TILE)
+            npk = nat.lib().vmcpde_gram_packed_doubles(P)
+            pack = torch.zeros(npk + 2 * P + 4, dtype=global_defs.tReal, device=device)
+            b = dict(Ppad=Ppad, npk=npk, pack=pack,
+                     packed=pack[:npk], rowsum=pack[npk:npk + P], rowdot=pack[npk + P:npk + 2 * P],
+                     sums=pack[npk + 2 * P:npk + 2 * P + 3], count=pack[npk + 2 * P + 3:npk + 2 * P + 4],
+                     stats=torch.zeros(4, dtype=global_defs.tReal, device=device),
+                     S=torch.zeros((Ppad, Ppad), dtype=global_defs.tReal, device=device),
+                     F=torch.zeros(P, dtype=global_defs.tReal, device=device),
+                     mean=torch.zeros(P, dtype=global_defs.tReal, device=device),
+                     c=torch.zeros(P, dtype=global_defs.tReal, device=device),
+                     cE=torch.zeros(1, dtype=global_defs.tReal, device=device),
+                     gram_ws=None, A=None, chol_ws=None, info=torch.zeros(1, dtype=torch.int32, device=device))
+            self._buf = {(P, str(device)): b}
+        return b
+
+    def _gram(self, b, JT, ldj, P, n, c, w, out):
+        need = nat.lib().vmcpde_gram_workspace_bytes(P, n)
+        if b["gram_ws"] is None or b["gram_ws"].numel() * 8 < need:
+            b["gram_ws"] = torch.empty(max(need // 8, 1), dtype=global_defs.tReal, device=JT.device)
+        nat.call("vmcpde_gram", nat.ptr(JT), ldj, P, n, nat.ptr(c), nat.ptr(w), nat.ptr(out), nat.ptr(b["gram_ws"]),
+                 b["gram_ws"].numel() * 8, nat.stream())
+
+    # ---- tdvp.py:36-52 -------------------------------------------------------------------------------------------
+    def get_tdvp_equation(self, Eloc, gradients, logProbs, psi=None):
+        """Means, F0, S0 (and lazily S, SExp) from this rank's samples, reduced over ranks.  Returns F; the reference's
+        other return values are the attribute `S` and the N x P array E~O~, which is never materialised here."""
+        device = Eloc.device
+        e = Eloc.reshape(-1).contiguous()
+        n = e.numel()
+        P = gradients.shape[-1]
+        b = self._buffers(P, device)
+        jt = psi.jt_buffer_of(gradients) if psi is not None and hasattr(psi, "jt_buffer_of") else None
+        if jt is None:   # generic input: repack once into the padded parameter-major layout the kernels consume
+            ldj = _round_up(n, 16)
+            JT = torch.zeros((b["Ppad"], ldj), dtype=global_defs.tReal, device=device)
+            JT[:P, :n] = gradients.reshape(n, P).T
+        else:
+            JT, ldj = jt
+        Ntot = float(mpi.globNumSamples) if mpi.globNumSamples else float(n * mpi.get_comm_size())
+        world = mpi.get_comm_size()
+        with torch.cuda.device(device):
+            nat.call("vmcpde_eloc_stats", nat.ptr(e), n, nat.ptr(b["stats"]), nat.stream())
+            b["sums"].copy_(b["stats"][:3])
+            b["count"].fill_(float(n))
+            mode = self.centering
+            if mode == "auto":
+                mode = "exact" if (world == 1 or self._c_prev is None or self._c_prev.numel() != P) else "lagged"
+            if mode == "exact":
+                # pass 1: raw sums -> global means (tdvp.py:37,41); tiny all-reduce when sharded
+                b["c"].zero_()
+                b["cE"].zero_()
+                nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, P, n, nat.ptr(e), None, None, nat.ptr(b["rowsum"]),
+                         nat.ptr(b["rowdot"]), nat.stream())
+                if world > 1:
+                    small = torch.cat([b["rowsum"], b["sums"][:1], b["count"]])
+                    mpi.allreduce_sum_(small)
+                    b["c"].copy_(small[:P] / small[P + 1])
+                    b["cE"].copy_(small[P:P + 1] / small[P + 1])
+                else:
+                    b["c"].copy_(b["rowsum"] / n)
+                    b["cE"].copy_(b["sums"][:1] / n)
+            else:
+                b["c"].copy_(self._c_prev)
+                b["cE"].copy_(self._cE_prev)
+            # pass 2 (tdvp.py:40-45 in shifted form): sum (O - c), sum (O - c)(E - cE); then the syrk (tdvp.py:46)
+            nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, P, n, nat.ptr(e), nat.ptr(b["c"]), nat.ptr(b["cE"]),
+                     nat.ptr(b["rowsum"]), nat.ptr(b["rowdot"]), nat.stream())
+            self._gram(b, JT, ldj, P, n, b["c"], None, b["packed"])
+            mpi.allreduce_sum_(b["pack"])            # the one collective of the step (no-op on a single rank)
+            use_chol = self._solver() == "cholesky"
+            if use_chol and b["A"] is None:
+                b["A"] = torch.zeros((b["Ppad"], b["Ppad"]), dtype=global_defs.tReal, device=device)
+            nat.call("vmcpde_gram_finalize", nat.ptr(b["packed"]), nat.ptr(b["rowsum"]), nat.ptr(b["rowdot"]), nat.ptr(b["sums"]),
+                     nat.ptr(b["c"]), nat.ptr(b["cE"]), P, Ntot, float(self.diagonalShift), nat.ptr(b["S"]), b["Ppad"],
+                     nat.ptr(b["A"]) if use_chol else None, b["Ppad"], nat.ptr(b["F"]), nat.ptr(b["mean"]), nat.stream())
+        sums = b["sums"]
+        self.ElocMean = sums[0] / Ntot                                        # tdvp.py:37
+        self.ElocMeanAbs = sums[2] / Ntot                                     # tdvp.py:38
+        self.ElocVar = sums[1] / Ntot - self.ElocMean ** 2                    # tdvp.py:39
+        self._Esq_mean = sums[1] / Ntot
+        self._c_prev, self._cE_prev = b["mean"].clone(), self.ElocMean.reshape(1).clone()
+        self.F0 = b["F"][:P]
+        self.S0 = b["S"][:P, :P]
+        self._lazy = dict(JT=JT, ldj=ldj, P=P, n=n, Ntot=Ntot, e=e, logp=logProbs.reshape(-1).contiguous(), b=b,
+                          mean=b["mean"], Emean=self.ElocMean)
+        self._SExp = self._rhoVar = self._snr = self._S = None
+        return self.F0
+
+    def _weighted_gram(self, w):
+        """(1/N) sum_n w_n^2 O~_n O~_n^T over all ranks from the retained Jacobian (w = logp: tdvp.py:33,47; w = E~: the
+        second moment behind rhoVar, tdvp.py:68-70)."""
+        z = self._lazy
+        b, P = z["b"], z["P"]
+        tmp = torch.zeros(b["npk"], dtype=global_defs.tReal, device=w.device)
+        out = torch.zeros((b["Ppad"], b["Ppad"]), dtype=global_defs.tReal, device=w.device)
+        zero = torch.zeros(P, dtype=global_defs.tReal, device=w.device)
+        with torch.cuda.device(w.device):
+            self._gram(b, z["JT"], z["ldj"], P, z["n"], z["mean"], w.contiguous(), tmp)
+            mpi.allreduce_sum_(tmp)
+            nat.call("vmcpde_gram_finalize", nat.ptr(tmp), nat.ptr(zero), None, None, None, None, P, z["Ntot"], 0.0, nat.ptr(out),
+                     b["Ppad"], None, 0, None, None, nat.stream())
+        return out[:P, :P]
+
+    @property
+    def S(self):
+        """tdvp.py:48-51: S0, or S0 + diagonalShift*diag(S0)."""
+        if self._S is None:
+            self._S = self.S0 if not (self.diagonalShift > 1e-10) else self.S0 + torch.diag(self.diagonalShift * torch.diag(self.S0))
+        return self._S
+
+    @property
+    def SExp(self):
+        """tdvp.py:47: <(logp O~)(logp O~)^T>, consumed by AdaptiveHeun (stepper.py:71)."""
+        if self._SExp is None:
+            self._SExp = self._weighted_gram(self._lazy["logp"])
+        return self._SExp
+
+    @property
+    def rhoVar(self):
+        """tdvp.py:68-70: Var_n[(E~ O~ V)_nk] = diag(V^T G V) - VtF^2 with G = <E~^2 O~ O~^T> (no N x P GEMM)."""
+        if self._rhoVar is None:
+            if self.V is None:
+                raise RuntimeError("rhoVar/snr need the eigenbasis: use solver='eigh'")
+            G = self._weighted_gram(self._lazy["e"] - self._lazy["Emean"])
+            self._rhoVar = ((G @ self.V) * self.V).sum(0) - self.VtF ** 2
+        return self._rhoVar
+
+    @property
+    def snr(self):
+        """tdvp.py:71."""
+        if self._snr is None:
+            self._snr = torch.sqrt(torch.abs(self._lazy["Ntot"] * (self.VtF * self.VtF) / self.rhoVar))
+        return self._snr
+
+    def _solver(self):
+        if self.solver == "auto":
+            return "cholesky" if self.diagonalShift > 1e-10 else "eigh"
+        return self.solver
+
+    # ---- tdvp.py:57-71 -------------------------------------------------------------------------------------------
+    def transform_to_eigenbasis(self, S, F, EOdata=None):
+        P = F.numel()
+        if self.diagonalizeOnDevice:
+            self.ev, self.V = torch.linalg.eigh(S)                            # tdvp.py:59 (rocSOLVER)
+        else:
+            tmpEv, tmpV = np.linalg.eigh(S.detach().cpu().numpy())            # tdvp.py:61-64 (host LAPACK)
+            self.ev = torch.from_numpy(tmpEv).to(F.device)
+            self.V = torch.from_numpy(tmpV).to(F.device)
+        self.VtF = torch.empty(P, dtype=global_defs.tReal, device=F.device)
+        Vc = self.V.contiguous()
+        self.V = Vc
+        with torch.cuda.device(F.device):
+            nat.call("vmcpde_gemv", nat.ptr(Vc), P, P, P, 1, nat.ptr(F.contiguous()), nat.ptr(self.VtF), nat.stream())   # tdvp.py:66
+
+    # ---- tdvp.py:73-94 -------------------------------------------------------------------------------------------
+    def solve(self, Eloc, gradients, logProbs, psi=None):
+        F = self.get_tdvp_equation(Eloc, gradients, logProbs, psi=psi)
+        b = self._lazy["b"]
+        P = F.numel()
+        device = F.device
+        update = torch.empty(P, dtype=global_defs.tReal, device=device)
+        with torch.cuda.device(device):
+            if self._solver() == "cholesky":
+                need = nat.lib().vmcpde_chol_workspace_bytes(P)
+                if b["chol_ws"] is None or b["chol_ws"].numel() * 8 < need:
+                    b["chol_ws"] = torch.empty(need // 8, dtype=global_defs.tReal, device=device)
+                nat.call("vmcpde_cholesky", nat.ptr(b["A"]), b["Ppad"], P, nat.ptr(b["info"]), nat.ptr(b["chol_ws"]), need, nat.stream())
+                nat.call("vmcpde_chol_solve", nat.ptr(b["A"]), b["Ppad"], P, nat.ptr(F), nat.ptr(update), nat.ptr(b["chol_ws"]), need,
+                         nat.stream())
+                self.ev = self.V = self.VtF = None
+                self.cholInfo = b["info"]
+            else:
+                self.transform_to_eigenbasis(self.S, F)
+                coef = torch.empty(P, dtype=global_defs.tReal, device=device)
+                snr = self.snr.contiguous() if self.useSNR else None                                   # tdvp.py:87-89
+                nat.call("vmcpde_pinv_coeffs", nat.ptr(self.ev), nat.ptr(self.VtF), nat.ptr(snr), P, float(self.svdTol),
+                         float(self.snrTol), nat.ptr(coef), nat.stream())                              # tdvp.py:82-85
+                nat.call("vmcpde_gemv", nat.ptr(self.V), P, P, P, 0, nat.ptr(coef), nat.ptr(update), nat.stream())   # tdvp.py:91
+            # residual and TDVP error (tdvp.py:93-94): S0 u once, the shifted S adds diagonalShift*diag(S0)*u
+            S0u = torch.empty(P, dtype=global_defs.tReal, device=device)
+            nat.call("vmcpde_gemv", nat.ptr(b["S"]), b["Ppad"], P, P, 0, nat.ptr(update), nat.ptr(S0u), nat.stream())
+        Su = S0u
+        if self.diagonalShift > 1e-10:
+            Su = S0u + self.diagonalShift * torch.diagonal(self.S0) * update
+        tdvp_error = 1 + (update @ S0u - 2 * (self.F0 @ update)) / self._Esq_mean                      # tdvp.py:93
+        residual = torch.linalg.norm(Su - F) / torch.linalg.norm(F)                                     # tdvp.py:94
+        return update, residual, tdvp_error
+
+    # ---- tdvp.py:96-164 ------------------------------------------------------------------------------------------
+    def __call__(self, netParameters, t, psi, evolutionEq, **rhsArgs):
+        nSamplesTDVP = rhsArgs["nSamplesTDVP"]
+        nSamplesObs = rhsArgs["nSamplesObs"]
+        mpi.globNumSamples = nSamplesTDVP                                     # tdvp.py:99
+        psi.set_parameters(netParameters)                                     # tdvp.py:101
+        timings = rhsArgs["timings"]
+
+        def start_timing(name):
+            if timings is not None:
+                torch.cuda.synchronize(psi.device)
+                timings.start_timing(name)
+
+        def stop_timing(name):
+            if timings is not None:
+                torch.cuda.synchronize(psi.device)
+                timings.stop_timing(name)
+
+        start_timing("sampling")
+        sampleConfigs, logProbs = psi.sample(numSamples=nSamplesTDVP)         # tdvp.py:117
+        stop_timing("sampling")
+
+        start_timing("compute Eloc")
+        Eloc, sampleGradients, logProbs = evolutionEq(psi, sampleConfigs, t)  # tdvp.py:122
+        stop_timing("compute Eloc")
+
+        start_timing("solve TDVP eqn.")
+        update, self.solverResidual, self.tdvp_error = self.solve(Eloc, sampleGradients, logProbs, psi=psi)   # tdvp.py:127
+        stop_timing("solve TDVP eqn.")
+
+        if nSamplesObs > nSamplesTDVP:                                        # tdvp.py:130-134
+            start_timing("sampling observables")
+            sampleConfigs, logProbs = psi.sample(numSamples=nSamplesObs)
+            stop_timing("sampling observables")
+
+        if not rhsArgs.get("observables", True):
+            return update, {}
+
+        if bool(torch.isnan(update).any()):                                   # tdvp.py:136-141
+            print(self.S0)
+            print(self.F0)
+            raise FloatingPointError("nan encountered in the TDVP update")
+
+        info = {}                                                             # tdvp.py:143-150
+        mean = sampleConfigs.mean(dim=(0, 1), keepdim=True)
+        info["x1"] = mean[0, 0]
+        X = sampleConfigs[0] - mean[0]
+        info["covar"] = X.T @ X / X.shape[0]
+        info["entropy"] = -logProbs.mean()
+        for m in [3, 4, 5, 6]:
+            info[f"x{m}"] = ((sampleConfigs - mean) ** m).mean(dim=(0, 1))
+        info["max_grad"] = Eloc.max()
+
+        if rhsArgs.get("integrals", True) is not None:                        # tdvp.py:152-162: always evaluated by the reference
+            dim = sampleConfigs.shape[-1]
+            g = torch.Generator(device=psi.device).manual_seed(int(psi.sampler.key) + 104729)
+            samples = torch.randn((1, nSamplesObs, dim), generator=g, dtype=global_defs.tReal, device=psi.device)
+            radius = torch.rand((1, nSamplesObs), generator=g, dtype=global_defs.tReal, device=psi.device)
+            samples = samples / torch.linalg.norm(samples, dim=-1, keepdim=True) * radius[..., None] ** (1 / dim)
+            for lim_normal in [1, 0.5, 0.1]:
+                T = 10
+                lim = lim_normal * math.sqrt(T)
+                sphere_volume = math.pi ** (dim / 2) / math.gamma(dim / 2 + 1) * lim ** dim
+                info[f"integral_{lim_normal}sigma"] = torch.mean(torch.exp(psi(lim * samples))) * sphere_volume
+        return update, info
