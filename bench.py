@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: TDVP steps/s at N_samp = 65 536, N_param ~ 4k (BASELINE.json, config C2).
+
+    python bench.py [--gpus N --steps K --warmup W]        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one evaluation of TDVP.__call__ through `update` (tdvp.py:96-128: sample -> Eloc + Jacobian -> S, F ->
+solve; observables excluded) on synthetic inputs: 2-D Fokker-Planck (Kramers equation with anharmonic
+drift, evolutionEq.py `advection_hamiltonian_wDiss`, lam = 0.1), coupling flow d=2, 4 blocks, hidden (21,21) -> P = 4213
+random-init parameters, fp64, latent draws from the on-device Philox sampler.  Weak scaling: every rank processes
+65 536 samples; `value` = (samples/s over all ranks) / 65 536, i.e. TDVP steps/s in units of 65 536-sample steps
+(equal to plain steps/s at N = 1).
+
+The JSON line also carries
+  roofline     -- the dominant kernel (fp64 MFMA Gram): algorithmic flops N*P*(P+1) per launch / average launch time,
+                  measured with HIP events on the launch stream inside the timed steps; peak = 78.6 TFLOP/s (AMD's
+                  MI355X fp64 matrix figure; the local guide lists no f64 MFMA rate) next to this run's measured
+                  back-to-back v_mfma_f64_16x16x4_f64 rate.
+  cpu_baseline -- the CPU oracle (oracle/vmc_oracle.py, the reference algorithm as written) timed on this box's host
+                  cores on a bounded sample and scaled to the full step (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+N_SAMP = 65536
+DIM, DEPTH, HIDDEN = 2, 4, (21, 21)
+EQ = "advection_hamiltonian_wDiss"
+LAM = 0.1
+DIAG_SHIFT = 1e-6
+PEAK_F64_MFMA_TFLOPS = 78.6     # AMD MI355X spec, fp64 matrix (dense); the guide has no measured f64 MFMA figure
+OUT_SCALE = 0.1                 # output kernels U(-0.1, 0.1) (the reference's 1e-5 makes J nearly degenerate)
+
+
+def build_problem(device, n_samp=N_SAMP, hidden=HIDDEN, seed=1):
+    import vmc_pde_amd as V
+    sampler = V.Sampler(key=1234, dim=DIM, name="Gauss", mcmc_info={"offset": np.ones(DIM), "bound": 0.25})
+    vs = V.VarState(sampler, DIM, seed, DEPTH, network_args=dict(intmediate=hidden, offset=np.ones(DIM), latentSpaceName="Gauss", dim=DIM))
+    theta = vs.net.init(seed, out_scale=OUT_SCALE)
+    vs.set_parameters(theta)
+    eq = V.EvolutionEquation(dim=DIM, name=EQ)
+    eq.eqParams[EQ]["params"]["lam"] = LAM
+    tdvp = V.TDVP(diagonalShift=DIAG_SHIFT, solver="cholesky")
+    return vs, eq, tdvp, theta
+
+
+def measure_mfma_peak(device):
+    from vmc_pde_amd import _native as nat
+    blocks, iters = 512, 4000
+    out = torch.empty(blocks * 256, dtype=torch.float64, device=device)
+    nat.call("vmcpde_bench_mfma_f64", 200, blocks, nat.ptr(out), nat.stream())
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        nat.call("vmcpde_bench_mfma_f64", iters, blocks, nat.ptr(out), nat.stream())
+        e1.record()
+        torch.cuda.synchronize()
+        flops = blocks * 4 * iters * 8 * 2048.0
+        best = max(best, flops / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    return best
+
+
+def cpu_baseline(theta_cpu, inds_up, inds_down):
+    """The reference algorithm as written (oracle), timed piecewise on bounded samples and scaled linearly in N."""
+    from oracle import vmc_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    spec = O.NetSpec(dim=DIM, inds_up=inds_up, inds_down=inds_down, intmediate=HIDDEN, offset=[1.0] * DIM)
+    P = O.num_parameters(spec)
+    vo = O.VarStateOracle(spec, theta_cpu)
+    eo = O.EvolutionEquationOracle(DIM, EQ)
+    eo.eqParams[EQ]["params"]["lam"] = LAM
+    g = torch.Generator().manual_seed(0)
+    n_ad, n_gemm = 512, 4096
+    z = O.latent_from_normals(spec, theta_cpu, torch.randn(n_ad, DIM, generator=g, dtype=torch.float64))
+    t0 = time.perf_counter()
+    x, _ = vo.flow_sample(z)
+    E, J, lp = eo(vo, x, 0.0)                      # vmap(grad) + jacrev(jacfwd) Hessian pass (var_state.py:31-32)
+    t_ad = time.perf_counter() - t0
+    Jg = torch.randn(n_gemm, P, generator=g, dtype=torch.float64)
+    Eg = torch.randn(n_gemm, generator=g, dtype=torch.float64)
+    t0 = time.perf_counter()
+    Oc = Jg - Jg.mean(0)                           # tdvp.py:41-42
+    EO = (Eg - Eg.mean())[:, None] * Oc            # tdvp.py:44
+    F0 = EO.mean(0)
+    S0 = Oc.T @ Oc / n_gemm                        # tdvp.py:46
+    Ow = Eg[:, None] * Oc
+    SExp = Ow.T @ Ow / n_gemm                      # tdvp.py:47
+    t_gram = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ev, Vm = np.linalg.eigh(S0.numpy())            # tdvp.py:61-64
+    t_eigh = time.perf_counter() - t0
+    Vt = torch.from_numpy(Vm)
+    t0 = time.perf_counter()
+    EOV = EO @ Vt                                  # tdvp.py:68
+    rho = EOV.var(0)
+    t_eov = time.perf_counter() - t0
+    total = t_ad * (N_SAMP / n_ad) + (t_gram + t_eov) * (N_SAMP / n_gemm) + t_eigh
+    return {"value": 1.0 / total, "unit": "TDVP steps/s", "cores": cores, "kind": "port",
+            "sample": (f"reference algorithm as written on torch/numpy fp64 CPU: autodiff J+Hessian at N={n_ad} (x{N_SAMP // n_ad}), "
+                       f"two Gram GEMMs + EO@V at N={n_gemm} (x{N_SAMP // n_gemm}), full P={P} eigh once; "
+                       f"parts {t_ad:.2f}s/{t_gram:.2f}s/{t_eov:.2f}s/{t_eigh:.2f}s -> {total:.1f}s per 65536-sample step (extrapolated)"),
+            "seconds_per_step_extrapolated": total}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--samples", type=int, default=N_SAMP, help="samples per rank (default: the BASELINE workload)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                 "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import vmc_pde_amd as V
+    from vmc_pde_amd import mpi_wrapper as mpi
+    vs, eq, tdvp, theta = build_problem(device, args.samples)
+    P = vs.numParameters
+    n_total = args.samples * world
+    kwargs = dict(evolutionEq=eq, psi=vs, nSamplesTDVP=n_total, nSamplesObs=n_total, timings=None, observables=False)
+
+    gram_events = []
+    tdvp._event_hook = lambda a, b: gram_events.append((a, b))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tdvp(theta, 0.0, **kwargs)
+    barrier()
+    gram_events.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        update, _ = tdvp(theta, 0.0, **kwargs)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert torch.isfinite(update).all(), "non-finite TDVP update"
+    resid = float(tdvp.solverResidual)
+
+    gram_ms = float(np.mean([a.elapsed_time(b) for a, b in gram_events])) if gram_events else float("nan")
+    flops = float(args.samples) * P * (P + 1)
+    achieved = flops / (gram_ms * 1e-3) / 1e12
+    peak_meas = measure_mfma_peak(device)
+
+    if rank == 0:
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "gram_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        steps_per_s = args.steps / elapsed
+        line = {
+            "metric": "TDVP steps/sec at N_samp=65k, N_param=4k",
+            "value": steps_per_s * (n_total / N_SAMP),
+            "unit": "TDVP steps/s (65536-sample steps)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: 2-D Fokker-Planck (Kramers, anharmonic drift lam=0.1), coupling flow d=2 x 4 blocks x hidden (21,21)",
+                       "n_param": P, "n_samp_per_gpu": args.samples, "n_samp_total": n_total, "solver": "cholesky",
+                       "diagonal_shift": DIAG_SHIFT, "solver_residual": resid, "parallelism": f"dp{world} (samples sharded, one all-reduce of (S,F) per step)"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": traffic,
+                         "kernel": "gram_kernel (fp64 MFMA syrk, + split-K reduce)", "ms_per_launch": gram_ms,
+                         "algorithmic_flops_per_launch": flops, "measured_mfma_f64_peak": peak_meas,
+                         "frac_of_measured_peak": achieved / peak_meas if peak_meas > 0 else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(theta.cpu(), vs.net.inds_up, vs.net.inds_down)
+            line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

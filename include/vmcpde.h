@@ -116,7 +116,7 @@ int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const double* x, int6
 
 /* ---- evolutionEq.py ------------------------------------------------------------------------------------ */
 /* evolutionEq.py:84-119 epilogue: Eloc_n from x, g and the directional second derivatives (J14 + eager einsums).
- * hv columns expected: diffusion(_drift): e_0..e_{d-1}; anisotropic: columns of chol(D), and Dmat [dev] d*d;
+ * hv columns expected: diffusion(_drift): e_0..e_{d-1}; anisotropic: the columns f_k of any factor D = F F^T, and Dmat [dev] d*d;
  * hamiltonian_wDiss: e_1,e_3,...  (momentum axes); advection: none. */
 int vmcpde_rhs(const vmcpde_eq_consts* c, int32_t dim, const double* x, const double* g, const double* hv, int32_t n_dirs,
                const double* Dmat, double t, int64_t n_samples, double* eloc, void* stream);
@@ -144,6 +144,10 @@ int vmcpde_gram(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, con
 int vmcpde_gram_finalize(const double* packed, const double* rowsum, const double* rowdot, const double* sums,
                          const double* c, const double* cE_dev, int32_t P, double n_total, double diagonal_shift,
                          double* S, int64_t lds, double* A_shifted, int64_t lda, double* F, double* mean, void* stream);
+
+/* diagnostic (no reference counterpart): `blocks` workgroups x 4 waves x `iters` x 8 back-to-back v_mfma_f64_16x16x4_f64
+ * (2048 flop each) with operands in registers; out: [dev] blocks*256.  Times the fp64 matrix-pipe peak for the roofline. */
+int vmcpde_bench_mfma_f64(int32_t iters, int32_t blocks, double* out, void* stream);
 
 /* ---- tdvp.py:57-94 solve ------------------------------------------------------------------------------- */
 /* in-place lower Cholesky of A (P x P, leading dim lda); rows with a non-positive pivot are pinned to the unit

@@ -1,0 +1,218 @@
+"""GPU parity: the flow kernels of csrc/flow.hip and csrc/sampler.hip (through the C ABI / host classes) against the
+autodiff CPU oracle on identical seeded inputs.  Tolerances are the fp64 figures of SURVEY.md 8(d)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vmc_oracle as O
+from helpers import make_spec, random_theta, make_varstate, rel_err
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [
+    # dim, depth, hidden, latent, coupling
+    (2, 4, (1,), "Gauss", "no_add"),            # the 'mwe' net of main.py:38,73
+    (2, 1, (3,), "Gauss", "no_add"),
+    (3, 4, (3,), "Gauss", "no_add"),            # odd d
+    (6, 4, (3,), "Gauss", "different_add"),     # the published phase-space net (P = 411)
+    (8, 1, (4, 4), "Student_t", "no_add"),
+    (8, 3, (6,), "Student_t", "no_add"),        # the published d=8 Student-t net (P = 393)
+    (6, 4, (4, 4), "Gauss", "plain"),
+    (4, 2, (3,), "Student_t", "jac_eq_1"),
+    (2, 4, (21, 21), "Gauss", "no_add"),        # BASELINE C2 net (P = 4213)
+    (2, 2, (9, 9, 9), "Gauss", "different_add"),
+]
+
+
+def _setup(cfg, n, seed=11):
+    dim, depth, hidden, latent, coupling = cfg
+    off = np.linspace(-0.5, 0.7, dim)
+    spec = make_spec(dim, depth, hidden, latent=latent, coupling=coupling, offset=off, seed=seed)
+    th = random_theta(spec, seed)
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn(1, n, dim, generator=g, dtype=torch.float64) * 0.8 + torch.as_tensor(off)
+    return spec, th, z
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_parameter_layout_matches_oracle(cfg):
+    spec, th, _ = _setup(cfg, 4)
+    vs = make_varstate(spec, th)
+    assert vs.numParameters == O.num_parameters(spec)
+    lay_o = [(n, tuple(s)) for n, s in O.param_layout(spec)]
+    lay_p = [("/".join(p), tuple(s)) for p, _, s in vs.net.layout]
+    assert lay_o == lay_p
+    assert vs.paramShapes == [(int(np.prod(s)), tuple(s)) for _, s in lay_o]
+    # set/get round trip and nested views (main.py:178 reads params["params"]["dist_params"])
+    assert torch.equal(vs.get_parameters().cpu(), th)
+    tree = O.unflatten(spec, th)
+    assert torch.equal(vs.params["params"]["mu"].cpu(), tree["mu"])
+    assert torch.equal(vs.params["params"]["myINN"]["blocks_0"]["s1"]["Dense_0"]["kernel"].cpu(), tree["myINN/blocks_0/s1/Dense_0/kernel"])
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_flow_sample_and_eval_parity(cfg):
+    n = 70 if cfg[2] != (21, 21) else 40        # ragged against the 64-lane wave on purpose
+    spec, th, z = _setup(cfg, n)
+    vo = O.VarStateOracle(spec, th)
+    vs = make_varstate(spec, th)
+    # J5: z -> (x, logp)
+    x_o, lp_o = vo.flow_sample(z)
+    x_p, lp_p = vs.flow_sample(z)
+    assert rel_err(x_p, x_o) < 1e-12
+    assert rel_err(lp_p, lp_o) < 1e-12
+    # forward direction (main.py:81)
+    y_p, l_p = vs.net.apply(vs.params, x_o[0, 0].clone(), evaluate=False, inv=False)
+    y_o, l_o = O.inn_w_prob(spec, th, x_o[0, 0], evaluate=False, inv=False)
+    assert rel_err(y_p, y_o) < 1e-12 and abs(float(l_p) - float(l_o)) < 1e-11 * max(1, abs(float(l_o)))
+    # J1, J3, J6
+    lo, go, Jo = vo(x_o, "eval_coordgrads")
+    lp, gp, Jp = vs(x_o, mode="eval_coordgrads")
+    assert lp.shape == (1, n) and gp.shape == (1, n, spec.dim) and Jp.shape == (1, n, vs.numParameters)
+    assert rel_err(lp, lo) < 1e-12
+    assert rel_err(gp, go) < 1e-11
+    assert float((Jp.cpu() - Jo).abs().max()) < 1e-11 * float(Jo.abs().max())
+    assert rel_err(vs(x_o, mode="eval"), lo) < 1e-12
+    # J4
+    Ho = vo.hessian(x_o)
+    Hp = vs.hessian(x_o)
+    assert float((Hp.cpu() - Ho).abs().max()) < 1e-10 * float(Ho.abs().max())
+
+
+def test_empty_and_single_sample():
+    spec, th, z = _setup(CONFIGS[2], 1)
+    vs = make_varstate(spec, th)
+    x, lp = vs.flow_sample(z)
+    assert x.shape == (1, 1, 3)
+    from vmc_pde_amd import _native as nat
+    x0 = torch.empty((0, 3), dtype=torch.float64, device=vs.device)
+    nat.call("vmcpde_flow_eval", vs.net.handle, nat.ptr(vs.get_parameters()), nat.ptr(x0), 0, None, 0, None, None, None, None, 0, nat.stream())
+
+
+@pytest.mark.parametrize("latent", ["Gauss", "Student_t"])
+def test_latent_from_normals_parity(latent):
+    from vmc_pde_amd import _native as nat
+    spec, th, _ = _setup((6, 2, (3,), latent, "no_add"), 4)
+    vs = make_varstate(spec, th)
+    g = torch.Generator().manual_seed(5)
+    n = 257
+    nrm = torch.randn(n, 6, generator=g, dtype=torch.float64)
+    chi2 = torch.distributions.Chi2(torch.tensor(3.0, dtype=torch.float64)).sample((n,))
+    z_o = O.latent_from_normals(spec, th, nrm, chi2)
+    z = torch.empty((n, 6), dtype=torch.float64, device=vs.device)
+    nat.call("vmcpde_latent_from_normals", vs.net.handle, nat.ptr(vs.get_parameters()), nat.ptr(nrm.to(vs.device)),
+             nat.ptr(chi2.to(vs.device)), n, nat.ptr(z), nat.stream())
+    assert rel_err(z, z_o[0]) < 1e-13
+
+
+@pytest.mark.parametrize("latent", ["Gauss", "Student_t"])
+def test_exact_sampler_statistics(latent):
+    # RNG streams cannot match JAX (H4): pin the law instead.  Gauss: mean mu+offset, cov L L^T; t: cov nu/(nu-2) L L^T
+    spec, th, _ = _setup((3, 2, (3,), latent, "no_add"), 4)
+    if latent == "Student_t":
+        off_d = [i for i, (nme, s) in enumerate(O.param_layout(spec)) if nme == "dist_params"]
+        th = th.clone()
+        names = [nme for nme, s in O.param_layout(spec) for _ in range(int(np.prod(s)))]
+        th[names.index("dist_params")] = np.log(7.0)     # nu = 8
+    vs = make_varstate(spec, th)
+    N = 400000
+    p = vs.params["params"]
+    from vmc_pde_amd import util
+    dist = {"S": util.build_cov_matrix(p["L"], p["L_diag"], 3), "mu": p["mu"], "dist_params": p["dist_params"], "_model": vs.net,
+            "_theta": vs.get_parameters()}
+    z = vs.sampler(N, dist)[0].cpu()
+    tree = O.unflatten(spec, th)
+    S = O.build_cov_matrix(tree["L"], tree["L_diag"], 3)
+    scale = 1.0 if latent == "Gauss" else 8.0 / 6.0
+    mean = tree["mu"] + torch.as_tensor(spec.offset)
+    assert float((z.mean(0) - mean).abs().max()) < 0.012
+    C = torch.cov(z.T)
+    assert float((C - scale * S).abs().max()) < 0.03 * float(S.abs().max()) * scale
+    # successive calls use fresh streams; same key + same call index reproduces
+    z2 = vs.sampler(1000, dist)[0]
+    assert not torch.equal(z2.cpu(), z[:1000])
+
+
+def test_sample_sharding_is_world_size_invariant():
+    # sample n depends only on (key, call, global index): rank shards concatenate to the single-rank draw
+    from vmc_pde_amd import _native as nat
+    spec, th, _ = _setup((2, 2, (3,), "Gauss", "no_add"), 4)
+    vs = make_varstate(spec, th)
+    full = torch.empty((1000, 2), dtype=torch.float64, device=vs.device)
+    a = torch.empty((400, 2), dtype=torch.float64, device=vs.device)
+    b = torch.empty((600, 2), dtype=torch.float64, device=vs.device)
+    t = vs.get_parameters()
+    nat.call("vmcpde_sample_latent", vs.net.handle, nat.ptr(t), 9, 3, 0, 1000, nat.ptr(full), nat.stream())
+    nat.call("vmcpde_sample_latent", vs.net.handle, nat.ptr(t), 9, 3, 0, 400, nat.ptr(a), nat.stream())
+    nat.call("vmcpde_sample_latent", vs.net.handle, nat.ptr(t), 9, 3, 400, 600, nat.ptr(b), nat.stream())
+    assert torch.equal(torch.cat([a, b]), full)
+
+
+def test_mcmc_parity_with_injected_uniforms():
+    import ctypes as C
+    from vmc_pde_amd import _native as nat
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(1)
+    chains, steps = 30, 200       # numChains=30 as main.py:69
+    off = np.array([0.25, 0.25])
+    st0 = O.radial_update_prop(rng.random(chains), rng.random(chains), 0.25, off)
+    ur, up, ua = rng.random((steps, chains)), rng.random((steps, chains)), rng.random((steps, chains))
+    out_o, nacc_o = O.mcmc_chain(st0, ur, up, ua, 0.25, off)
+    states = torch.as_tensor(st0).to(dev).contiguous()
+    out = torch.empty((steps * chains, 2), dtype=torch.float64, device=dev)
+    nacc = torch.zeros(1, dtype=torch.int64, device=dev)
+    off2 = (C.c_double * 2)(*off.tolist())
+    nat.call("vmcpde_mcmc_from_uniforms", nat.ptr(torch.as_tensor(ur).to(dev)), nat.ptr(torch.as_tensor(up).to(dev)),
+             nat.ptr(torch.as_tensor(ua).to(dev)), chains, steps, 0.25, off2, nat.ptr(states), nat.ptr(out), nat.ptr(nacc), nat.stream())
+    assert int(nacc.item()) == nacc_o
+    assert float(np.abs(out.cpu().numpy() - out_o).max()) < 1e-14
+
+
+def test_mcmc_sampler_stationary_density():
+    import vmc_pde_amd as V
+    off = np.array([0.25, 0.25])
+    s = V.Sampler(key=3, numChains=64, dim=2, name="cos_dist", mcmc_info={"offset": off, "bound": 0.25})
+    x = s(64 * 3000, None)[0].cpu().numpy()
+    assert x.shape == (64 * 3000, 2)
+    r = 4 * np.linalg.norm(x - off, axis=1)
+    rr = np.linspace(0, 1, 20001)
+    w = (1 + np.cos(np.pi * rr)) * rr
+    expect = np.trapezoid(w * rr, rr) / np.trapezoid(w, rr)
+    assert abs(r.mean() - expect) < 0.01 and r.max() <= 1.0 + 1e-12
+
+
+EQS = ["diffusion", "diffusion_drift", "diffusion_anisotropic", "advection_hamiltonian", "advection_hamiltonian_wDiss"]
+
+
+@pytest.mark.parametrize("name", EQS)
+def test_rhs_parity(name):
+    import vmc_pde_amd as V
+    cfg = (6, 2, (3,), "Gauss", "different_add")
+    spec, th, z = _setup(cfg, 50)
+    vo = O.VarStateOracle(spec, th)
+    vs = make_varstate(spec, th)
+    x, _ = vo.flow_sample(z)
+    eo = O.EvolutionEquationOracle(6, name)
+    ep = V.EvolutionEquation(dim=6, name=name)
+    if name == "diffusion_anisotropic":
+        ep.eqParams[name]["D"] = eo.eqParams[name]["D"].clone()
+    if "hamiltonian" in name:
+        eo.eqParams[name]["params"]["lam"] = 0.1      # BASELINE C2: anharmonic drift
+        ep.eqParams[name]["params"]["lam"] = 0.1
+    E_o, J_o, lp_o = eo(vo, x, 0.3)
+    E_p, J_p, lp_p = ep(vs, x, 0.3)
+    assert E_p.shape == (1, 50)
+    assert rel_err(E_p, E_o) < 1e-10
+    assert rel_err(lp_p, lp_o) < 1e-12
+    assert float((J_p.cpu() - J_o).abs().max()) < 1e-11 * float(J_o.abs().max())
+
+
+def test_rhs_advection_paper_time_dependent():
+    import vmc_pde_amd as V
+    spec, th, z = _setup((2, 3, (3,), "Gauss", "no_add"), 33)
+    vo, vs = O.VarStateOracle(spec, th), make_varstate(spec, th)
+    x, _ = vo.flow_sample(z)
+    for t in (0.0, 1.7):
+        E_o, _, _ = O.EvolutionEquationOracle(2, "advection_paper")(vo, x, t)
+        E_p, _, _ = V.EvolutionEquation(dim=2, name="advection_paper")(vs, x, t)
+        assert rel_err(E_p, E_o) < 1e-11

@@ -1,0 +1,132 @@
+"""GPU parity: Gram / moments kernels (csrc/gram.hip) through the C ABI against numpy on identical inputs."""
+import numpy as np
+import pytest
+import torch
+
+from vmc_pde_amd import _native as nat
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _pad(v, m):
+    return (v + m - 1) // m * m
+
+
+def _jt(P, N, seed, scale=1.0, mean=0.0):
+    rng = np.random.default_rng(seed)
+    J = rng.standard_normal((N, P)) * scale + mean * rng.standard_normal(P)
+    ldj = _pad(N, 16)
+    JT = torch.zeros((_pad(P, 128), ldj), dtype=torch.float64, device=DEV)
+    JT[:P, :N] = torch.as_tensor(J.T)
+    return J, JT, ldj
+
+
+def _gram(JT, ldj, P, N, c=None, w=None):
+    npk = nat.lib().vmcpde_gram_packed_doubles(P)
+    packed = torch.full((npk,), float("nan"), dtype=torch.float64, device=DEV)
+    need = nat.lib().vmcpde_gram_workspace_bytes(P, N)
+    ws = torch.empty(max(need // 8, 1), dtype=torch.float64, device=DEV)
+    nat.call("vmcpde_gram", nat.ptr(JT), ldj, P, N, nat.ptr(c), nat.ptr(w), nat.ptr(packed), nat.ptr(ws), ws.numel() * 8, nat.stream())
+    return packed
+
+
+def _unpack(packed, P):
+    nb = _pad(P, 128) // 128
+    S = np.zeros((nb * 128, nb * 128))
+    pk = packed.cpu().numpy().reshape(-1, 128, 128)
+    t = 0
+    for i in range(nb):
+        for j in range(i + 1):
+            S[i * 128:(i + 1) * 128, j * 128:(j + 1) * 128] = pk[t]
+            if i != j:
+                S[j * 128:(j + 1) * 128, i * 128:(i + 1) * 128] = pk[t].T
+            t += 1
+    return S[:P, :P]
+
+
+def test_mfma_f64_layout_with_asymmetric_operand():
+    # exact small integers: any row/col swap in the f64 C/D lane map (cdna_hip_programming.md:159-162) shows up bit-for-bit
+    P, N = 256, 64
+    J = (np.arange(N)[:, None] * 3 + np.arange(P)[None, :] * 7 + (np.arange(P)[None, :] ** 2) % 5) % 11 - 5.0
+    JT = torch.zeros((256, 64), dtype=torch.float64, device=DEV)
+    JT[:P, :N] = torch.as_tensor(J.T)
+    S = _unpack(_gram(JT, 64, P, N), P)
+    assert np.array_equal(S, J.T @ J)
+
+
+@pytest.mark.parametrize("P,N", [(37, 1024), (128, 16), (129, 17), (411, 1000), (640, 4099), (4213, 2048)])
+def test_gram_parity_with_centring(P, N):
+    J, JT, ldj = _jt(P, N, seed=P + N, mean=3.0)
+    c = torch.as_tensor(J.mean(0)).to(DEV)
+    S = _unpack(_gram(JT, ldj, P, N, c=c), P)
+    O = J - J.mean(0)
+    ref = O.T @ O
+    assert np.linalg.norm(S - ref) / np.linalg.norm(ref) < 1e-13       # rel-Frobenius, SURVEY 8(d): 1e-12
+    assert np.array_equal(S, S.T)
+    # uncentred variant (c = NULL)
+    S0 = _unpack(_gram(JT, ldj, P, N), P)
+    assert np.linalg.norm(S0 - J.T @ J) / np.linalg.norm(J.T @ J) < 1e-13
+
+
+def test_gram_weighted_is_SExp_form():
+    # tdvp.py:33,47: (logp*O)^T (logp*O)
+    P, N = 200, 777
+    J, JT, ldj = _jt(P, N, seed=4)
+    w = np.random.default_rng(9).standard_normal(N)
+    c = torch.as_tensor(J.mean(0)).to(DEV)
+    S = _unpack(_gram(JT, ldj, P, N, c=c, w=torch.as_tensor(w).to(DEV)), P)
+    Ow = w[:, None] * (J - J.mean(0))
+    assert np.linalg.norm(S - Ow.T @ Ow) / np.linalg.norm(Ow.T @ Ow) < 1e-13
+
+
+def test_gram_is_deterministic_and_linear_in_samples():
+    # size-independent properties at a larger shape: bitwise reproducible; Gram(all) = Gram(first half) + Gram(second half)
+    P, N = 1000, 16384
+    J, JT, ldj = _jt(P, N, seed=2)
+    a = _gram(JT, ldj, P, N)
+    b = _gram(JT, ldj, P, N)
+    assert torch.equal(a, b)
+    h = N // 2
+    JT2 = JT[:, h:].contiguous()
+    s = _gram(JT, ldj, P, h) + _gram(JT2, h, P, N - h)
+    assert float((a - s).abs().max()) < 1e-10 * float(a.abs().max())
+
+
+def test_row_moments_eloc_stats_and_finalize():
+    P, N = 411, 1000
+    J, JT, ldj = _jt(P, N, seed=8, mean=2.0)
+    rng = np.random.default_rng(1)
+    E = rng.standard_normal(N) * 2 + 0.7
+    e = torch.as_tensor(E).to(DEV)
+    sums = torch.zeros(4, dtype=torch.float64, device=DEV)
+    nat.call("vmcpde_eloc_stats", nat.ptr(e), N, nat.ptr(sums), nat.stream())
+    assert np.allclose(sums.cpu().numpy(), [E.sum(), (E ** 2).sum(), np.abs(E).sum(), E.max()], rtol=1e-13)
+    # shifted one-pass moments with an arbitrary (wrong) shift must still finalise to the exact two-pass result
+    c = torch.as_tensor(J.mean(0) + 0.3 * rng.standard_normal(P)).to(DEV)
+    cE = torch.tensor([0.2], dtype=torch.float64, device=DEV)
+    rowsum = torch.empty(P, dtype=torch.float64, device=DEV)
+    rowdot = torch.empty(P, dtype=torch.float64, device=DEV)
+    nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, P, N, nat.ptr(e), nat.ptr(c), nat.ptr(cE), nat.ptr(rowsum), nat.ptr(rowdot), nat.stream())
+    Jc = J - c.cpu().numpy()
+    assert np.allclose(rowsum.cpu().numpy(), Jc.sum(0), rtol=1e-12, atol=1e-10)
+    assert np.allclose(rowdot.cpu().numpy(), (Jc * (E - 0.2)[:, None]).sum(0), rtol=1e-12, atol=1e-10)
+    packed = _gram(JT, ldj, P, N, c=c)
+    Pp = _pad(P, 128)
+    S = torch.zeros((Pp, Pp), dtype=torch.float64, device=DEV)
+    A = torch.zeros((Pp, Pp), dtype=torch.float64, device=DEV)
+    F = torch.empty(P, dtype=torch.float64, device=DEV)
+    mean = torch.empty(P, dtype=torch.float64, device=DEV)
+    nat.call("vmcpde_gram_finalize", nat.ptr(packed), nat.ptr(rowsum), nat.ptr(rowdot), nat.ptr(sums), nat.ptr(c), nat.ptr(cE), P, float(N),
+             1e-3, nat.ptr(S), Pp, nat.ptr(A), Pp, nat.ptr(F), nat.ptr(mean), nat.stream())
+    Oc = J - J.mean(0)
+    S_ref = Oc.T @ Oc / N
+    F_ref = (Oc * (E - E.mean())[:, None]).mean(0)
+    Sg = S.cpu().numpy()[:P, :P]
+    assert np.linalg.norm(Sg - S_ref) / np.linalg.norm(S_ref) < 1e-12
+    assert np.array_equal(Sg, Sg.T)
+    assert np.allclose(F.cpu().numpy(), F_ref, rtol=1e-11, atol=1e-13)
+    assert np.allclose(mean.cpu().numpy(), J.mean(0), rtol=1e-13)
+    Ag = A.cpu().numpy()[:P, :P]
+    assert np.allclose(Ag, Sg + 1e-3 * np.diag(np.diag(Sg)), rtol=1e-15, atol=0)   # tdvp.py:50-51
+    assert float(S[P:].abs().max()) == 0.0 and float(S[:, P:].abs().max()) == 0.0   # padding stays zero (H7)

@@ -1,0 +1,95 @@
+"""GPU parity: blocked Cholesky, triangular solves, mat-vecs and the spectral cut-off coefficients (csrc/solve.hip)."""
+import numpy as np
+import pytest
+import torch
+
+from vmc_pde_amd import _native as nat
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _pad(v, m):
+    return (v + m - 1) // m * m
+
+
+def _spd(P, seed, cond=1e6):
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((P, P)))
+    ev = np.logspace(0, -np.log10(cond), P)
+    return (Q * ev) @ Q.T
+
+
+def _chol(Amat, P):
+    Pp = _pad(P, 128)
+    A = torch.zeros((Pp, Pp), dtype=torch.float64, device=DEV)
+    A[:P, :P] = torch.as_tensor(Amat)
+    need = nat.lib().vmcpde_chol_workspace_bytes(P)
+    ws = torch.empty(need // 8, dtype=torch.float64, device=DEV)
+    info = torch.zeros(1, dtype=torch.int32, device=DEV)
+    nat.call("vmcpde_cholesky", nat.ptr(A), Pp, P, nat.ptr(info), nat.ptr(ws), need, nat.stream())
+    return A, Pp, ws, need, info
+
+
+@pytest.mark.parametrize("P", [5, 128, 129, 300, 1000])
+def test_cholesky_and_solve_parity(P):
+    Amat = _spd(P, P, cond=1e4)
+    A, Pp, ws, need, info = _chol(Amat, P)
+    L = np.tril(A.cpu().numpy()[:P, :P])
+    Lref = np.linalg.cholesky(Amat)
+    assert int(info.item()) == 0
+    assert np.abs(L - Lref).max() < 1e-10 * np.abs(Lref).max()
+    rng = np.random.default_rng(P + 1)
+    F = rng.standard_normal(P)
+    u = torch.empty(P, dtype=torch.float64, device=DEV)
+    nat.call("vmcpde_chol_solve", nat.ptr(A), Pp, P, nat.ptr(torch.as_tensor(F).to(DEV)), nat.ptr(u), nat.ptr(ws), need, nat.stream())
+    uref = np.linalg.solve(Amat, F)
+    assert np.linalg.norm(Amat @ u.cpu().numpy() - F) / np.linalg.norm(F) < 1e-9
+    assert np.linalg.norm(u.cpu().numpy() - uref) / np.linalg.norm(uref) < 1e-8
+
+
+def test_cholesky_pins_dead_parameters():
+    # H7: a parameter with zero gradient gives a zero row/column of S; its update component must be 0
+    P = 200
+    Amat = _spd(P, 3, cond=1e3)
+    dead = [7, 130, 199]
+    Amat[dead, :] = 0.0
+    Amat[:, dead] = 0.0
+    A, Pp, ws, need, info = _chol(Amat, P)
+    assert int(info.item()) == len(dead)
+    F = np.random.default_rng(2).standard_normal(P)
+    F[dead] = 0.0
+    u = torch.empty(P, dtype=torch.float64, device=DEV)
+    nat.call("vmcpde_chol_solve", nat.ptr(A), Pp, P, nat.ptr(torch.as_tensor(F).to(DEV)), nat.ptr(u), nat.ptr(ws), need, nat.stream())
+    un = u.cpu().numpy()
+    live = [i for i in range(P) if i not in dead]
+    assert np.all(un[dead] == 0.0)
+    assert np.allclose(un[live], np.linalg.solve(Amat[np.ix_(live, live)], F[live]), rtol=1e-9)
+
+
+def test_gemv_and_pinv_coeffs():
+    rng = np.random.default_rng(0)
+    R, Cc = 300, 411
+    Amat = rng.standard_normal((R, Cc))
+    A = torch.as_tensor(Amat).to(DEV).contiguous()
+    x = rng.standard_normal(Cc)
+    y = torch.empty(R, dtype=torch.float64, device=DEV)
+    nat.call("vmcpde_gemv", nat.ptr(A), Cc, R, Cc, 0, nat.ptr(torch.as_tensor(x).to(DEV)), nat.ptr(y), nat.stream())
+    assert np.allclose(y.cpu().numpy(), Amat @ x, rtol=1e-12, atol=1e-12)
+    xt = rng.standard_normal(R)
+    yt = torch.empty(Cc, dtype=torch.float64, device=DEV)
+    nat.call("vmcpde_gemv", nat.ptr(A), Cc, R, Cc, 1, nat.ptr(torch.as_tensor(xt).to(DEV)), nat.ptr(yt), nat.stream())
+    assert np.allclose(yt.cpu().numpy(), Amat.T @ xt, rtol=1e-12, atol=1e-12)
+    # tdvp.py:82-89 incl. the hard 1e-14 cut, a negative round-off eigenvalue and the SNR factor
+    P = 64
+    ev = np.sort(np.concatenate([[-4e-14, 1e-16, 1e-13, 3e-12], np.logspace(-11, 2, P - 4)]))
+    VtF, snr = rng.standard_normal(P), np.abs(rng.standard_normal(P)) * 3
+    rel = np.abs(ev / ev[-1])
+    inv = np.where(rel > 1e-14, 1.0 / ev, 0.0)
+    reg = 1.0 / (1.0 + (1e-11 / rel) ** 6)
+    for use_snr in (False, True):
+        r = reg * (1.0 / (1.0 + (2.0 / snr) ** 6)) if use_snr else reg
+        coef = torch.empty(P, dtype=torch.float64, device=DEV)
+        nat.call("vmcpde_pinv_coeffs", nat.ptr(torch.as_tensor(ev).to(DEV)), nat.ptr(torch.as_tensor(VtF).to(DEV)),
+                 nat.ptr(torch.as_tensor(snr).to(DEV)) if use_snr else None, P, 1e-11, 2.0, nat.ptr(coef), nat.stream())
+        assert np.allclose(coef.cpu().numpy(), inv * r * VtF, rtol=1e-13, atol=0)

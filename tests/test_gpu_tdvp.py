@@ -1,0 +1,185 @@
+"""GPU parity of the whole hot path: one TDVP right-hand side (sample -> Eloc/J -> S,F -> solve) and one Heun step of the
+product classes against the CPU oracle, with the latent draws injected.  Tolerances: SURVEY.md 8(d)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vmc_oracle as O
+from helpers import make_spec, random_theta, make_varstate, FixedSampler, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(dim, depth, hidden, latent, coupling, eq, N, seed=3, lam=0.0):
+    import vmc_pde_amd as V
+    off = np.linspace(0.4, -0.3, dim)
+    spec = make_spec(dim, depth, hidden, latent=latent, coupling=coupling, offset=off, seed=seed)
+    th = random_theta(spec, seed, out_scale=0.03)
+    g = torch.Generator().manual_seed(seed)
+    nrm = torch.randn(N, dim, generator=g, dtype=torch.float64)
+    chi2 = torch.distributions.Chi2(torch.tensor(float(np.exp(0.0) + 1.0), dtype=torch.float64)).sample((N,))
+    eo = O.EvolutionEquationOracle(dim, eq)
+    ep = V.EvolutionEquation(dim=dim, name=eq)
+    if "hamiltonian" in eq:
+        eo.eqParams[eq]["params"]["lam"] = lam
+        ep.eqParams[eq]["params"]["lam"] = lam
+    return spec, th, nrm, chi2, eo, ep
+
+
+CASES = [
+    (2, 4, (1,), "Gauss", "no_add", "diffusion", 1024),                           # BASELINE C1 (main.py 'mwe')
+    (2, 3, (4, 4), "Gauss", "no_add", "advection_hamiltonian_wDiss", 700),        # C2-like, ragged N
+    (6, 4, (3,), "Gauss", "different_add", "advection_hamiltonian_wDiss", 512),   # C4-like (published P = 411)
+    (8, 3, (6,), "Student_t", "no_add", "diffusion", 600),                        # published Student-t net
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_tdvp_rhs_parity_eigh_path(case):
+    import vmc_pde_amd as V
+    from vmc_pde_amd import mpi_wrapper as mpi
+    dim, depth, hidden, latent, coupling, eq, N = case
+    spec, th, nrm, chi2, eo, ep = _problem(dim, depth, hidden, latent, coupling, eq, N, lam=0.1)
+    z = O.latent_from_normals(spec, th, nrm, chi2)
+    # oracle: the reference as written
+    vo = O.VarStateOracle(spec, th)
+    to = O.TDVPOracle()
+    upd_o, aux = to.rhs(th, 0.2, vo, eo, z)
+    # product
+    vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()))
+    tp = V.TDVP(solver="eigh")
+    upd_p, info = tp(th.cuda(), 0.2, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None)
+    P = vs.numParameters
+    assert rel_err(tp.S0, to.S0) < 1e-11 and tp.S0.shape == (P, P)
+    assert rel_err(tp.F0, to.F0) < 1e-10
+    assert abs(float(tp.ElocMean) - float(to.ElocMean)) < 1e-11 * (1 + abs(float(to.ElocMean)))
+    assert abs(float(tp.ElocVar) - float(to.ElocVar)) < 1e-10 * (1 + abs(float(to.ElocVar)))
+    assert abs(float(tp.ElocMeanAbs) - float(to.ElocMeanAbs)) < 1e-11 * (1 + abs(float(to.ElocMeanAbs)))
+    # S is rank deficient: compare the update in the S-norm, and the scalar diagnostics
+    du = upd_p.cpu() - upd_o
+    assert float(torch.linalg.norm(to.S0 @ du) / torch.linalg.norm(to.F0)) < 1e-8
+    assert abs(float(tp.tdvp_error) - float(to.tdvp_error)) < 1e-9
+    assert float(tp.solverResidual) < max(10 * float(to.solverResidual), 1e-9)
+    ev_o = to.ev
+    assert float((tp.ev.cpu() - ev_o).abs().max()) < 1e-10 * float(ev_o.abs().max())
+    # lazily evaluated attributes: SExp (tdvp.py:47), rhoVar / snr (tdvp.py:70-71) -- basis independent checks
+    assert rel_err(tp.SExp, to.SExp) < 1e-10
+    big = ev_o > 1e-6 * ev_o[-1]
+    rho_p, rho_o = tp.rhoVar.cpu(), to.rhoVar
+    assert float((rho_p[big] - rho_o[big]).abs().max()) < 1e-7 * float(rho_o[big].abs().max())
+    # observables (tdvp.py:143-150)
+    obs = to.observables(aux["x"], aux["logp"], aux["Eloc"])
+    for k in ("x1", "covar", "entropy", "x3", "x4", "x5", "x6", "max_grad"):
+        assert rel_err(info[k], obs[k]) < 1e-10, k
+    assert {"integral_1sigma", "integral_0.5sigma", "integral_0.1sigma"} <= set(info)
+    assert mpi.globNumSamples == N
+
+
+def test_tdvp_cholesky_path_matches_regularised_reference():
+    # diagonalShift > 0 (tdvp.py:50-51) makes S positive definite; the reference's pseudo-inverse then equals the
+    # plain solve up to its soft cut-off, which is what the on-device Cholesky computes.
+    import vmc_pde_amd as V
+    dim, depth, hidden, latent, coupling, eq, N = 2, 3, (4, 4), "Gauss", "no_add", "advection_hamiltonian_wDiss", 2000
+    spec, th, nrm, chi2, eo, ep = _problem(dim, depth, hidden, latent, coupling, eq, N, lam=0.1)
+    z = O.latent_from_normals(spec, th, nrm, chi2)
+    shift = 1e-4
+    to = O.TDVPOracle(diagonalShift=shift)
+    upd_o, _ = to.rhs(th, 0.0, O.VarStateOracle(spec, th), eo, z)
+    vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()))
+    tp = V.TDVP(diagonalShift=shift)        # solver="auto" -> cholesky
+    upd_p, _ = tp(th.cuda(), 0.0, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None)
+    assert tp._solver() == "cholesky" and int(tp.cholInfo.item()) == 0
+    S = to.S0 + torch.diag(shift * torch.diag(to.S0))
+    exact = torch.linalg.solve(S, to.F0)
+    assert float(torch.linalg.norm(upd_p.cpu() - exact) / torch.linalg.norm(exact)) < 1e-8
+    assert float(tp.solverResidual) < 1e-9
+    # against the reference's own (spectral) answer for the shifted matrix, in the S-norm
+    du = upd_p.cpu() - upd_o
+    assert float(torch.linalg.norm(S @ du) / torch.linalg.norm(to.F0)) < 1e-6
+    assert rel_err(tp.S, S) < 1e-11
+
+
+def test_heun_step_parity_and_value_semantics():
+    import vmc_pde_amd as V
+    dim, depth, hidden, latent, coupling, eq, N = 2, 4, (1,), "Gauss", "no_add", "diffusion", 1024
+    spec, th, nrm, chi2, eo, ep = _problem(dim, depth, hidden, latent, coupling, eq, N)
+    g = torch.Generator().manual_seed(99)
+    nrm2 = torch.randn(N, dim, generator=g, dtype=torch.float64)
+    normals = [nrm, nrm2]
+
+    # oracle Heun step (stepper.py:129-139), fresh latent normals per stage, z built from the stage's parameters
+    vo = O.VarStateOracle(spec, th)
+    to = O.TDVPOracle()
+
+    def f_o(y, t, k):
+        z = O.latent_from_normals(spec, y, normals[k], chi2)
+        u, aux = to.rhs(y, t, vo, eo, z)
+        return u, aux
+    dt = O.fixed_stepper_dt(1e-3, 1.3, 1e-2)
+    y_o, _ = O.heun_step(f_o, th.clone(), 0.0, dt)
+
+    class StageSampler:
+        key = 1
+
+        def __init__(self):
+            self.k = 0
+
+        def __call__(self, numSamples, dist_params, multipleOf=1):
+            from vmc_pde_amd import _native as nat
+            z = torch.empty((N, dim), dtype=torch.float64, device="cuda")
+            nat.call("vmcpde_latent_from_normals", dist_params["_model"].handle, nat.ptr(dist_params["_theta"]),
+                     nat.ptr(normals[self.k].cuda()), None, N, nat.ptr(z), nat.stream())
+            self.k += 1
+            return z[None]
+
+    vs = make_varstate(spec, th, sampler=StageSampler())
+    stepper = V.FixedStepper(timeStep=1e-3, mode="Heun", maxStep=1e-2, increase_fac=1.3)
+    y0 = th.cuda()
+    keep = y0.clone()
+    y_p, dt_p, info = stepper.step(0, V.TDVP(solver="eigh"), y0, evolutionEq=ep, psi=vs, nSamplesTDVP=N, nSamplesObs=N,
+                                   normFunction=lambda v, S: v @ S @ v, timings=None)
+    assert dt_p == dt
+    assert torch.equal(y0, keep)                       # the caller's tensor is not mutated (stepper.py:136 rebinding)
+    assert rel_err(y_p, y_o) < 1e-9
+    assert "entropy" in info
+
+
+def test_adaptive_heun_runs_and_uses_SExp():
+    import vmc_pde_amd as V
+    dim, depth, hidden, latent, coupling, eq, N = 2, 2, (2,), "Gauss", "no_add", "diffusion", 512
+    spec, th, *_ = _problem(dim, depth, hidden, latent, coupling, eq, N)
+    vs = make_varstate(spec, th)
+    st = V.AdaptiveHeun(timeStep=1e-3, tol=1e-2, maxStep=1e-2)
+    y, dt, info = st.step(0, V.TDVP(solver="eigh"), th.cuda(), evolutionEq=V.EvolutionEquation(dim=2, name="diffusion"), psi=vs,
+                          nSamplesTDVP=N, nSamplesObs=N, normFunction=lambda v, S: v @ S @ v, timings=V.util.Timings())
+    assert y.shape == th.shape and dt > 0 and torch.isfinite(y).all()
+
+
+def test_timings_sections_match_reference_names():
+    import vmc_pde_amd as V
+    spec, th, *_ = _problem(2, 2, (2,), "Gauss", "no_add", "diffusion", 256)
+    vs = make_varstate(spec, th)
+    tm = V.util.Timings()
+    V.TDVP()(th.cuda(), 0, vs, V.EvolutionEquation(dim=2, name="diffusion"), nSamplesTDVP=256, nSamplesObs=512, timings=tm)
+    assert list(tm.timing_dict) == ["sampling", "compute Eloc", "solve TDVP eqn.", "sampling observables"]   # tdvp.py:116-134
+
+
+def test_gaussian_diffusion_known_answer_on_gpu():
+    # KA-4 at N = 200k on the device: theta_dot restricted to L_diag = D; full-stack sampling + flow + Gram + solve
+    import vmc_pde_amd as V
+    dim = 3
+    spec = make_spec(dim, 2, (2,))
+    th = O.init_parameters(spec, 1, out_scale=0.0)
+    vs = make_varstate(spec, th)
+    N = 200000
+    x, lp = vs.sample(N)
+    E, J, lp2 = V.EvolutionEquation(dim=dim, name="diffusion")(vs, x, 0.0)
+    assert rel_err(lp, lp2) < 1e-12
+    names = [n for n, s in O.param_layout(spec) for _ in range(int(np.prod(s)))]
+    idx = [i for i, n in enumerate(names) if n == "L_diag"]
+    t = V.TDVP(solver="eigh")
+    V.mpi_wrapper.globNumSamples = N
+    upd, resid, err = t.solve(E, J[:, :, idx].contiguous(), lp2)
+    assert torch.allclose(t.S0.cpu(), 2 * torch.eye(dim, dtype=torch.float64), atol=0.03)
+    assert torch.allclose(upd.cpu(), torch.ones(dim, dtype=torch.float64), atol=0.02)
+    assert abs(float(err)) < 3e-3

@@ -1,0 +1,138 @@
+"""CPU tests of the host logic: sample sharding, the packed-buffer algebra behind the single all-reduce, the steppers'
+control flow, and the world_size-2 path over gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import vmc_oracle as O
+
+
+def test_distribute_sampling_and_first_sample_id_match_oracle():
+    from vmc_pde_amd import mpi_wrapper as mpi
+    assert mpi.distribute_sampling(10000) == 10000 and mpi.globNumSamples == 10000
+    assert mpi.distribute_sampling(10000, localDevices=1, numChainsPerDevice=30) == O.distribute_sampling(10000, 1, 0, 1, 30)[0]
+    assert mpi.globNumSamples == O.distribute_sampling(10000, 1, 0, 1, 30)[1]
+    assert mpi.first_sample_id(777) == 0
+    assert mpi.rank == 0 and mpi.commSize == 1
+
+
+class _ToyRHS:
+    """f(y, t, **rhsArgs, intStep=k) -> (k, info): linear ODE with a recorded call log (stepper.py:135-137 protocol)."""
+
+    def __init__(self, A):
+        self.A, self.calls = A, []
+        self.SExp = torch.eye(A.shape[0], dtype=torch.float64)
+
+    def __call__(self, y, t, intStep=0, **kw):
+        self.calls.append((intStep, float(t)))
+        return self.A @ y, {"intStep": intStep}
+
+
+def test_fixed_stepper_matches_oracle_and_clones():
+    from vmc_pde_amd.stepper import FixedStepper
+    A = torch.tensor([[0.0, 1.0], [-1.0, -0.1]], dtype=torch.float64)
+    y0 = torch.tensor([1.0, 0.5], dtype=torch.float64)
+    for mode, ref in (("Heun", O.heun_step), ("Euler", O.euler_step)):
+        f = _ToyRHS(A)
+        st = FixedStepper(timeStep=1e-2, maxStep=5e-2, increase_fac=1.3, mode=mode)
+        keep = y0.clone()
+        y1, dt, info = st.step(0.25, f, y0, foo=1)
+        assert dt == O.fixed_stepper_dt(1e-2, 1.3, 5e-2) and st.dt == dt
+        y_ref, _ = ref(lambda y, t, k: (A @ y, {}), y0, 0.25, dt)
+        assert torch.allclose(y1, y_ref, atol=1e-15) and torch.equal(y0, keep)
+        assert [c[0] for c in f.calls] == ([0, 1] if mode == "Heun" else [0])
+        assert info["intStep"] == (1 if mode == "Heun" else 0)
+    # geometric growth saturates at maxStep (stepper.py:131)
+    st = FixedStepper(timeStep=1e-7, maxStep=1e-2, increase_fac=1.3)
+    for _ in range(60):
+        st.step(0, _ToyRHS(A), y0)
+    assert st.dt == 1e-2
+
+
+def test_adaptive_heun_matches_oracle():
+    from vmc_pde_amd.stepper import AdaptiveHeun
+    A = torch.tensor([[0.0, 1.0], [-4.0, -0.3]], dtype=torch.float64)
+    y0 = torch.tensor([1.0, 0.0], dtype=torch.float64)
+    f = _ToyRHS(A)
+    st = AdaptiveHeun(timeStep=0.2, tol=1e-6, maxStep=1.0)
+    y1, real_dt, info = st.step(0.0, f, y0, normFunction=O.norm_fun)
+    y_ref, real_ref, dt_ref, _ = O.adaptive_heun_step(lambda y, t, k: (A @ y, {}), y0, 0.0, 0.2, 1e-6, 1.0, O.norm_fun, lambda: f.SExp)
+    assert torch.allclose(y1, y_ref, atol=1e-14) and real_dt == real_ref and st.dt == dt_ref
+    assert len(f.calls) % 5 == 0 and [c[0] for c in f.calls[:5]] == [0, 1, 2, 3, 4]   # five RHS calls per attempt
+
+
+def test_shifted_moment_algebra_of_the_packed_buffer():
+    """What every rank contributes and how the replicated finalize recovers the exact centred (S, F) of tdvp.py:40-46:
+    S = sum_r G_r(c)/N - delta delta^T, F = sum_r f_r(c,cE)/N - delta deltaE, for ANY common shift (c, cE)."""
+    rng = np.random.default_rng(0)
+    N, P = 3000, 17
+    J = rng.standard_normal((N, P)) * 2 + 5 * rng.standard_normal(P)
+    E = rng.standard_normal(N) + 3
+    Oc, Ec = J - J.mean(0), E - E.mean()
+    S_ref, F_ref = Oc.T @ Oc / N, (Ec[:, None] * Oc).mean(0)
+    c, cE = J[:100].mean(0), E[:100].mean()          # a lagged / partial estimate of the means
+    shards = [slice(0, 1000), slice(1000, 3000)]
+    G = sum((J[s] - c).T @ (J[s] - c) for s in shards)
+    rs = sum((J[s] - c).sum(0) for s in shards)
+    rd = sum(((J[s] - c) * (E[s] - cE)[:, None]).sum(0) for s in shards)
+    sE = sum(E[s].sum() for s in shards)
+    delta, dE = rs / N, sE / N - cE
+    assert np.allclose(G / N - np.outer(delta, delta), S_ref, rtol=1e-12, atol=1e-12)
+    assert np.allclose(rd / N - delta * dE, F_ref, rtol=1e-12, atol=1e-12)
+    assert np.allclose(c + delta, J.mean(0))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vmc_pde_amd import mpi_wrapper as mpi
+    n = 10001
+    per = mpi.distribute_sampling(n)
+    first = mpi.first_sample_id(n)
+    # the single packed all-reduce: every rank contributes its shard's partial sums
+    rng = np.random.default_rng(5)
+    X = torch.as_tensor(rng.standard_normal((n, 6)))
+    mine = X[first:first + per]
+    pack = torch.cat([(mine.T @ mine).reshape(-1), mine.sum(0), torch.tensor([float(per)])])
+    mpi.allreduce_sum_(pack)
+    ok = torch.allclose(pack[:36].reshape(6, 6), X.T @ X, atol=1e-9) and float(pack[-1]) == n
+    # reference-named generic reducers (mpi_wrapper.py:129-274) on (1, n_local, d) data
+    mpi.globNumSamples = n
+    gm = mpi.global_mean(mine[None])
+    gv = mpi.global_variance(mine[None])
+    gc = mpi.global_covariance((mine - X.mean(0))[None])
+    ok = ok and torch.allclose(gm, X.mean(0), atol=1e-12) and torch.allclose(gv, X.var(0, unbiased=False), atol=1e-12)
+    ok = ok and torch.allclose(gc, torch.cov(X.T, correction=0), atol=1e-12)
+    q.put((rank, per, first, mpi.rank, mpi.commSize, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_sharding_and_single_allreduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, per0, first0, rk0, cs0, ok0), (r1, per1, first1, rk1, cs1, ok1) = res
+    assert (per0, per1) == (5001, 5000) and (first0, first1) == (0, 5001)     # mpi_wrapper.py:83-86,113-126
+    assert (rk0, rk1, cs0, cs1) == (0, 1, 2, 2) and ok0 and ok1
+    for r in range(2):
+        assert O.distribute_sampling(10001, 2, r)[0] == (per0, per1)[r]

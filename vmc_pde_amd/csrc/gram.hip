@@ -194,7 +194,32 @@ __global__ void finalize_F_kernel(const double* __restrict__ rowsum, const doubl
   if (mean) mean[p] = (c ? c[p] : 0.0) + delta;
 }
 
+// Diagnostic: back-to-back v_mfma_f64_16x16x4_f64 on 8 independent accumulators per wave (operands in registers, no memory
+// traffic) -- the measured matrix-pipe peak the Gram kernel's utilisation is quoted against (bench.py).
+__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(int iters, double* __restrict__ out) {
+  double4_t acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + 1e-3 * (threadIdx.x & 63), b = 1.0 - 1e-3 * (threadIdx.x & 15);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+    a = -a;   // keeps the sums bounded; one VALU op per 8 MFMAs
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 }  // namespace
+
+extern "C" int vmcpde_bench_mfma_f64(int32_t iters, int32_t blocks, double* out, void* stream) {
+  VMC_REQUIRE(out && iters >= 1 && blocks >= 1, "vmcpde_bench_mfma_f64: bad argument");
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, out);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 extern "C" int64_t vmcpde_gram_packed_doubles(int32_t P) {
   if (P <= 0) return 0;

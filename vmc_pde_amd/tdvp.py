@@ -74,8 +74,15 @@ class TDVP:
         need = nat.lib().vmcpde_gram_workspace_bytes(P, n)
         if b["gram_ws"] is None or b["gram_ws"].numel() * 8 < need:
             b["gram_ws"] = torch.empty(max(need // 8, 1), dtype=global_defs.tReal, device=JT.device)
+        hook = getattr(self, "_event_hook", None)     # bench.py: HIP events on the launch stream around the S-build
+        if hook is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         nat.call("vmcpde_gram", nat.ptr(JT), ldj, P, n, nat.ptr(c), nat.ptr(w), nat.ptr(out), nat.ptr(b["gram_ws"]),
                  b["gram_ws"].numel() * 8, nat.stream())
+        if hook is not None:
+            e1.record()
+            hook(e0, e1)
 
     # ---- tdvp.py:36-52 -------------------------------------------------------------------------------------------
     def get_tdvp_equation(self, Eloc, gradients, logProbs, psi=None):
