@@ -55,7 +55,7 @@ def build_problem(device, n_samp=N_SAMP, hidden=HIDDEN, seed=1):
 
 def measure_mfma_peak(device):
     from vmc_pde_amd import _native as nat
-    blocks, iters = 512, 4000
+    blocks, iters = 512, 4000      # iters is a multiple of 16 (the kernel's unroll)
     out = torch.empty(blocks * 256, dtype=torch.float64, device=device)
     nat.call("vmcpde_bench_mfma_f64", 200, blocks, nat.ptr(out), nat.stream())
     torch.cuda.synchronize()
@@ -74,7 +74,9 @@ def measure_mfma_peak(device):
 def cpu_baseline(theta_cpu, inds_up, inds_down):
     """The reference algorithm as written (oracle), timed piecewise on bounded samples and scaled linearly in N."""
     from oracle import vmc_oracle as O
-    cores = os.cpu_count() or 1
+    # threads actually used: the cores this process may run on, capped at the GPU box's 16-core share per GPU
+    # (an OpenMP pool as wide as the host's 256 hardware threads makes the oracle's many small ops far slower)
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
     spec = O.NetSpec(dim=DIM, inds_up=inds_up, inds_down=inds_down, intmediate=HIDDEN, offset=[1.0] * DIM)
     P = O.num_parameters(spec)
@@ -82,7 +84,7 @@ def cpu_baseline(theta_cpu, inds_up, inds_down):
     eo = O.EvolutionEquationOracle(DIM, EQ)
     eo.eqParams[EQ]["params"]["lam"] = LAM
     g = torch.Generator().manual_seed(0)
-    n_ad, n_gemm = 512, 4096
+    n_ad, n_gemm = 4096, 4096
     z = O.latent_from_normals(spec, theta_cpu, torch.randn(n_ad, DIM, generator=g, dtype=torch.float64))
     t0 = time.perf_counter()
     x, _ = vo.flow_sample(z)

@@ -86,7 +86,8 @@ def test_empty_and_single_sample():
     assert x.shape == (1, 1, 3)
     from vmc_pde_amd import _native as nat
     x0 = torch.empty((0, 3), dtype=torch.float64, device=vs.device)
-    nat.call("vmcpde_flow_eval", vs.net.handle, nat.ptr(vs.get_parameters()), nat.ptr(x0), 0, None, 0, None, None, None, None, 0, nat.stream())
+    th_d = vs.get_parameters()
+    nat.call("vmcpde_flow_eval", vs.net.handle, nat.ptr(th_d), nat.ptr(x0), 0, None, 0, None, None, None, None, 0, nat.stream())   # empty batch: no-op
 
 
 @pytest.mark.parametrize("latent", ["Gauss", "Student_t"])
@@ -100,8 +101,8 @@ def test_latent_from_normals_parity(latent):
     chi2 = torch.distributions.Chi2(torch.tensor(3.0, dtype=torch.float64)).sample((n,))
     z_o = O.latent_from_normals(spec, th, nrm, chi2)
     z = torch.empty((n, 6), dtype=torch.float64, device=vs.device)
-    nat.call("vmcpde_latent_from_normals", vs.net.handle, nat.ptr(vs.get_parameters()), nat.ptr(nrm.to(vs.device)),
-             nat.ptr(chi2.to(vs.device)), n, nat.ptr(z), nat.stream())
+    th_d, nrm_d, chi2_d = vs.get_parameters(), nrm.to(vs.device), chi2.to(vs.device)   # keep the buffers alive across the launch
+    nat.call("vmcpde_latent_from_normals", vs.net.handle, nat.ptr(th_d), nat.ptr(nrm_d), nat.ptr(chi2_d), n, nat.ptr(z), nat.stream())
     assert rel_err(z, z_o[0]) < 1e-13
 
 
@@ -162,8 +163,9 @@ def test_mcmc_parity_with_injected_uniforms():
     out = torch.empty((steps * chains, 2), dtype=torch.float64, device=dev)
     nacc = torch.zeros(1, dtype=torch.int64, device=dev)
     off2 = (C.c_double * 2)(*off.tolist())
-    nat.call("vmcpde_mcmc_from_uniforms", nat.ptr(torch.as_tensor(ur).to(dev)), nat.ptr(torch.as_tensor(up).to(dev)),
-             nat.ptr(torch.as_tensor(ua).to(dev)), chains, steps, 0.25, off2, nat.ptr(states), nat.ptr(out), nat.ptr(nacc), nat.stream())
+    ur_d, up_d, ua_d = (torch.as_tensor(a).to(dev) for a in (ur, up, ua))   # keep the buffers alive across the launch
+    nat.call("vmcpde_mcmc_from_uniforms", nat.ptr(ur_d), nat.ptr(up_d), nat.ptr(ua_d), chains, steps, 0.25, off2, nat.ptr(states),
+             nat.ptr(out), nat.ptr(nacc), nat.stream())
     assert int(nacc.item()) == nacc_o
     assert float(np.abs(out.cpu().numpy() - out_o).max()) < 1e-14
 

@@ -42,7 +42,8 @@ def test_cholesky_and_solve_parity(P):
     rng = np.random.default_rng(P + 1)
     F = rng.standard_normal(P)
     u = torch.empty(P, dtype=torch.float64, device=DEV)
-    nat.call("vmcpde_chol_solve", nat.ptr(A), Pp, P, nat.ptr(torch.as_tensor(F).to(DEV)), nat.ptr(u), nat.ptr(ws), need, nat.stream())
+    F_d = torch.as_tensor(F).to(DEV)
+    nat.call("vmcpde_chol_solve", nat.ptr(A), Pp, P, nat.ptr(F_d), nat.ptr(u), nat.ptr(ws), need, nat.stream())
     uref = np.linalg.solve(Amat, F)
     assert np.linalg.norm(Amat @ u.cpu().numpy() - F) / np.linalg.norm(F) < 1e-9
     assert np.linalg.norm(u.cpu().numpy() - uref) / np.linalg.norm(uref) < 1e-8
@@ -60,7 +61,8 @@ def test_cholesky_pins_dead_parameters():
     F = np.random.default_rng(2).standard_normal(P)
     F[dead] = 0.0
     u = torch.empty(P, dtype=torch.float64, device=DEV)
-    nat.call("vmcpde_chol_solve", nat.ptr(A), Pp, P, nat.ptr(torch.as_tensor(F).to(DEV)), nat.ptr(u), nat.ptr(ws), need, nat.stream())
+    F_d = torch.as_tensor(F).to(DEV)
+    nat.call("vmcpde_chol_solve", nat.ptr(A), Pp, P, nat.ptr(F_d), nat.ptr(u), nat.ptr(ws), need, nat.stream())
     un = u.cpu().numpy()
     live = [i for i in range(P) if i not in dead]
     assert np.all(un[dead] == 0.0)
@@ -74,11 +76,13 @@ def test_gemv_and_pinv_coeffs():
     A = torch.as_tensor(Amat).to(DEV).contiguous()
     x = rng.standard_normal(Cc)
     y = torch.empty(R, dtype=torch.float64, device=DEV)
-    nat.call("vmcpde_gemv", nat.ptr(A), Cc, R, Cc, 0, nat.ptr(torch.as_tensor(x).to(DEV)), nat.ptr(y), nat.stream())
+    x_d = torch.as_tensor(x).to(DEV)
+    nat.call("vmcpde_gemv", nat.ptr(A), Cc, R, Cc, 0, nat.ptr(x_d), nat.ptr(y), nat.stream())
     assert np.allclose(y.cpu().numpy(), Amat @ x, rtol=1e-12, atol=1e-12)
     xt = rng.standard_normal(R)
     yt = torch.empty(Cc, dtype=torch.float64, device=DEV)
-    nat.call("vmcpde_gemv", nat.ptr(A), Cc, R, Cc, 1, nat.ptr(torch.as_tensor(xt).to(DEV)), nat.ptr(yt), nat.stream())
+    xt_d = torch.as_tensor(xt).to(DEV)
+    nat.call("vmcpde_gemv", nat.ptr(A), Cc, R, Cc, 1, nat.ptr(xt_d), nat.ptr(yt), nat.stream())
     assert np.allclose(yt.cpu().numpy(), Amat.T @ xt, rtol=1e-12, atol=1e-12)
     # tdvp.py:82-89 incl. the hard 1e-14 cut, a negative round-off eigenvalue and the SNR factor
     P = 64
@@ -90,6 +94,7 @@ def test_gemv_and_pinv_coeffs():
     for use_snr in (False, True):
         r = reg * (1.0 / (1.0 + (2.0 / snr) ** 6)) if use_snr else reg
         coef = torch.empty(P, dtype=torch.float64, device=DEV)
-        nat.call("vmcpde_pinv_coeffs", nat.ptr(torch.as_tensor(ev).to(DEV)), nat.ptr(torch.as_tensor(VtF).to(DEV)),
-                 nat.ptr(torch.as_tensor(snr).to(DEV)) if use_snr else None, P, 1e-11, 2.0, nat.ptr(coef), nat.stream())
+        ev_d, VtF_d, snr_d = (torch.as_tensor(a).to(DEV) for a in (ev, VtF, snr))   # keep alive across the launch
+        nat.call("vmcpde_pinv_coeffs", nat.ptr(ev_d), nat.ptr(VtF_d), nat.ptr(snr_d) if use_snr else None, P, 1e-11, 2.0,
+                 nat.ptr(coef), nat.stream())
         assert np.allclose(coef.cpu().numpy(), inv * r * VtF, rtol=1e-13, atol=0)

@@ -675,8 +675,9 @@ int vmcpde_prepare_latent_internal(vmcpde_model* m, const double* theta, hipStre
 extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const double* x, int64_t n_samples,
                                 const double* dirs, int32_t n_dirs, double* logp, double* g, double* hv,
                                 double* JT, int64_t ldj, void* stream) {
-  VMC_REQUIRE(m && theta && x, "vmcpde_flow_eval: null argument");
   VMC_REQUIRE(n_samples >= 0, "negative sample count");
+  if (n_samples == 0) return 0;   // empty batch (torch gives a NULL data pointer for it)
+  VMC_REQUIRE(m && theta && x, "vmcpde_flow_eval: null argument");
   VMC_REQUIRE(n_dirs >= 0 && n_dirs <= VMCPDE_MAX_DIRS, "n_dirs %d outside [0,%d]", n_dirs, VMCPDE_MAX_DIRS);
   VMC_REQUIRE(n_dirs == 0 || (dirs && hv), "directions given without dirs/hv buffers");
   VMC_REQUIRE(JT == nullptr || ldj >= n_samples, "ldj %lld < n_samples %lld", (long long)ldj, (long long)n_samples);
@@ -698,8 +699,8 @@ extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const doub
 
 extern "C" int vmcpde_flow_sample(vmcpde_model* m, const double* theta, const double* z, int64_t n_samples, int inv,
                                   double* x, double* logp, void* stream) {
-  VMC_REQUIRE(m && theta && z && x, "vmcpde_flow_sample: null argument");
   if (n_samples <= 0) return 0;
+  VMC_REQUIRE(m && theta && z && x, "vmcpde_flow_sample: null argument");
   hipStream_t st = (hipStream_t)stream;
   if (int rc = vmcpde_prepare_latent_internal(m, theta, st)) return rc;
   Regions r = make_regions(m->host);

@@ -195,16 +195,17 @@ __global__ void finalize_F_kernel(const double* __restrict__ rowsum, const doubl
 }
 
 // Diagnostic: back-to-back v_mfma_f64_16x16x4_f64 on 8 independent accumulators per wave (operands in registers, no memory
-// traffic) -- the measured matrix-pipe peak the Gram kernel's utilisation is quoted against (bench.py).
+// traffic; iters is rounded up to a multiple of 16) -- the measured matrix-pipe peak the Gram kernel's utilisation is quoted against (bench.py).
 __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(int iters, double* __restrict__ out) {
   double4_t acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  double a = 1.0 + 1e-3 * (threadIdx.x & 63), b = 1.0 - 1e-3 * (threadIdx.x & 15);
-  for (int it = 0; it < iters; ++it) {
+  const double a = 1e-3 * (1 + (threadIdx.x & 63)), b = 1e-3 * (16 - (threadIdx.x & 15));
+  for (int it = 0; it < iters; it += 16) {   // 128 MFMAs per trip so loop overhead and register shuffles vanish
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
-    a = -a;   // keeps the sums bounded; one VALU op per 8 MFMAs
+    for (int rep = 0; rep < 16; ++rep)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
   }
   double s = 0.0;
 #pragma unroll
