@@ -1,0 +1,39 @@
+#!/opt/conda/bin/python3.9
+"""Extracts small known-answer fixtures from the reference's PUBLISHED result files (HDF5 data, read as data with h5py
+from /opt/conda/bin/python3.9 -- the reference code itself is not imported or executed).
+
+    /opt/conda/bin/python3.9 tests/golden/make_published_fixtures.py
+
+Sources (SURVEY.md section 6 / BASELINE.md section 1):
+  vmc_fluids/paper_plot/data_diffusion/dim8_Gauss_NsamplesTDVP10000_NsamplesObs10000/infos.hdf5
+  vmc_fluids/paper_plot/data_diffusion/dim8_StudentT_nu2_NsamplesTDVP10000_NsamplesObs10000/infos.hdf5
+"""
+import os
+
+import h5py
+import numpy as np
+
+REF = "/root/reference/vmc_fluids/paper_plot/"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    with h5py.File(REF + "data_diffusion/dim8_Gauss_NsamplesTDVP10000_NsamplesObs10000/infos.hdf5", "r") as f:
+        g = dict(times=f["times"][:], entropy=f["entropy"][:], covar_diag=np.diagonal(f["covar"][:], axis1=1, axis2=2).copy(),
+                 tdvp_error=f["tdvp_error"][:], solver_res=f["solver_res"][:], ev_first=f["ev"][0], ev_last=f["ev"][-1],
+                 x1_last=f["x1"][-1])
+    np.savez_compressed(os.path.join(OUT, "published_diffusion_d8_gauss.npz"), **g)
+    with h5py.File(REF + "data_diffusion/dim8_StudentT_nu2_NsamplesTDVP10000_NsamplesObs10000/infos.hdf5", "r") as f:
+        s = dict(times=f["times"][:], entropy=f["entropy"][:], dist_params=f["dist_params"][:, 0], tdvp_error=f["tdvp_error"][:],
+                 solver_res=f["solver_res"][:], covar_diag=np.diagonal(f["covar"][:], axis1=1, axis2=2).copy())
+    np.savez_compressed(os.path.join(OUT, "published_diffusion_d8_student_t.npz"), **s)
+    for k, v in g.items():
+        print("gauss", k, v.shape)
+    dt = np.diff(g["times"])
+    print("dt[:8]", dt[:8], "ratio", dt[1:8] / dt[:7], "max dt", dt.max(), "t_end", g["times"][-1])
+    print("entropy dev", np.abs(g["entropy"] - 0.5 * 8 * np.log(2 * np.pi * np.e * (1 + 2 * g["times"]))).max())
+    print("nu", np.exp(s["dist_params"][[0, -1]]) + 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+"""The N > 1 path on the one available GPU: two ranks (gloo, both on cuda:0) shard the samples, all-reduce the packed
+(S, F) buffer once and run the replicated solve; the result must equal the single-rank run on the same global sample
+set (the Philox sampler indexes draws by global sample id, so the union of the shards IS the single-rank batch)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+N, DIM, DEPTH, HIDDEN = 6001, 2, 3, (5, 5)     # odd N: ranks get 3001 / 3000 samples
+
+
+def _problem():
+    import vmc_pde_amd as V
+    sampler = V.Sampler(key=77, dim=DIM, name="Gauss", mcmc_info={"offset": np.ones(DIM), "bound": 0.25})
+    vs = V.VarState(sampler, DIM, 5, DEPTH, network_args=dict(intmediate=HIDDEN, offset=np.ones(DIM), latentSpaceName="Gauss", dim=DIM))
+    vs.set_parameters(vs.net.init(5, out_scale=0.05))
+    eq = V.EvolutionEquation(dim=DIM, name="advection_hamiltonian_wDiss")
+    eq.eqParams[eq.name]["params"]["lam"] = 0.1
+    return V, vs, eq
+
+
+def _two_calls(V, vs, eq, solver_kw):
+    tdvp = V.TDVP(**solver_kw)
+    th0 = vs.get_parameters()
+    u0, _ = tdvp(th0, 0.0, vs, eq, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+    S0, F0 = tdvp.S0.clone(), tdvp.F0.clone()
+    th1 = th0 + 1e-3 * torch.sin(torch.arange(th0.numel(), dtype=th0.dtype, device=th0.device))   # same on every rank / run
+    u1, _ = tdvp(th1, 0.1, vs, eq, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)   # second call: lagged centring when sharded
+    return [t.cpu() for t in (u0, S0, F0, u1, tdvp.S0, tdvp.F0)] + [float(tdvp.ElocMean), float(tdvp.ElocVar)]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    V, vs, eq = _problem()
+    res = {}
+    for name, kw in (("chol", dict(diagonalShift=1e-5)), ("eigh", dict(solver="eigh"))):
+        res[name] = _two_calls(V, vs, eq, kw)
+    q.put((rank, {k: [v.numpy() if torch.is_tensor(v) else v for v in vals] for k, vals in res.items()}))   # by value
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_rank():
+    V, vs, eq = _problem()
+    single = {name: _two_calls(V, vs, eq, kw) for name, kw in (("chol", dict(diagonalShift=1e-5)), ("eigh", dict(solver="eigh")))}
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in procs)
+    got = {r: {k: [torch.from_numpy(v) if isinstance(v, np.ndarray) else v for v in vals] for k, vals in d.items()} for r, d in got.items()}
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for name in ("chol", "eigh"):
+        u0, S0, F0, u1, S1, F1, Em, Ev = single[name]
+        for rank in (0, 1):
+            r = got[rank][name]
+            assert float((r[1] - S0).abs().max() / S0.abs().max()) < 1e-12        # S of the first call (exact centring)
+            assert float((r[2] - F0).abs().max() / F0.abs().max()) < 1e-11
+            assert float((r[4] - S1).abs().max() / S1.abs().max()) < 1e-11        # second call: lagged centring, one all-reduce
+            assert float((r[5] - F1).abs().max() / F1.abs().max()) < 1e-10
+            assert abs(r[6] - Em) < 1e-11 * (1 + abs(Em)) and abs(r[7] - Ev) < 1e-10 * (1 + abs(Ev))
+            if name == "chol":                                                       # well conditioned: updates agree directly
+                assert float(torch.linalg.norm(r[0] - u0) / torch.linalg.norm(u0)) < 1e-7
+                assert float(torch.linalg.norm(r[3] - u1) / torch.linalg.norm(u1)) < 1e-7
+            else:                                                                    # singular S: compare in the S-norm
+                assert float(torch.linalg.norm(S0 @ (r[0] - u0)) / torch.linalg.norm(F0)) < 1e-8
+        # the replicated solve is bit-identical on both ranks (same all-reduced inputs, deterministic kernels)
+        assert torch.equal(got[0][name][0], got[1][name][0]) and torch.equal(got[0][name][3], got[1][name][3])

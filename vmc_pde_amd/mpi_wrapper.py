@@ -65,7 +65,12 @@ def first_sample_id(numSamples=None):
 def allreduce_sum_(buf: torch.Tensor) -> torch.Tensor:
     """In-place sum over ranks of one packed device buffer (the single collective of a TDVP step)."""
     if _on() and dist.get_world_size() > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        if buf.is_cuda and dist.get_backend() == "gloo":     # CPU-backend rehearsal of the multi-rank path: stage via host
+            tmp = buf.cpu()
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+            buf.copy_(tmp)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)       # backend "nccl" = RCCL over xGMI
     return buf
 
 
