@@ -13,14 +13,14 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _run(latent, n_steps, seed=1, dts=None):
+def _run(latent, n_steps, seed=1, dts=None, on_device=True):
     import vmc_pde_amd as V
     dim = 8
     sampler = V.Sampler(key=seed, dim=dim, numChains=30, name=latent, mcmc_info={"offset": np.zeros(dim), "bound": 0.25})
     # 392 = 44 latent + 348 flow parameters <=> 3 blocks x hidden (6,)  
     vs = V.VarState(sampler, dim, seed, 3, network_args={"intmediate": (6,), "offset": np.zeros(dim), "latentSpaceName": latent, "dim": dim})
     stepper = V.FixedStepper(timeStep=5e-8, mode="Heun", maxStep=1e-2, increase_fac=2.0)   # first step 1e-7, doubling (published `times`)
-    tdvp = V.TDVP(diagonalizeOnDevice=True)
+    tdvp = V.TDVP(diagonalizeOnDevice=on_device)
     eq = V.EvolutionEquation(dim=dim, name="diffusion")
     t, out = 0.0, dict(times=[], entropy=[], covar=[], tdvp_error=[], solver_res=[], nu=[])
     for n in range(n_steps):
@@ -62,7 +62,8 @@ def test_student_t_diffusion_d8_follows_published_nu():
     ref = np.load(os.path.join(GOLD, "published_diffusion_d8_student_t.npz"))
     n = 400                                                                             # t ~ 3.8: enough to see the trend
     # the published run changed its step size adaptively between t = 1.6e-3 and 3e-2: replay its recorded dt sequence
-    vs, run = _run("Student_t", n, dts=np.diff(ref["times"]))
+    # host LAPACK eigh as the reference (tdvp.py:61-64): rocSOLVER's eigh does not always converge on the heavy-tailed S
+    vs, run = _run("Student_t", n, dts=np.diff(ref["times"]), on_device=False)
     assert vs.numParameters == 393
     assert np.allclose(run["times"], ref["times"][:n], rtol=0, atol=1e-9)
     nu_ref = np.exp(ref["dist_params"][:n]) + 1

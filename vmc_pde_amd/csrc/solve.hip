@@ -6,6 +6,8 @@
 // 128-wide panels: diagonal block factor + triangular inverse in LDS, panel solve and trailing update on the fp64
 // MFMA tile engine (mfma_tile.hpp).  The spectral (parity) path keeps the reference's formulae: eigh comes from the
 // caller, the cut-off coefficients (tdvp.py:82-89) and the mat-vecs (tdvp.py:66,91,93,94) are the kernels below.
+#include <cstdlib>
+
 #include "mfma_tile.hpp"
 
 using namespace vmcpde;
@@ -43,6 +45,33 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// One 16x16 block product on the matrix pipe with LDS-resident operands fetched through per-lane functors:
+// acc(i,j) += sum_{k<K} fa(i,k) * fb(j,k);  lane l supplies fa(l&15, k4 + (l>>4)) and fb(l&15, k4 + (l>>4)).
+// C/D element q of a lane is (row = (l>>4) + 4q, col = l&15)  (f64 MFMA layout).
+template <class FA, class FB>
+__device__ __forceinline__ void mfma16(double4_t& acc, int K, FA fa, FB fb) {
+  const int lr = threadIdx.x & 15, lk = (threadIdx.x & 63) >> 4;
+#pragma unroll 4
+  for (int k4 = 0; k4 < K; k4 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa(lr, k4 + lk), fb(lr, k4 + lk), acc, 0, 0, 0);
+}
+
+// d = sqrt(p) and 1/d for a positive normal p: v_rsq_f64 seed + two coupled Goldschmidt steps + one residual correction
+// (ocml's sqrt()/rsqrt() carry range-scaling code that bloats the unrolled factor loop into spills).
+__device__ __forceinline__ void sqrt_rsqrt(double p, double& d, double& inv_d) {
+  const double y = __builtin_amdgcn_rsq(p);
+  double g = p * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double e = fma(-g, g, p);
+  g = fma(e, h, g);
+  d = g;
+  inv_d = h + h;
+}
+
 // Wave 0: Cholesky of the 32x32 diagonal sub-block at (j0,j0) of the LDS block `a` and its triangular inverse.
 // Lane i keeps row i in registers (lanes 32..63 mirror 0..31); each column's multipliers are exchanged through a
 // 32-double LDS line read back as broadcasts (one wave: DS operations execute in issue order, no workgroup barrier).
@@ -50,8 +79,8 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // through an LDS slot) because hipcc otherwise hoists the lane masks into SGPRs and spills; a sched_barrier closes every
 // column to keep the live set small.
 // L goes to the lower triangle; X = L^-1 is kept transposed in the dead strict upper part: X[r][c] <-> a[c][r+1].
-// scr: 32-double exchange line.
-__device__ __forceinline__ int factor_inverse_32(double* a, int j0, double* scr) {
+// scr: 32-double exchange line followed by the 32 reciprocal diagonal entries.
+__device__ __forceinline__ int factor_inverse_32(double* a, int j0, double* scr, double* T1, bool do_inverse) {
   const int i = threadIdx.x & 31;
   const int rowbase = (j0 + i) * DP + j0;
   double* col = scr;
@@ -64,10 +93,14 @@ __device__ __forceinline__ int factor_inverse_32(double* a, int j0, double* scr)
     const double p = readlane_f64(r[j], j);
     const bool bad = !(p > 0.0) || !isfinite(p);     // wave-uniform: dead / padded parameter (H7) -> unit row
     pinned += bad ? 1 : 0;
-    const double d = bad ? 1.0 : sqrt(p);
-    col[i] = bad ? 0.0 : r[j] / d;                   // multipliers of the rows below (junk for rows above: harmless)
+    double d, inv_d;
+    sqrt_rsqrt(p, d, inv_d);                         // one coupled iteration instead of sqrt + a division per column
+    d = bad ? 1.0 : d;
+    inv_d = bad ? 0.0 : inv_d;
+    col[i] = r[j] * inv_d;                           // multipliers of the rows below (junk for rows above: harmless)
     __builtin_amdgcn_wave_barrier();
     col[j] = d;                                      // the diagonal entry, same value from every lane
+    col[SB + j] = bad ? 1.0 : inv_d;                 // 1/L[j][j] for the triangular inverse below (unit row when pinned)
     __builtin_amdgcn_wave_barrier();
     const double l = col[i];
     r[j] = l;
@@ -81,18 +114,44 @@ __device__ __forceinline__ int factor_inverse_32(double* a, int j0, double* scr)
   for (int c = 0; c < SB; ++c) a[rowbase + c] = r[c];
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  // column i of X by forward substitution: x[k] = (delta_ki - sum_{i<=m<k} L[k][m] x[m]) / L[k][k], k = i..31.
-  // x lives in its final place (row j0+i of `a`, shifted by one column); the inner loop is unrolled by 8 so eight LDS
-  // read pairs are in flight (a fully unrolled register-resident version makes hipcc spill ~600 VGPRs).
-  if ((threadIdx.x & 63) < SB) {
-    double* xrow = a + rowbase + 1;
-    for (int k = i; k < SB; ++k) {
-      const double* lrow = a + (j0 + k) * DP + j0;
-      double acc = (k == i) ? 1.0 : 0.0;
-#pragma unroll 8
-      for (int m = i; m < k; ++m) acc = fma(-lrow[m], xrow[m], acc);
-      xrow[k] = acc / lrow[k];
+  // the two 16x16 diagonal blocks of X = L^-1 by forward substitution, 16 columns each on lanes 0..15 / 16..31:
+  // x[k] = (delta_kc - sum_{c<=m<k} L[k][m] x[m]) / L[k][k].  x lives in its final place (shifted by one column); the
+  // inner loop is unrolled by 8 so eight LDS read pairs are in flight (a fully unrolled register-resident version makes
+  // hipcc spill ~600 VGPRs).  The off-diagonal 16x16 block is assembled by the whole workgroup (chol_diag_kernel).
+  if (do_inverse && (threadIdx.x & 63) < SB) {
+    // fixed trip counts + masks: hipcc can then issue all 32 LDS reads of a row at once (a loop with per-lane bounds
+    // degenerates into one dependent LDS round trip per element)
+    const int b0 = j0 + (i & 16), ci = i & 15;
+    double* xrow = a + (b0 + ci) * DP + b0 + 1;
+#pragma unroll 1
+    for (int k = 0; k < 16; ++k) {
+      const double* lrow = a + (b0 + k) * DP + b0;
+      double acc0 = (k == ci) ? 1.0 : 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int m = 0; m < 16; m += 2) {
+        const double x0 = (m >= ci && m < k) ? xrow[m] : 0.0;
+        const double x1 = (m + 1 >= ci && m + 1 < k) ? xrow[m + 1] : 0.0;
+        acc0 = fma(-lrow[m], x0, acc0);
+        acc1 = fma(-lrow[m + 1], x1, acc1);
+      }
+      if (k >= ci) xrow[k] = (acc0 + acc1) * col[SB + (b0 - j0) + k];
     }
+  }
+  if (do_inverse) {
+    // off-diagonal 16x16 block X21 = -X22 (L21 X11) on the matrix pipe (this wave only; DS ops are in order)
+    __builtin_amdgcn_wave_barrier();
+    const int lane = threadIdx.x & 63;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    mfma16(acc, 16, [&](int r, int k) { return a[(j0 + 16 + r) * DP + j0 + k]; },
+           [&](int c, int k) { return (k >= c) ? a[(j0 + c) * DP + j0 + k + 1] : 0.0; });          // X11[k][c]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T1[((lane >> 4) + 4 * q) * (SB + 1) + (lane & 15)] = acc[q];
+    __builtin_amdgcn_wave_barrier();
+    acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+    mfma16(acc, 16, [&](int r, int k) { return (k <= r) ? a[(j0 + 16 + k) * DP + j0 + 16 + r + 1] : 0.0; },   // X22[r][k]
+           [&](int c, int k) { return T1[k * (SB + 1) + c]; });
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[(j0 + (lane & 15)) * DP + j0 + 16 + (lane >> 4) + 4 * q + 1] = -acc[q];
   }
   return pinned;
 }
@@ -101,7 +160,7 @@ __device__ __forceinline__ int factor_inverse_32(double* a, int j0, double* scr)
 // and X = L^-1 (dense lower triangular, zero elsewhere) to Linv.  One workgroup of 256 threads; rows/cols >= n are
 // padded with the identity.  LDS: the 128 x 129 block + three 32 x 33 scratch tiles.
 __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, int64_t lda, int k0, int n, double* __restrict__ Linv,
-                                                       int* __restrict__ info) {
+                                                       int* __restrict__ info, int phase /* diagnostic: 5 = everything */) {
   extern __shared__ double a[];          // [NB][DP] followed by T[3][SB][SB+1]
   double* T = a + NB * DP;
   double* scr = T + 3 * SB * (SB + 1);   // exchange line of factor_inverse_32
@@ -129,69 +188,56 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, 
 #pragma nounroll
   for (int jb = 0; jb < NB / SB; ++jb) {
     const int j0 = jb * SB;
-    if (t < 64) {
-      const int pinned = factor_inverse_32(a, j0, scr);
+    if (phase >= 1 && t < 64) {
+      const int pinned = factor_inverse_32(a, j0, scr, T, phase >= 2);
       if (t == 0 && pinned) atomicAdd(info, pinned);
     }
     __syncthreads();
     const int R = NB - j0 - SB;          // rows (and trailing columns) below this sub-block
-    if (R > 0) {
-      // panel below: L[i][j0+c] = sum_{m<=c} A[i][j0+m] X[c][m]   (thread: row t/8 of each 32-row pass, 4 columns)
-      double accp[3][4];
-      const int cq = (t & 7) * 4;
+    const int lane = t & 63, wave = t >> 6;
+    const int crow = lane >> 4, ccol = lane & 15;    // C/D element q of this lane: (crow + 4q, ccol)
+    if (R > 0 && phase >= 3) {
+      // panel below on the matrix pipe: L[i][j0+c] = sum_{m<=c} A[i][j0+m] X[c][m]; 16-row blocks round-robin over the
+      // waves, both 16-column blocks per row block held in registers until every wave has read its operands
+      const int nib = R / 16;
+      double4_t accp[2][2];
 #pragma unroll
-      for (int ps = 0; ps < 3; ++ps) {
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int ib16 = wave + 4 * s2;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) accp[ps][q] = 0.0;
-        if (ps * SB < R) {
-          const int i = j0 + SB + ps * SB + (t >> 3);
-#pragma unroll 2
-          for (int m = 0; m < SB; ++m) {
-            const double av = a[i * DP + j0 + m];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int c = cq + q;
-              const double xv = (m <= c) ? a[(j0 + m) * DP + j0 + c + 1] : 0.0;
-              accp[ps][q] = fma(av, xv, accp[ps][q]);
-            }
-          }
+        for (int cb = 0; cb < 2; ++cb) {
+          accp[s2][cb] = (double4_t){0.0, 0.0, 0.0, 0.0};
+          if (ib16 < nib)
+            mfma16(accp[s2][cb], SB, [&](int r, int k) { return a[(j0 + SB + 16 * ib16 + r) * DP + j0 + k]; },
+                   [&](int c, int k) { return (k <= 16 * cb + c) ? a[(j0 + k) * DP + j0 + 16 * cb + c + 1] : 0.0; });   // X[c][k]
         }
       }
       __syncthreads();
 #pragma unroll
-      for (int ps = 0; ps < 3; ++ps)
-        if (ps * SB < R) {
-          const int i = j0 + SB + ps * SB + (t >> 3);
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int ib16 = wave + 4 * s2;
+        if (ib16 < nib)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) a[i * DP + j0 + cq + q] = accp[ps][q];
-        }
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[(j0 + SB + 16 * ib16 + crow + 4 * q) * DP + j0 + 16 * cb + ccol] = accp[s2][cb][q];
+      }
       __syncthreads();
-      // trailing update inside the block: A[i][c] -= sum_m L[i][j0+m] L[c][j0+m], 4x4 register tiles, lower part only
-      const int nt = R / 4;
-      for (int tile = t; tile < nt * nt; tile += 256) {
-        const int ti = tile / nt, tc = tile - ti * nt;
-        if (tc > ti) continue;
-        const int i0 = j0 + SB + 4 * ti, c0 = j0 + SB + 4 * tc;
-        double acc[4][4];
+      if (phase >= 4) {
+        // trailing update inside the block: A[i][c] -= sum_m L[i][j0+m] L[c][j0+m] on the lower 16x16 block pairs
+        const int base = j0 + SB;
+        const int npair = nib * (nib + 1) / 2;
+        for (int pr = wave; pr < npair; pr += 4) {
+          int bi, bc;
+          tri_decode(pr, bi, bc);
+          double4_t acc;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+          for (int q = 0; q < 4; ++q) acc[q] = a[(base + 16 * bi + crow + 4 * q) * DP + base + 16 * bc + ccol];
+          mfma16(acc, SB, [&](int r, int k) { return -a[(base + 16 * bi + r) * DP + j0 + k]; },
+                 [&](int c, int k) { return a[(base + 16 * bc + c) * DP + j0 + k]; });
 #pragma unroll
-          for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
-#pragma unroll 2
-        for (int m = 0; m < SB; ++m) {
-          double li[4], lc[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { li[u] = a[(i0 + u) * DP + j0 + m]; lc[u] = a[(c0 + u) * DP + j0 + m]; }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[u][v] = fma(li[u], lc[v], acc[u][v]);
+          for (int q = 0; q < 4; ++q) a[(base + 16 * bi + crow + 4 * q) * DP + base + 16 * bc + ccol] = acc[q];
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int v = 0; v < 4; ++v)
-            if (c0 + v <= i0 + u) a[(i0 + u) * DP + c0 + v] -= acc[u][v];
       }
       __syncthreads();
     }
@@ -203,77 +249,40 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, 
     if (j <= i) A[(int64_t)(k0 + i) * lda + k0 + j] = a[i * DP + j];
   }
 
-  // off-diagonal blocks of X = L^-1:  X_{ib,jb} = -X_{ib,ib} * sum_{mb=jb}^{ib-1} L_{ib,mb} X_{mb,jb},  by block distance.
-  // One 4x4 register tile per thread (64 tiles per 32x32 block, at most 3 blocks per round).
+  // off-diagonal 32x32 blocks of X = L^-1:  X_{ib,jb} = -X_{ib,ib} * sum_{mb=jb}^{ib-1} L_{ib,mb} X_{mb,jb},  by block
+  // distance, on the matrix pipe: every 32x32 block is four 16x16 MFMA blocks, dealt round-robin to the four waves.
   // Storage reminder: X[row][col] (row >= col) <-> a[col][row+1]; entries with row < col of a diagonal X block are L's, so
   // they are masked to zero when read.
+  {
+    const int lane = t & 63, wave = t >> 6;
+    const int crow = lane >> 4, ccol = lane & 15;
 #pragma nounroll
-  for (int dlt = 1; dlt < NB / SB; ++dlt) {
-    const int npairs = NB / SB - dlt;
-    const bool work = t < npairs * 64;
-    const int p = t >> 6, r0 = ((t & 63) >> 3) * 4, c0 = (t & 7) * 4;
-    const int jb = p, ib = p + dlt;
-    if (work) {
-      double acc[4][4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
-      for (int mb = jb; mb < ib; ++mb) {
-        const double* lp = a + (SB * ib + r0) * DP + SB * mb;
-        const double* xp = a + (SB * jb + c0) * DP + SB * mb + 1;
-        const bool diag = (mb == jb);
-#pragma unroll 2
-        for (int m = 0; m < SB; ++m) {
-          double lv[4], xv[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) lv[u] = lp[u * DP + m];
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            xv[v] = xp[v * DP + m];
-            if (diag && m < c0 + v) xv[v] = 0.0;
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[u][v] = fma(lv[u], xv[v], acc[u][v]);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) T[(p * SB + r0 + u) * (SB + 1) + c0 + v] = acc[u][v];
-    }
-    __syncthreads();
-    if (work) {
-      double acc[4][4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
-      const double* xii = a + (SB * ib) * DP + SB * ib + r0 + 1;      // X_ii[r0+u][m] <-> xii[m*DP + u]
-      const double* tp = T + (p * SB) * (SB + 1) + c0;
-#pragma unroll 2
-      for (int m = 0; m < r0 + 4; ++m) {
-        double xv[4], tv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          xv[u] = xii[m * DP + u];
-          if (m > r0 + u) xv[u] = 0.0;
+    for (int dlt = 1; dlt < ((phase >= 5) ? NB / SB : 1); ++dlt) {
+      const int nblk = 4 * (NB / SB - dlt);
+      // T_p = sum_mb L_{ib,mb} X_{mb,jb}
+      for (int b = wave; b < nblk; b += 4) {
+        const int p = b >> 2, rb = (b >> 1) & 1, cb = b & 1, jb = p, ib = p + dlt;
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int mb = jb; mb < ib; ++mb) {
+          const bool diag = (mb == jb);
+          mfma16(acc, SB, [&](int r, int k) { return a[(SB * ib + 16 * rb + r) * DP + SB * mb + k]; },
+                 [&](int c, int k) { return (diag && k < 16 * cb + c) ? 0.0 : a[(SB * jb + 16 * cb + c) * DP + SB * mb + k + 1]; });
         }
 #pragma unroll
-        for (int v = 0; v < 4; ++v) tv[v] = tp[m * (SB + 1) + v];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int v = 0; v < 4; ++v) acc[u][v] = fma(xv[u], tv[v], acc[u][v]);
+        for (int q = 0; q < 4; ++q) T[(p * SB + 16 * rb + crow + 4 * q) * (SB + 1) + 16 * cb + ccol] = acc[q];
       }
+      __syncthreads();
+      // X_{ib,jb} = -X_{ib,ib} T_p   (X_ii lower triangular: only k <= row contributes)
+      for (int b = wave; b < nblk; b += 4) {
+        const int p = b >> 2, rb = (b >> 1) & 1, cb = b & 1, jb = p, ib = p + dlt;
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        mfma16(acc, 16 * (rb + 1), [&](int r, int k) { return (k <= 16 * rb + r) ? a[(SB * ib + k) * DP + SB * ib + 16 * rb + r + 1] : 0.0; },
+               [&](int c, int k) { return T[(p * SB + k) * (SB + 1) + 16 * cb + c]; });
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) a[(SB * jb + c0 + v) * DP + SB * ib + r0 + u + 1] = -acc[u][v];
+        for (int q = 0; q < 4; ++q) a[(SB * jb + 16 * cb + ccol) * DP + SB * ib + 16 * rb + crow + 4 * q + 1] = -acc[q];
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   for (int idx = t; idx < NB * NB; idx += 256) {
     const int i = idx / NB, c = idx - i * NB;
@@ -296,11 +305,102 @@ __global__ __launch_bounds__(256, 2) void chol_trsm_kernel(double* __restrict__ 
   tile_store_global(acc, A + (int64_t)row0 * lda + k0, lda, rows, n, 0);
 }
 
-// Trailing update: A22 -= L21 L21^T on the lower-triangle tiles (syrk, K = n)
-__global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double* __restrict__ A, int64_t lda, int P, int k0, int n) {
+// Latency-optimised strip kernel for the two short dependent GEMMs of every panel (K = 128 exactly):
+//   mode 0 (panel solve):        A[row0.., k0:k0+128] <- A[row0.., k0:k0+128] * Linv^T          (B = Linv, 128 x 128)
+//   mode 1 (next-panel update):  A[row0.., c0:c0+128] -= A[row0.., k0:k0+128] * A[c0.., k0:k0+128]^T   (c0 = k0+128)
+// One workgroup = a 32-row strip x all 128 columns (4 waves, 32 x 32 each), so a block row is spread over four CUs and
+// the whole K range is in flight at once: every global load of both K-halves is issued before the first wait (one
+// workgroup per CU, up to 512 VGPRs), then two LDS stage / MFMA rounds.  The 128-wide tile engine needs ~40 us for
+// the same work on these small grids (one K-step of prefetch, 13.7 us of MFMA per 128^3 tile on a single CU).
+constexpr int SK = 64;            // K half
+constexpr int SP = SK + 2;        // LDS pitch: 4r + 2k dwords mod 64 distinct over a half-wave of ds_read_b64
+__global__ __launch_bounds__(256, 1) void chol_strip_kernel(double* __restrict__ A, int64_t lda, int P, int k0, int mode,
+                                                            const double* __restrict__ Linv) {
+  extern __shared__ double lds[];          // Bs[128][SP] then As[32][SP]
+  double* Bs = lds;
+  double* As = lds + NB * SP;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int row0 = k0 + NB + blockIdx.x * 32;            // first row of this strip (a row below the panel)
+  const int c0 = k0 + NB;                                // first row of the B operand in mode 1
+  const double* __restrict__ Bsrc = mode ? (A + (int64_t)c0 * lda + k0) : Linv;
+  const int64_t ldb = mode ? lda : NB;
+  const double* __restrict__ Asrc = A + (int64_t)row0 * lda + k0;
+  // ---- issue every load: per K-half 16 double2 of B (128 rows x 32 double2) and 4 of A (32 rows x 32 double2) per thread
+  double2_t vb[2][16], va[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int idx = q * 256 + t, r = idx >> 5, kp = (idx & 31) * 2;
+      vb[h][q] = *reinterpret_cast<const double2_t*>(Bsrc + (int64_t)r * ldb + h * SK + kp);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = q * 256 + t, r = idx >> 5, kp = (idx & 31) * 2;
+      va[h][q] = *reinterpret_cast<const double2_t*>(Asrc + (int64_t)r * lda + h * SK + kp);
+    }
+  }
+  double4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int idx = q * 256 + t, r = idx >> 5, kp = (idx & 31) * 2;
+      *reinterpret_cast<double2_t*>(Bs + r * SP + kp) = vb[h][q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = q * 256 + t, r = idx >> 5, kp = (idx & 31) * 2;
+      *reinterpret_cast<double2_t*>(As + r * SP + kp) = va[h][q];
+    }
+    __syncthreads();
+    const double* __restrict__ ap = As + lr * SP + lk;
+    const double* __restrict__ bp = Bs + (32 * wave + lr) * SP + lk;
+#pragma unroll 4
+    for (int k4 = 0; k4 < SK / 4; ++k4) {
+      const double a0 = ap[4 * k4], a1 = ap[16 * SP + 4 * k4];
+      const double b0 = bp[4 * k4], b1 = bp[16 * SP + 4 * k4];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: wave w owns columns 32w..32w+31 of the strip
+  double* __restrict__ C = A + (int64_t)row0 * lda + (mode ? c0 : k0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * i + (lane >> 4) + 4 * r;
+        const int col = 32 * wave + 16 * j + (lane & 15);
+        if (row0 + row < P && (mode == 0 || c0 + col < P)) {
+          double* p = C + (int64_t)row * lda + col;
+          *p = mode ? (*p - acc[i][j][r]) : acc[i][j][r];
+        }
+      }
+}
+
+// Trailing update: A22 -= L21 L21^T on the lower-triangle tiles (syrk, K = n).
+// part 0: all tiles; part 1: only the first block column (ti, 0) -- the next panel; part 2: the remaining tiles (tj >= 1).
+__global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double* __restrict__ A, int64_t lda, int P, int k0, int n, int part) {
   extern __shared__ double lds[];
   int ti, tj;
-  tri_decode(blockIdx.x, ti, tj);
+  if (part == 1) {
+    ti = blockIdx.x;
+    tj = 0;
+  } else {
+    tri_decode(blockIdx.x, ti, tj);
+    if (part == 2) { ++ti; ++tj; }
+  }
   const int base = k0 + n;
   const int rowA0 = base + ti * TILE, rowB0 = base + tj * TILE;
   const int rowsA = (P - rowA0 < TILE) ? (P - rowA0) : TILE;
@@ -324,22 +424,17 @@ __device__ __forceinline__ void diag_apply(const double* __restrict__ Linv, doub
   if (!trans) {
     const int lane = t & 63, wave = t >> 6;
     const double x0 = sh[2 * lane], x1 = sh[2 * lane + 1];
-#pragma unroll 1
-    for (int rr = 0; rr < 32; rr += 8) {
-      double s[8];
+    // all 32 rows of this wave in flight at once (one memory latency instead of four)
+    double2_t v[32];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const double2_t v = *reinterpret_cast<const double2_t*>(Linv + (wave * 32 + rr + u) * NB + 2 * lane);
-        s[u] = v.x * x0 + v.y * x1;     // Linv is exactly zero above the diagonal and in padded rows
-      }
+    for (int u = 0; u < 32; ++u) v[u] = *reinterpret_cast<const double2_t*>(Linv + (wave * 32 + u) * NB + 2 * lane);
+    double mine = 0.0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s[u] = wave_sum(s[u]);
-      if (lane == 0) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (wave * 32 + rr + u < n) r[wave * 32 + rr + u] = s[u];
-      }
+    for (int u = 0; u < 32; ++u) {
+      const double su = wave_sum(v[u].x * x0 + v[u].y * x1);     // Linv is exactly zero above the diagonal and in padded rows
+      if (lane == u) mine = su;
     }
+    if (lane < 32 && wave * 32 + lane < n) r[wave * 32 + lane] = mine;
   } else {
     const int j = t & (NB - 1), half = t >> 7;
     double s = 0.0;
@@ -368,21 +463,18 @@ __global__ __launch_bounds__(256) void solve_fwd_step(const double* __restrict__
   // 4 waves x 32 rows; a row is 64 lanes x 2 columns; rows beyond P are zero-padded storage
   const int lane = t & 63, wave = t >> 6;
   const double y0 = yk[2 * lane], y1 = yk[2 * lane + 1];
-#pragma unroll 1
-  for (int rr = 0; rr < 32; rr += 8) {
-    double s[8];
+  {
+    double2_t v[32];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const double2_t v = *reinterpret_cast<const double2_t*>(L + (int64_t)(b0 + wave * 32 + rr + u) * lda + k0 + 2 * lane);
-      s[u] = v.x * y0 + v.y * y1;
+    for (int u = 0; u < 32; ++u) v[u] = *reinterpret_cast<const double2_t*>(L + (int64_t)(b0 + wave * 32 + u) * lda + k0 + 2 * lane);
+    const double rold = (lane < 32 && wave * 32 + lane < nbk) ? r[b0 + wave * 32 + lane] : 0.0;
+    double mine = 0.0;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      const double su = wave_sum(v[u].x * y0 + v[u].y * y1);
+      if (lane == u) mine = su;
     }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s[u] = wave_sum(s[u]);
-    if (lane == 0) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (wave * 32 + rr + u < nbk) r[b0 + wave * 32 + rr + u] -= s[u];
-    }
+    if (lane < 32 && wave * 32 + lane < nbk) r[b0 + wave * 32 + lane] = rold - mine;
   }
   __syncthreads();
   if (blockIdx.x == 0) diag_apply(Linv_all + (int64_t)b * NB * NB, r + b0, nbk, 0, sh, part);
@@ -480,26 +572,52 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
   hipStream_t st = (hipStream_t)stream;
   double* Linv = static_cast<double*>(workspace);
   const int nb = (P + NB - 1) / NB;
-  const size_t diag_lds = ((size_t)NB * DP + 3 * SB * (SB + 1) + SB) * sizeof(double);
+  const size_t diag_lds = ((size_t)NB * DP + 3 * SB * (SB + 1) + 2 * SB) * sizeof(double);
   const size_t tile_lds = TILE_LDS_BYTES;
+  const size_t strip_lds = (size_t)(NB + 32) * SP * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
-    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
+    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds));
     VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
     attr_set = true;
   }
   VMC_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), st));
+  // Lookahead: the diagonal block of panel k+1 only depends on the first block column of panel k's trailing update, so it
+  // is factored on an internal side stream while the rest of that update runs on the caller's stream.  The fork/join is
+  // anchored on the caller's stream with events: from outside, all work is ordered in `stream` as usual.
+  static const int diag_phase = getenv("VMCPDE_DIAG_PHASE") ? atoi(getenv("VMCPDE_DIAG_PHASE")) : 5;   // timing diagnostics only
+  static hipStream_t side = nullptr;
+  static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  if (side == nullptr) {
+    VMC_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    VMC_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    VMC_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
+  {
+    const int n0 = (P < NB) ? P : NB;
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), diag_lds, st, A, lda, 0, n0, Linv, info, diag_phase);
+  }
   for (int k = 0; k < nb; ++k) {
     const int k0 = k * NB;
     const int n = (P - k0 < NB) ? (P - k0) : NB;
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), diag_lds, st, A, lda, k0, n, Linv + (int64_t)k * NB * NB, info);
     const int rem = P - (k0 + n);
-    if (rem > 0) {
-      const int nrem = (rem + TILE - 1) / TILE;
-      hipLaunchKernelGGL(chol_trsm_kernel, dim3(nrem), dim3(256), tile_lds, st, A, lda, P, k0, n, Linv + (int64_t)k * NB * NB);
-      hipLaunchKernelGGL(chol_syrk_kernel, dim3((unsigned)tri_count(nrem)), dim3(256), tile_lds, st, A, lda, P, k0, n);
+    if (rem <= 0) break;
+    const int nrem = (rem + TILE - 1) / TILE;
+    // n == NB here (a panel with rows below it is always full); row strips of 32 over the zero-padded row range
+    hipLaunchKernelGGL(chol_strip_kernel, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 0, Linv + (int64_t)k * NB * NB);
+    hipLaunchKernelGGL(chol_strip_kernel, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 1, Linv);
+    VMC_CHECK_HIP(hipEventRecord(ev_fork, st));
+    VMC_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+    {
+      const int k1 = k0 + n;
+      const int n1 = (P - k1 < NB) ? (P - k1) : NB;
+      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), diag_lds, side, A, lda, k1, n1, Linv + (int64_t)(k + 1) * NB * NB, info, diag_phase);
     }
+    VMC_CHECK_HIP(hipEventRecord(ev_join, side));
+    if (nrem > 1)
+      hipLaunchKernelGGL(chol_syrk_kernel, dim3((unsigned)tri_count(nrem - 1)), dim3(256), tile_lds, st, A, lda, P, k0, n, 2);
+    VMC_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
   }
   VMC_CHECK_HIP(hipGetLastError());
   return 0;

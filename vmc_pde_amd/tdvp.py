@@ -204,9 +204,14 @@ class TDVP:
     # ---- tdvp.py:57-71 -------------------------------------------------------------------------------------------
     def transform_to_eigenbasis(self, S, F, EOdata=None):
         P = F.numel()
+        done = False
         if self.diagonalizeOnDevice:
-            self.ev, self.V = torch.linalg.eigh(S)                            # tdvp.py:59 (rocSOLVER)
-        else:
+            try:
+                self.ev, self.V = torch.linalg.eigh(S)                        # tdvp.py:59 (rocSOLVER)
+                done = True
+            except RuntimeError:                                              # rocSOLVER did not converge: fall back to LAPACK
+                done = False
+        if not done:
             tmpEv, tmpV = np.linalg.eigh(S.detach().cpu().numpy())            # tdvp.py:61-64 (host LAPACK)
             self.ev = torch.from_numpy(tmpEv).to(F.device)
             self.V = torch.from_numpy(tmpV).to(F.device)
