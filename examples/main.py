@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""The reference driver loop (vmc_fluids/main.py:60-210, plumbing only: no plots) on vmc_pde_amd.
+
+    python examples/main.py [--mode mwe|diffusion|harmonicOsc|harmonicOsc_diff] [--t-end 0.05] [--samples 10000]
+
+Same objects, same call sequence, same printed diagnostics and `infos` keys as the reference; arrays are fp64 torch tensors
+on the GPU.  The `infos` record is written to <wdir>/infos.npz, and -- what the reference lacks -- the parameters are
+checkpointed every step to <wdir>/checkpoint.pt so a run can be resumed with --resume.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vmc_pde_amd import var_state, sampler as sampler_mod, evolutionEq as evolutionEq_mod, tdvp, stepper, util, grid as grid_mod  # noqa: E402
+
+
+def norm_fun(v, S):          # main.py:24-26
+    return v @ S @ v
+
+
+mode_dict = {  # main.py:33-38
+    "harmonicOsc": {"offset": np.ones(2), "dim": 2, "latent_space_name": "Gauss", "mcmcbound": 0.25, "gridbound": 8., "symgrid": True, "evolution_type": "advection_hamiltonian"},
+    "harmonicOsc_diff": {"offset": np.array([1., 0, 0, 1, 0, 0]), "dim": 6, "latent_space_name": "Gauss", "mcmcbound": 0.25, "gridbound": 8., "symgrid": True, "evolution_type": "advection_hamiltonian_wDiss"},
+    "diffusion": {"offset": np.zeros(8), "dim": 8, "latent_space_name": "Student_t", "mcmcbound": 0.25, "gridbound": 10., "symgrid": True, "evolution_type": "diffusion"},
+    "diffusion_anisotropic": {"offset": np.zeros(12), "dim": 12, "latent_space_name": "Gauss", "mcmcbound": 0.25, "gridbound": 10., "symgrid": True, "evolution_type": "diffusion_anisotropic"},
+    "mwe": {"offset": np.zeros(2), "dim": 2, "latent_space_name": "Gauss", "mcmcbound": 0.25, "gridbound": 10., "symgrid": True, "evolution_type": "diffusion"},
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="mwe", choices=sorted(mode_dict))
+    ap.add_argument("--t-end", type=float, default=5.0)
+    ap.add_argument("--samples", type=int, default=10000)
+    ap.add_argument("--wdir", default=None)
+    ap.add_argument("--resume", action="store_true")
+    args = ap.parse_args()
+    m = mode_dict[args.mode]
+    dim, offset = m["dim"], m["offset"]
+    initKey = 1
+
+    smp = sampler_mod.Sampler(dim=dim, numChains=30, name=m["latent_space_name"], mcmc_info={"offset": offset, "bound": m["mcmcbound"]})   # main.py:69
+    vState = var_state.VarState(smp, dim, initKey, 4, network_args={"intmediate": (dim // 2,) * 1, "offset": offset,
+                                                                     "latentSpaceName": m["latent_space_name"], "dim": dim})              # main.py:73
+    print(f"Number of Model parameters: {vState.numParameters}")
+    x_real = torch.ones(dim, dtype=torch.float64)                                                                                          # main.py:77-96
+    z_latent, _ = vState.net.apply(vState.params, x_real, evaluate=False, inv=False)
+    x_back, _ = vState.net.apply(vState.params, z_latent, evaluate=False, inv=True)
+    print(z_latent, x_back)
+    if dim == 2:                                                                                                                           # main.py:100-105
+        g = grid_mod.Grid(np.ones(dim) * m["gridbound"], 200, sym=m["symgrid"])
+        print("Integral value:", float(vState.integrate(g)))
+
+    dt, maxStep = 1e-7, 1e-2                                                                                                               # main.py:108-118
+    myStepper = stepper.FixedStepper(timeStep=dt, mode='Heun', maxStep=maxStep, increase_fac=1.3)
+    tdvpEq = tdvp.TDVP()
+    timings = util.Timings()
+    evolutionEq = evolutionEq_mod.EvolutionEquation(dim=dim, name=m["evolution_type"])
+    nSamplesTDVP = nSamplesObs = args.samples
+    wdir = args.wdir or f"output/{args.mode}/NsamplesTDVP{nSamplesTDVP}_NsamplesObs{nSamplesObs}/"
+    os.makedirs(wdir, exist_ok=True)
+
+    t = 0.0
+    infos = {"times": [], "ev": [], "snr": [], "solver_res": [], "tdvp_error": [], "dist_params": []}                                     # main.py:157
+    ckpt = os.path.join(wdir, "checkpoint.pt")
+    if args.resume and os.path.exists(ckpt):
+        st = torch.load(ckpt)
+        vState.set_parameters(st["theta"])
+        t, myStepper.dt, smp._calls = st["t"], st["dt"], st["sampler_calls"]
+        print(f"resumed at t = {t}")
+    while t < args.t_end + dt:                                                                                                             # main.py:159
+        t1 = time.perf_counter()
+        dp, dt, info = myStepper.step(0, tdvpEq, vState.get_parameters(), evolutionEq=evolutionEq, psi=vState, nSamplesTDVP=nSamplesTDVP,
+                                      nSamplesObs=nSamplesObs, normFunction=norm_fun, timings=timings, integrals=False)
+        vState.set_parameters(dp)
+        infos["times"].append(t)
+        print(f"t = {t:.3f}, dt = {dt:e}")
+        print("\t Timings:")
+        timings.print_timings()
+        print(f"\t Total (in main.py): {time.perf_counter() - t1}")
+        print("\t Data:")
+        print(f"\t > Solver Residual = {float(tdvpEq.solverResidual)}")
+        print(f"\t > TDVP Error = {float(tdvpEq.tdvp_error)}")
+        print(f"\t > Entropy = {float(info['entropy'])}")
+        print(f"\t > dist params = {vState.params['params']['dist_params']}")
+        print(f"\t > Means = {info['x1']}")
+        for key in info.keys():
+            infos.setdefault(key, []).append(info[key])
+        infos["ev"].append(tdvpEq.ev)
+        infos["snr"].append(tdvpEq.snr)
+        infos["solver_res"].append(tdvpEq.solverResidual)
+        infos["tdvp_error"].append(tdvpEq.tdvp_error)
+        infos["dist_params"].append(vState.params['params']['dist_params'].clone())
+        t = t + dt
+        torch.save({"theta": vState.get_parameters().cpu(), "t": t, "dt": myStepper.dt, "sampler_calls": smp._calls}, ckpt)
+    util.store_infos(wdir, infos)                                                                                                          # main.py:209
+    print("wrote", wdir + "infos.npz")
+
+
+if __name__ == "__main__":
+    main()

@@ -186,3 +186,39 @@ def test_gaussian_diffusion_known_answer_on_gpu():
     assert torch.allclose(t.S0.cpu(), 2 * torch.eye(dim, dtype=torch.float64), atol=0.08)   # 5 sigma of the MC estimate
     assert torch.allclose(upd.cpu(), torch.ones(dim, dtype=torch.float64), atol=0.04)
     assert abs(float(err)) < 3e-3
+
+
+def test_lagged_centring_equals_exact_centring():
+    # steady state uses the previous call's mean as the shift of the one-pass moments (tdvp.py `centering`): same (S, F)
+    import vmc_pde_amd as V
+    spec, th, nrm, chi2, eo, ep = _problem(2, 3, (4, 4), "Gauss", "no_add", "advection_hamiltonian_wDiss", 3000, lam=0.1)
+    z = O.latent_from_normals(spec, th, nrm, chi2).cuda()
+    th1 = th + 2e-2 * torch.sin(torch.arange(th.numel(), dtype=torch.float64))
+    out = {}
+    for mode in ("exact", "auto"):
+        vs = make_varstate(spec, th, sampler=FixedSampler(z))
+        t = V.TDVP(solver="eigh", centering=mode)
+        t(th.cuda(), 0.0, vs, ep, nSamplesTDVP=3000, nSamplesObs=3000, timings=None, observables=False)
+        t(th1.cuda(), 0.0, vs, ep, nSamplesTDVP=3000, nSamplesObs=3000, timings=None, observables=False)   # "auto": lagged now
+        out[mode] = (t.S0.clone(), t.F0.clone(), float(t.ElocMean))
+    assert rel_err(out["auto"][0], out["exact"][0]) < 1e-12
+    assert rel_err(out["auto"][1], out["exact"][1]) < 1e-11
+    assert abs(out["auto"][2] - out["exact"][2]) < 1e-12 * (1 + abs(out["exact"][2]))
+
+
+def test_reference_driver_loop_mwe(tmp_path):
+    # BASELINE config 1 ("plumbing"): the main.py loop of the reference on this package, a few Heun steps, infos keys, resume
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "examples", "main.py"), "--mode", "mwe", "--samples", "1024", "--t-end", "3e-6", "--wdir", str(tmp_path) + "/"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Number of Model parameters: 37" in out.stdout            # KA-7
+    assert "Integral value: 1.0" in out.stdout or "Integral value: 0.99" in out.stdout   # main.py:104 (KA-3)
+    rec = np.load(os.path.join(str(tmp_path), "infos.npz"))
+    for key in ("times", "ev", "snr", "solver_res", "tdvp_error", "dist_params", "x1", "covar", "entropy", "x3", "x4", "x5", "x6", "max_grad"):
+        assert key in rec.files, key
+    n = len(rec["times"])
+    assert rec["ev"].shape == (n, 37) and rec["snr"].shape == (n, 37) and rec["covar"].shape == (n, 2, 2)
+    out2 = subprocess.run(cmd + ["--resume", "--t-end", "6e-6"], capture_output=True, text=True, timeout=300)
+    assert out2.returncode == 0 and "resumed at t" in out2.stdout

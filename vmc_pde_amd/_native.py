@@ -13,7 +13,9 @@ from pathlib import Path
 import torch
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "_lib" / "libvmcpde.so"
+import os as _os
+
+LIB_PATH = Path(_os.environ["VMCPDE_LIB"]) if _os.environ.get("VMCPDE_LIB") else _HERE / "_lib" / "libvmcpde.so"   # override: A/B builds
 HEADER_PATH = _HERE.parent / "include" / "vmcpde.h"
 
 MAX_DIM = 16

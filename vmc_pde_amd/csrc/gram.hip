@@ -16,6 +16,8 @@
 // (144 B pitch: the 16 rows x 2 k-columns a ds_read_b64 wave-instruction touches fall on 64 distinct banks).
 // Split-K over the sample axis gives >= 8 work units per CU-slot; partial tiles go to a workspace and are summed by
 // a deterministic second kernel (no atomics: bitwise reproducible, which the replicated multi-GPU solve relies on).
+#include <cstdlib>
+
 #include "mfma_tile.hpp"
 
 using namespace vmcpde;
@@ -33,8 +35,8 @@ GramPlan make_plan(int P, int64_t N) {
   GramPlan g;
   g.nb = (P + TILE - 1) / TILE;
   g.ntiles = (int)tri_count(g.nb);
-  // aim at >= 8 rounds of the 512 resident workgroup slots (256 CUs x 2) so the tail round costs < 1/8,
-  // but keep each unit >= 64 K-steps so prologue/epilogue stay negligible
+  // aim at >= 8 rounds of the 512 resident workgroup slots (256 CUs x 2) but keep each unit >= 64 K-steps so
+  // prologue/epilogue stay negligible; among the next few split factors take the one whose last round is fullest
   const int64_t ksteps = (N + BK - 1) / BK;
   int64_t want = (8 * 512 + g.ntiles - 1) / g.ntiles;
   int64_t maxsplit = ksteps / 64;
@@ -42,6 +44,17 @@ GramPlan make_plan(int P, int64_t N) {
   int64_t ns = want < maxsplit ? want : maxsplit;
   if (ns < 1) ns = 1;
   if (ns > 64) ns = 64;
+  if (ns > 1) {
+    double best = 1e30;
+    int64_t pick = ns;
+    for (int64_t c = ns; c <= ns + 4 && c <= maxsplit && c <= 64; ++c) {
+      const double rounds = (double)(g.ntiles * c) / 512.0;
+      const double waste = (double)(int64_t)(rounds + 0.999999) / rounds;   // ceil(rounds) / rounds
+      if (waste < best - 1e-9) { best = waste; pick = c; }
+    }
+    ns = pick;
+  }
+  if (getenv("VMCPDE_GRAM_NSPLIT")) ns = atoi(getenv("VMCPDE_GRAM_NSPLIT"));   // tuning knob
   int64_t steps_per = (ksteps + ns - 1) / ns;
   g.chunk = steps_per * BK;
   g.nsplit = (int)((N + g.chunk - 1) / g.chunk);
@@ -53,15 +66,27 @@ template <bool SCALE>
 __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__ JT, int64_t ldj, int P, int64_t N,
                                                       const double* __restrict__ c, const double* __restrict__ scale,
                                                       int ntiles, int nsplit, int64_t chunk, int total_units,
-                                                      int units_per_xcd, double* __restrict__ out) {
+                                                      int units_per_xcd, int order, double* __restrict__ out) {
   extern __shared__ double lds[];
-  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2), so give each XCD
-  // a contiguous run of units = neighbouring tiles of the same sample chunk, whose operand panels overlap.
-  const int unit = (int)(blockIdx.x & 7) * units_per_xcd + (int)(blockIdx.x >> 3);
-  if (unit >= total_units) return;
-  const int split = unit / ntiles;
+  // XCD-aware order.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2) and started in
+  // blockIdx order, so slot = blockIdx / 8 is "time".  order 1 (default): all XCDs sweep the SAME sample chunk at the
+  // same time -- slot -> (split, local tile), XCD x owns a contiguous run of that split's tiles -- which keeps the
+  // chip-wide working set at one or two chunks of J (Infinity-Cache sized) and neighbouring tiles (shared operand
+  // panels) on one L2.  order 0: one sample chunk per XCD (eight chunks in flight).
+  int split, tile;
+  if (order == 1) {
+    const int slot = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
+    split = slot / units_per_xcd;                      // units_per_xcd = tiles per XCD per split here
+    tile = xcd * units_per_xcd + (slot - split * units_per_xcd);
+    if (tile >= ntiles || split >= nsplit) return;
+  } else {
+    const int unit = (int)(blockIdx.x & 7) * units_per_xcd + (int)(blockIdx.x >> 3);
+    if (unit >= total_units) return;
+    split = unit / ntiles;
+    tile = unit - split * ntiles;
+  }
   int ti, tj;
-  tri_decode(unit - split * ntiles, ti, tj);
+  tri_decode(tile, ti, tj);
   const int64_t k0 = (int64_t)split * chunk;
   const int64_t k1 = (k0 + chunk < N) ? (k0 + chunk) : N;
   const int rowA0 = ti * TILE, rowB0 = tj * TILE;
@@ -73,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
   tile_mainloop<SCALE>(acc, JT, ldj, rowA0, JT, ldj, rowB0, ti == tj, k0, k1, c, rowsA, c, rowsB, scale, lds);
-  tile_store(acc, out + ((int64_t)split * ntiles + (unit - split * ntiles)) * (TILE * TILE));
+  tile_store(acc, out + ((int64_t)split * ntiles + tile) * (TILE * TILE));
 }
 
 // packed[tile][e] = sum_split slabs[split][tile][e]   (fixed order -> deterministic)
@@ -265,10 +290,13 @@ extern "C" int vmcpde_gram(const double* JT, int64_t ldj, int32_t P, int64_t n_s
     out = static_cast<double*>(workspace);
   }
   hipStream_t st = (hipStream_t)stream;
+  static const int order = getenv("VMCPDE_GRAM_ORDER") ? atoi(getenv("VMCPDE_GRAM_ORDER")) : 1;   // tuning knob
   const int total = g.ntiles * g.nsplit;
-  const int per_xcd = (total + 7) / 8;
-  const int grid = per_xcd * 8;
-  const size_t lds_bytes = TILE_LDS_BYTES;
+  const int per_xcd = (order == 1) ? (g.ntiles + 7) / 8 : (total + 7) / 8;
+  const int grid = (order == 1) ? per_xcd * 8 * g.nsplit : per_xcd * 8;
+  // tuning knob: extra dynamic LDS forces one workgroup per CU (to measure what the co-resident partner is worth)
+  static const size_t lds_pad = getenv("VMCPDE_GRAM_LDSPAD") ? (size_t)atoi(getenv("VMCPDE_GRAM_LDSPAD")) : 0;
+  const size_t lds_bytes = TILE_LDS_BYTES + lds_pad;
   static bool attr_set = false;
   if (!attr_set) {
     VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -277,10 +305,10 @@ extern "C" int vmcpde_gram(const double* JT, int64_t ldj, int32_t P, int64_t n_s
   }
   if (w)
     hipLaunchKernelGGL(gram_kernel<true>, dim3(grid), dim3(256), lds_bytes, st, JT, ldj, P, n_samples, c, w, g.ntiles, g.nsplit,
-                       g.chunk, total, per_xcd, out);
+                       g.chunk, total, per_xcd, order, out);
   else
     hipLaunchKernelGGL(gram_kernel<false>, dim3(grid), dim3(256), lds_bytes, st, JT, ldj, P, n_samples, c, w, g.ntiles, g.nsplit,
-                       g.chunk, total, per_xcd, out);
+                       g.chunk, total, per_xcd, order, out);
   VMC_CHECK_HIP(hipGetLastError());
   if (g.nsplit > 1) {
     const int64_t per_split = (int64_t)g.ntiles * TILE * TILE;

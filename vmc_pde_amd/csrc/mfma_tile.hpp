@@ -7,7 +7,7 @@
 // Workgroup = 256 threads = 4 waves as 2x2, 64x64 per wave = 4x4 MFMA blocks = 128 accumulator VGPRs, so two
 // workgroups fit per CU (two waves per SIMD: one feeds the matrix pipe while its partner stages).
 // K-step BK = 16: operands go global -> registers (issued one K-step ahead, centred / scaled in flight) -> LDS rows of
-// 18 doubles (pitch 144 B: the 16 rows x 2 k-columns one ds_read_b64 half-wave touches fall on 32 distinct bank pairs).
+// 17 doubles (pitch 136 B, conflict-free fragment reads; staged with 8-byte LDS writes since rows are only 8-B aligned).
 //
 // Contract (checked by the host wrappers): operand matrices have all 128 rows of every tile allocated (row padding
 // is zero-filled by the owner), row pitch even (16-B aligned double2 loads), 128 * pitch * 8 < 2^32.
@@ -21,7 +21,9 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 
 constexpr int TILE = VMCPDE_GRAM_TILE;  // 128
 constexpr int BK = 16;
-constexpr int LDP = BK + 2;             // LDS row pitch in doubles
+constexpr int LDP = BK + 1;             // LDS row pitch in doubles: 34 dwords = 2 (mod 32) and (mod 64), so the 16 rows one
+                                        // fragment read touches sit on distinct banks for ds_read_b64 AND ds_read2_b64 (hipcc
+                                        // merges two K-columns into read2, which banks mod 32: pitch 18 measured 40 % conflict cycles)
 constexpr int TILE_LDS = TILE * LDP;    // doubles per staged operand tile
 constexpr int TILE_LDS_DOUBLES = 4 * TILE_LDS + 2 * TILE;   // 2 operands x 2 buffers + the two shift vectors
 constexpr size_t TILE_LDS_BYTES = TILE_LDS_DOUBLES * sizeof(double);   // 75,776 B -> two workgroups per CU
@@ -83,19 +85,21 @@ __device__ __forceinline__ void stage_store(const Staged& r, double* __restrict_
       if (!(kp + 1 < krem)) v.y = 0.0;
     }
     if (SCALE) { v.x *= r.sc.x; v.y *= r.sc.y; }
-    *reinterpret_cast<double2_t*>(lds + tile_off + row * LDP + kp) = v;
+    lds[tile_off + row * LDP + kp] = v.x;       // odd pitch: 8-byte stores (ds_write2_b64)
+    lds[tile_off + row * LDP + kp + 1] = v.y;
   }
 }
 
-// acc[i][j] += A_tile(64 rows of this wave) * B_tile(64 rows of this wave)^T over one staged K-step
-__device__ __forceinline__ void mma_kstep(double4_t (&acc)[4][4], const double* __restrict__ lds, int offAs, int offBs,
-                                          int wr, int wc) {
+// acc[i][j] += A_tile(64 rows of this wave) * B_tile(64 rows of this wave)^T over K-columns [4*K4A, 4*K4B) of one staged K-step
+template <int K4A, int K4B>
+__device__ __forceinline__ void mma_part(double4_t (&acc)[4][4], const double* __restrict__ lds, int offAs, int offBs,
+                                         int wr, int wc) {
   const int lane = threadIdx.x & 63;
   const int lr = lane & 15, lk = lane >> 4;
   const double* __restrict__ ap = lds + offAs + (64 * wr + lr) * LDP + lk;
   const double* __restrict__ bp = lds + offBs + (64 * wc + lr) * LDP + lk;
 #pragma unroll
-  for (int k4 = 0; k4 < BK / 4; ++k4) {
+  for (int k4 = K4A; k4 < K4B; ++k4) {
     double a[4], b[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[i] = ap[16 * i * LDP + 4 * k4];
@@ -106,6 +110,11 @@ __device__ __forceinline__ void mma_kstep(double4_t (&acc)[4][4], const double* 
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
   }
+}
+
+__device__ __forceinline__ void mma_kstep(double4_t (&acc)[4][4], const double* __restrict__ lds, int offAs, int offBs,
+                                          int wr, int wc) {
+  mma_part<0, BK / 4>(acc, lds, offAs, offBs, wr, wc);
 }
 
 // Main loop of one tile.  alias: the B tile is the A tile (diagonal tile of a syrk) -> only A is staged.
@@ -157,15 +166,28 @@ __device__ __forceinline__ void tile_mainloop(double4_t (&acc)[4][4], const doub
   }
   __syncthreads();
   int cur = 0;
-  // steady state: every step issues the next FULL step's loads, runs the 64 MFMAs of the current one, then stages
+  // steady state.  Registers ra/rb hold the raw loads of step s+1 on entry.  Each iteration: first half of the MFMAs of
+  // step s; then (loads have been in flight for a full iteration) centre + write step s+1 into the other LDS buffer and
+  // immediately re-issue the loads of step s+2 into the same registers; second half of the MFMAs covers the LDS writes,
+  // so the closing barrier finds them done.  sched_barriers pin this order (hipcc would hoist the vmcnt wait).
   int64_t k = k0;
-  for (int64_t s = 0; s + 1 < nfull; ++s, k += BK) {
+  if (nfull > 1) {
     stage_load<SCALE, false>(ra, tA + k + BK, offA, strideA, SCALE ? scale + k + BK : nullptr, BK);
     if (!alias) stage_load<SCALE, false>(rb, tB + k + BK, offB, strideB, SCALE ? scale + k + BK : nullptr, BK);
-    mma_kstep(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc);
-    __builtin_amdgcn_sched_barrier(0);   // keep the centring + ds_write (and their vmcnt wait) behind the MFMAs
+  }
+  for (int64_t s = 0; s + 1 < nfull; ++s, k += BK) {
+    mma_part<0, BK / 8>(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);   // let the short VALU/LDS staging burst win issue slots over the partner's MFMAs (+0.5 % measured)
     stage_store<SCALE, false>(ra, lds, (cur ^ 1) * 2 * TILE_LDS, SHA, BK);
     if (!alias) stage_store<SCALE, false>(rb, lds, (cur ^ 1) * 2 * TILE_LDS + TILE_LDS, SHB, BK);
+    if (s + 2 < nfull) {
+      stage_load<SCALE, false>(ra, tA + k + 2 * BK, offA, strideA, SCALE ? scale + k + 2 * BK : nullptr, BK);
+      if (!alias) stage_load<SCALE, false>(rb, tB + k + 2 * BK, offB, strideB, SCALE ? scale + k + 2 * BK : nullptr, BK);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_part<BK / 8, BK / 4>(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc);
     __syncthreads();
     cur ^= 1;
   }

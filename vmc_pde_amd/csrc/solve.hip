@@ -126,13 +126,17 @@ __device__ __forceinline__ int factor_inverse_32(double* a, int j0, double* scr,
 #pragma unroll 1
     for (int k = 0; k < 16; ++k) {
       const double* lrow = a + (b0 + k) * DP + b0;
+      double lv[16], xv[16];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {      // unconditional loads (all in bounds), masked afterwards
+        lv[m] = lrow[m];
+        xv[m] = xrow[m];
+      }
       double acc0 = (k == ci) ? 1.0 : 0.0, acc1 = 0.0;
 #pragma unroll
       for (int m = 0; m < 16; m += 2) {
-        const double x0 = (m >= ci && m < k) ? xrow[m] : 0.0;
-        const double x1 = (m + 1 >= ci && m + 1 < k) ? xrow[m + 1] : 0.0;
-        acc0 = fma(-lrow[m], x0, acc0);
-        acc1 = fma(-lrow[m + 1], x1, acc1);
+        acc0 = fma(-lv[m], (m >= ci && m < k) ? xv[m] : 0.0, acc0);
+        acc1 = fma(-lv[m + 1], (m + 1 >= ci && m + 1 < k) ? xv[m + 1] : 0.0, acc1);
       }
       if (k >= ci) xrow[k] = (acc0 + acc1) * col[SB + (b0 - j0) + k];
     }

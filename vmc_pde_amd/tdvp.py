@@ -40,8 +40,9 @@ class TDVP:
     diagonalShift: float = 0
     diagonalizeOnDevice: bool = False
     solver: str = "auto"          # "eigh" (reference pseudo-inverse), "cholesky", or "auto" (cholesky iff diagonalShift > 1e-10)
-    centering: str = "auto"       # "exact": global means before the Gram (one extra tiny all-reduce when world_size > 1)
-                                  # "lagged": previous call's global mean as shift -> a single all-reduce per step
+    centering: str = "auto"       # "exact": global means before the Gram (an extra pass over J, + one tiny all-reduce when sharded)
+                                  # "lagged": previous call's global mean as shift -> one pass, a single all-reduce per step
+                                  # "auto": exact on the first call, lagged afterwards (algebraically identical, see finalize)
 
     def __post_init__(self):
         self._buf = {}
@@ -108,7 +109,7 @@ class TDVP:
             b["count"].fill_(float(n))
             mode = self.centering
             if mode == "auto":
-                mode = "exact" if (world == 1 or self._c_prev is None or self._c_prev.numel() != P) else "lagged"
+                mode = "exact" if (self._c_prev is None or self._c_prev.numel() != P) else "lagged"
             if mode == "exact":
                 # pass 1: raw sums -> global means (tdvp.py:37,41); tiny all-reduce when sharded
                 b["c"].zero_()
