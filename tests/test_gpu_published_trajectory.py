@@ -58,16 +58,20 @@ def test_gaussian_diffusion_d8_matches_published_trajectory():
 
 
 def test_student_t_diffusion_d8_follows_published_nu():
-    # Student-t latent starting at nu = 2 relaxes towards a Gaussian: published nu 2.00 -> 25.10, entropy tracks the analytic curve
+    # Student-t latent starting at nu = 2 (infinite variance) relaxing towards a Gaussian.  The evolution of the shape
+    # parameter nu = exp(dist_params)+1 is nearly deterministic, so it pins the Student-t log-density, its dist_params /
+    # L / mu gradients (net.py:23-36) and the chi^2 sampler end to end against the reference's published output.
+    # Only the first 40 steps (t <= 0.19) are compared: at nu ~ 2.5 a single heavy-tail outlier can derail any one run
+    # (the reference guards this with its NaN exit, tdvp.py:136-141), and the published run changed its step size
+    # adaptively between t = 1.6e-3 and 3e-2, which is replayed from the recorded times.  The entropy is not compared:
+    # main.py:55-57 notes that the published diffusion runs used another covariance parametrisation (I + A A^T).
     ref = np.load(os.path.join(GOLD, "published_diffusion_d8_student_t.npz"))
-    n = 400                                                                             # t ~ 3.8: enough to see the trend
-    # the published run changed its step size adaptively between t = 1.6e-3 and 3e-2: replay its recorded dt sequence
-    # host LAPACK eigh as the reference (tdvp.py:61-64): rocSOLVER's eigh does not always converge on the heavy-tailed S
-    vs, run = _run("Student_t", n, dts=np.diff(ref["times"]), on_device=False)
+    n = 40
+    vs, run = _run("Student_t", n, dts=np.diff(ref["times"]), on_device=False)     # host LAPACK eigh as tdvp.py:61-64
     assert vs.numParameters == 393
     assert np.allclose(run["times"], ref["times"][:n], rtol=0, atol=1e-9)
-    nu_ref = np.exp(ref["dist_params"][:n]) + 1
-    assert abs(run["nu"][0] - 2.0) < 1e-3 and run["nu"][-1] > 5.0                       # grows by an order of magnitude like the reference
-    assert 0.4 < run["nu"][-1] / nu_ref[-1] < 2.5, (run["nu"][-1], nu_ref[-1])
-    late = run["times"] > 1.0
-    assert np.abs(run["entropy"][late] - ref["entropy"][:n][late]).max() < 0.5
+    nu_ref = np.exp(ref["dist_params"][:n]) + 1                                      # recorded after each step (main.py:162,190), as in _run
+    assert np.abs(run["nu"] / nu_ref - 1).max() < 0.015, np.abs(run["nu"] / nu_ref - 1).max()
+    assert run["nu"][-1] > 2.5                                                       # 2.00 -> 2.55 over these steps in the published run
+    # the ansatz cannot follow this flow exactly: the published TDVP error is 0.22 -> 0.11 over these steps
+    assert np.all(run["tdvp_error"] < 2 * ref["tdvp_error"][:n] + 0.02) and np.all(run["tdvp_error"] > 0.4 * ref["tdvp_error"][:n])
