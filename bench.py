@@ -205,7 +205,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload]["desc"],
-                       "n_param": P, "n_samp_per_gpu": args.samples, "n_samp_total": n_total, "solver": "cholesky",
+                       "n_param": P, "n_samp_per_gpu": args.samples, "n_samp_total": n_total, "solver": "cholesky", "gram_operands": ("uncentred+DMA" if tdvp._uncentred_ok else "centred in staging"),
+                       "mean2_over_var_max": (float(tdvp._ratio_host[0]) if tdvp._ratio_host is not None else None),
                        "diagonal_shift": DIAG_SHIFT, "solver_residual": resid, "parallelism": f"dp{world} (samples sharded, one all-reduce of (S,F) per step)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": traffic,

@@ -137,13 +137,16 @@ int64_t vmcpde_gram_workspace_bytes(int32_t P, int64_t n_samples);
  * w = logp^2 gives SExp (tdvp.py:33,47); w = Etilde^2 gives the SNR Gram (tdvp.py:68-70). */
 int vmcpde_gram(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, const double* c, const double* w,
                 double* packed, void* workspace, int64_t workspace_bytes, void* stream);
-/* tdvp.py:45-46,50-51: S[i][j] = packed/Ntot - delta_i delta_j (full symmetric, both triangles written),
+/* tdvp.py:45-46,50-51: S[i][j] = packed/Ntot - d_i d_j (full symmetric, both triangles written) with
+ * d = rowsum/Ntot + c - c_gram = (global mean) - (the shift vmcpde_gram was given; c_gram NULL = 0, i.e. uncentred Gram),
  * A_shifted = S + diag(diagonal_shift * diag S) (optional second copy for the in-place Cholesky, may be NULL),
- * F = rowdot/Ntot - delta*deltaE, mean = c + delta, with delta = rowsum/Ntot, deltaE = sums[0]/Ntot - cE.
- * S: [dev] P*lds, A_shifted: [dev] P*lda.  All inputs may already be all-reduced over ranks (Ntot = global count). */
+ * F = rowdot/Ntot - delta*deltaE, mean = c + delta, with delta = rowsum/Ntot, deltaE = sums[0]/Ntot - cE  (c = the shift
+ * vmcpde_row_moments was given, NULL = 0).  S: [dev] P*lds, A_shifted: [dev] P*lda.  All inputs may already be all-reduced
+ * over ranks (Ntot = global count). */
 int vmcpde_gram_finalize(const double* packed, const double* rowsum, const double* rowdot, const double* sums,
-                         const double* c, const double* cE_dev, int32_t P, double n_total, double diagonal_shift,
-                         double* S, int64_t lds, double* A_shifted, int64_t lda, double* F, double* mean, void* stream);
+                         const double* c, const double* c_gram, const double* cE_dev, int32_t P, double n_total,
+                         double diagonal_shift, double* S, int64_t lds, double* A_shifted, int64_t lda, double* F, double* mean,
+                         void* stream);
 
 /* diagnostic (no reference counterpart): `blocks` workgroups x 4 waves x `iters` x 8 back-to-back v_mfma_f64_16x16x4_f64
  * (2048 flop each) with operands in registers; out: [dev] blocks*256.  Times the fp64 matrix-pipe peak for the roofline. */

@@ -117,7 +117,7 @@ def test_row_moments_eloc_stats_and_finalize():
     A = torch.zeros((Pp, Pp), dtype=torch.float64, device=DEV)
     F = torch.empty(P, dtype=torch.float64, device=DEV)
     mean = torch.empty(P, dtype=torch.float64, device=DEV)
-    nat.call("vmcpde_gram_finalize", nat.ptr(packed), nat.ptr(rowsum), nat.ptr(rowdot), nat.ptr(sums), nat.ptr(c), nat.ptr(cE), P, float(N),
+    nat.call("vmcpde_gram_finalize", nat.ptr(packed), nat.ptr(rowsum), nat.ptr(rowdot), nat.ptr(sums), nat.ptr(c), nat.ptr(c), nat.ptr(cE), P, float(N),
              1e-3, nat.ptr(S), Pp, nat.ptr(A), Pp, nat.ptr(F), nat.ptr(mean), nat.stream())
     Oc = J - J.mean(0)
     S_ref = Oc.T @ Oc / N
@@ -130,3 +130,10 @@ def test_row_moments_eloc_stats_and_finalize():
     Ag = A.cpu().numpy()[:P, :P]
     assert np.allclose(Ag, Sg + 1e-3 * np.diag(np.diag(Sg)), rtol=1e-15, atol=0)   # tdvp.py:50-51
     assert float(S[P:].abs().max()) == 0.0 and float(S[:, P:].abs().max()) == 0.0   # padding stays zero (H7)
+    # uncentred Gram + mean outer product removed in finalize (c_gram = NULL): same S up to the cancellation eps*(1+m^2/var)
+    packed0 = _gram(JT, ldj, P, N)
+    S2 = torch.zeros((Pp, Pp), dtype=torch.float64, device=DEV)
+    nat.call("vmcpde_gram_finalize", nat.ptr(packed0), nat.ptr(rowsum), nat.ptr(rowdot), nat.ptr(sums), nat.ptr(c), None, nat.ptr(cE), P, float(N),
+             0.0, nat.ptr(S2), Pp, None, 0, None, None, nat.stream())
+    S2g = S2.cpu().numpy()[:P, :P]
+    assert np.linalg.norm(S2g - S_ref) / np.linalg.norm(S_ref) < 1e-11

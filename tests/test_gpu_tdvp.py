@@ -222,3 +222,20 @@ def test_reference_driver_loop_mwe(tmp_path):
     assert rec["ev"].shape == (n, 37) and rec["snr"].shape == (n, 37) and rec["covar"].shape == (n, 2, 2)
     out2 = subprocess.run(cmd + ["--resume", "--t-end", "6e-6"], capture_output=True, text=True, timeout=300)
     assert out2.returncode == 0 and "resumed at t" in out2.stdout
+
+
+def test_uncentred_gram_fast_path_matches_centred():
+    import vmc_pde_amd as V
+    spec, th, nrm, chi2, eo, ep = _problem(2, 3, (4, 4), "Gauss", "no_add", "advection_hamiltonian_wDiss", 3000, lam=0.1)
+    z = O.latent_from_normals(spec, th, nrm, chi2).cuda()
+    out = {}
+    for mode in ("centred", "uncentred", "auto"):
+        vs = make_varstate(spec, th, sampler=FixedSampler(z))
+        t = V.TDVP(solver="eigh", gramShift=mode)
+        for _ in range(3):      # "auto" switches to the uncentred kernel once the asynchronous mean^2/var check has landed
+            t(th.cuda(), 0.0, vs, ep, nSamplesTDVP=3000, nSamplesObs=3000, timings=None, observables=False)
+            torch.cuda.synchronize()
+        out[mode] = (t.S0.clone(), t.F0.clone(), t._uncentred_ok)
+    assert rel_err(out["uncentred"][0], out["centred"][0]) < 1e-11
+    assert rel_err(out["auto"][0], out["centred"][0]) < 1e-11 and out["auto"][2]
+    assert rel_err(out["uncentred"][1], out["centred"][1]) < 1e-13

@@ -46,6 +46,21 @@ struct Regions {
   int total;
 };
 
+// values-only passes (flow_sample): state, two single-component MLP buffers, the s stash and the latent line
+Regions make_regions_values(const FlowProgram& fp) {
+  Regions r = {};
+  const int d = fp.dim, W = fp.max_width;
+  r.cs = W;
+  int u = 0;
+  r.X = u; u += d;
+  r.A = u; u += W;
+  r.B = u; u += W;
+  r.SOUT = u; u += d;
+  r.LAT = u; u += d;
+  r.total = u;
+  return r;
+}
+
 Regions make_regions(const FlowProgram& fp) {
   Regions r;
   const int d = fp.dim, W = fp.max_width;
@@ -703,7 +718,7 @@ extern "C" int vmcpde_flow_sample(vmcpde_model* m, const double* theta, const do
   VMC_REQUIRE(m && theta && z && x, "vmcpde_flow_sample: null argument");
   hipStream_t st = (hipStream_t)stream;
   if (int rc = vmcpde_prepare_latent_internal(m, theta, st)) return rc;
-  Regions r = make_regions(m->host);
+  Regions r = make_regions_values(m->host);
   int bytes = 0;
   const int lanes = pick_lanes(r.total, &bytes);
   VMC_REQUIRE(bytes <= 160 * 1024, "network too wide for the LDS-resident flow kernel");

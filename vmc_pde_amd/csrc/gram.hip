@@ -62,7 +62,7 @@ GramPlan make_plan(int P, int64_t N) {
   return g;
 }
 
-template <bool SCALE>
+template <bool CENTER, bool SCALE>
 __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__ JT, int64_t ldj, int P, int64_t N,
                                                       const double* __restrict__ c, const double* __restrict__ scale,
                                                       int ntiles, int nsplit, int64_t chunk, int total_units,
@@ -97,7 +97,10 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  tile_mainloop<SCALE>(acc, JT, ldj, rowA0, JT, ldj, rowB0, ti == tj, k0, k1, c, rowsA, c, rowsB, scale, lds);
+  if (!CENTER && !SCALE)
+    tile_mainloop_dma(acc, JT, ldj, rowA0, JT, ldj, rowB0, ti == tj, k0, k1, lds);
+  else
+    tile_mainloop<CENTER, SCALE>(acc, JT, ldj, rowA0, JT, ldj, rowB0, ti == tj, k0, k1, c, rowsA, c, rowsB, scale, lds);
   tile_store(acc, out + ((int64_t)split * ntiles + tile) * (TILE * TILE));
 }
 
@@ -172,7 +175,8 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const double* __restri
 // S[i][j] = packed/Ntot - delta_i delta_j ; optional second copy A = S + diag(shift * diag S) for the in-place Cholesky.
 // grid: (4, 4, ntiles) 32x32 sub-tiles; the mirrored block goes through an LDS transpose so both writes are coalesced.
 __global__ __launch_bounds__(256) void finalize_S_kernel(const double* __restrict__ packed, const double* __restrict__ rowsum,
-                                                        int P, double inv_n, double shift, double* __restrict__ S,
+                                                        const double* __restrict__ c, const double* __restrict__ cg, int P,
+                                                        double inv_n, double shift, double* __restrict__ S,
                                                         int64_t lds_, double* __restrict__ A2, int64_t lda2) {
   __shared__ double tr[32][33];
   int ti, tj;
@@ -186,7 +190,10 @@ __global__ __launch_bounds__(256) void finalize_S_kernel(const double* __restric
     const int gi = ti * TILE + r, gj = tj * TILE + cidx;
     double v = 0.0;
     if (gi < P && gj < P) {
-      v = tile[r * TILE + cidx] * inv_n - (rowsum[gi] * inv_n) * (rowsum[gj] * inv_n);
+      // delta = (global mean) - (shift the Gram kernel used) = rowsum/N + c - c_gram
+      const double di = rowsum[gi] * inv_n + (c ? c[gi] : 0.0) - (cg ? cg[gi] : 0.0);
+      const double dj = rowsum[gj] * inv_n + (c ? c[gj] : 0.0) - (cg ? cg[gj] : 0.0);
+      v = tile[r * TILE + cidx] * inv_n - di * dj;
       S[(int64_t)gi * lds_ + gj] = v;
       if (A2) A2[(int64_t)gi * lda2 + gj] = (gi == gj) ? v + shift * v : v;
     }
@@ -247,6 +254,12 @@ extern "C" int vmcpde_bench_mfma_f64(int32_t iters, int32_t blocks, double* out,
   return 0;
 }
 
+#ifdef VMC_GRAM_STAMPS
+extern "C" int vmcpde_debug_read_stamps(unsigned long long* out_host, int n) {
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(vmcpde::g_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif
+
 extern "C" int64_t vmcpde_gram_packed_doubles(int32_t P) {
   if (P <= 0) return 0;
   const int nb = (P + TILE - 1) / TILE;
@@ -299,16 +312,20 @@ extern "C" int vmcpde_gram(const double* JT, int64_t ldj, int32_t P, int64_t n_s
   const size_t lds_bytes = TILE_LDS_BYTES + lds_pad;
   static bool attr_set = false;
   if (!attr_set) {
-    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_set = true;
   }
-  if (w)
-    hipLaunchKernelGGL(gram_kernel<true>, dim3(grid), dim3(256), lds_bytes, st, JT, ldj, P, n_samples, c, w, g.ntiles, g.nsplit,
-                       g.chunk, total, per_xcd, order, out);
-  else
-    hipLaunchKernelGGL(gram_kernel<false>, dim3(grid), dim3(256), lds_bytes, st, JT, ldj, P, n_samples, c, w, g.ntiles, g.nsplit,
-                       g.chunk, total, per_xcd, order, out);
+#define VMC_LAUNCH_GRAM(CEN, SCA)                                                                                              \
+  hipLaunchKernelGGL((gram_kernel<CEN, SCA>), dim3(grid), dim3(256), lds_bytes, st, JT, ldj, P, n_samples, c, w, g.ntiles, g.nsplit, \
+                     g.chunk, total, per_xcd, order, out)
+  if (c && w) VMC_LAUNCH_GRAM(true, true);
+  else if (c) VMC_LAUNCH_GRAM(true, false);
+  else if (w) VMC_LAUNCH_GRAM(false, true);
+  else VMC_LAUNCH_GRAM(false, false);
+#undef VMC_LAUNCH_GRAM
   VMC_CHECK_HIP(hipGetLastError());
   if (g.nsplit > 1) {
     const int64_t per_split = (int64_t)g.ntiles * TILE * TILE;
@@ -321,7 +338,7 @@ extern "C" int vmcpde_gram(const double* JT, int64_t ldj, int32_t P, int64_t n_s
 }
 
 extern "C" int vmcpde_gram_finalize(const double* packed, const double* rowsum, const double* rowdot, const double* sums,
-                                    const double* c, const double* cE_dev, int32_t P, double n_total, double diagonal_shift,
+                                    const double* c, const double* c_gram, const double* cE_dev, int32_t P, double n_total, double diagonal_shift,
                                     double* S, int64_t lds, double* A_shifted, int64_t lda, double* F, double* mean, void* stream) {
   VMC_REQUIRE(packed && rowsum && S, "vmcpde_gram_finalize: null argument");
   VMC_REQUIRE(P >= 1 && lds >= P && n_total > 0, "bad shape");
@@ -330,7 +347,7 @@ extern "C" int vmcpde_gram_finalize(const double* packed, const double* rowsum, 
   hipStream_t st = (hipStream_t)stream;
   const int nb = (P + TILE - 1) / TILE;
   const double inv_n = 1.0 / n_total;
-  hipLaunchKernelGGL(finalize_S_kernel, dim3(4, 4, (unsigned)tri_count(nb)), dim3(256), 0, st, packed, rowsum, P, inv_n,
+  hipLaunchKernelGGL(finalize_S_kernel, dim3(4, 4, (unsigned)tri_count(nb)), dim3(256), 0, st, packed, rowsum, c, c_gram, P, inv_n,
                      diagonal_shift, S, lds, A_shifted, lda);
   VMC_CHECK_HIP(hipGetLastError());
   if (F || mean) {

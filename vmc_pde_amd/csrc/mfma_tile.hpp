@@ -16,6 +16,19 @@
 
 namespace vmcpde {
 
+#ifdef VMC_GRAM_STAMPS
+// diagnostic build only (tools/probe_gram_stamps.py): per-workgroup cycle sums of the main-loop segments
+__device__ unsigned long long g_stamps[16384 * 8];
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define VMC_STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _t = stamp(); seg[i] += _t - tprev; tprev = _t; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define VMC_STAMP(i)
+#endif
+
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
@@ -57,29 +70,35 @@ __device__ __forceinline__ void stage_load(Staged& r, const double* __restrict__
     if (!TAIL) r.sc = *reinterpret_cast<const double2_t*>(scale_k + kp);
     else { r.sc.x = (kp < krem) ? scale_k[kp] : 0.0; r.sc.y = (kp + 1 < krem) ? scale_k[kp + 1] : 0.0; }
   }
+  // wave-uniform base (SGPR pair) + 32-bit per-lane BYTE offset: global_load ... v_off, s[base:base+1] -- no 64-bit
+  // VALU address arithmetic in the loop (fp64 MFMA and VALU share the SIMD's issue, so every VALU op here stretches
+  // the staging burst; the host wrappers guarantee 128 * pitch * 8 < 2^32)
+  const char* __restrict__ base = reinterpret_cast<const char*>(tile);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
+    const uint32_t boff = (off + q * slot_stride) * 8u;
     if (!TAIL) {
-      r.v[q] = *reinterpret_cast<const double2_t*>(tile + off + q * slot_stride);
+      r.v[q] = *reinterpret_cast<const double2_t*>(base + boff);
     } else {
-      const double* p = tile + off + q * slot_stride;
+      const double* p = reinterpret_cast<const double*>(base + boff);
       r.v[q].x = (kp < krem) ? p[0] : 0.0;
       r.v[q].y = (kp + 1 < krem) ? p[1] : 0.0;
     }
   }
 }
 
-template <bool SCALE, bool TAIL>
+template <bool CENTER, bool SCALE, bool TAIL>
 __device__ __forceinline__ void stage_store(const Staged& r, double* __restrict__ lds, int tile_off, const double (&sh)[4], int64_t krem) {
   const int t = threadIdx.x;
   const int kp = (t & 7) * 2;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int row = q * 32 + (t >> 3);
-    const double s = sh[q];
     double2_t v = r.v[q];
-    v.x -= s;
-    v.y -= s;
+    if (CENTER) {
+      v.x -= sh[q];
+      v.y -= sh[q];
+    }
     if (TAIL) {   // columns beyond the sample count must contribute 0, not -shift
       if (!(kp < krem)) v.x = 0.0;
       if (!(kp + 1 < krem)) v.y = 0.0;
@@ -120,7 +139,7 @@ __device__ __forceinline__ void mma_kstep(double4_t (&acc)[4][4], const double* 
 // Main loop of one tile.  alias: the B tile is the A tile (diagonal tile of a syrk) -> only A is staged.
 // shiftA/shiftB may be null (no centring); they are read for `nshift*` valid rows and zero-extended.
 // lds: TILE_LDS_DOUBLES doubles.
-template <bool SCALE>
+template <bool CENTER, bool SCALE>
 __device__ __forceinline__ void tile_mainloop(double4_t (&acc)[4][4], const double* __restrict__ A, int64_t lda, int rowA0,
                                               const double* __restrict__ B, int64_t ldb, int rowB0, bool alias, int64_t k0,
                                               int64_t k1, const double* __restrict__ shiftA, int nshiftA,
@@ -156,13 +175,13 @@ __device__ __forceinline__ void tile_mainloop(double4_t (&acc)[4][4], const doub
   if (nfull > 0) {
     stage_load<SCALE, false>(ra, tA + k0, offA, strideA, SCALE ? scale + k0 : nullptr, BK);
     if (!alias) stage_load<SCALE, false>(rb, tB + k0, offB, strideB, SCALE ? scale + k0 : nullptr, BK);
-    stage_store<SCALE, false>(ra, lds, 0, SHA, BK);
-    if (!alias) stage_store<SCALE, false>(rb, lds, TILE_LDS, SHB, BK);
+    stage_store<CENTER, SCALE, false>(ra, lds, 0, SHA, BK);
+    if (!alias) stage_store<CENTER, SCALE, false>(rb, lds, TILE_LDS, SHB, BK);
   } else {
     stage_load<SCALE, true>(ra, tA + k0, offA, strideA, SCALE ? scale + k0 : nullptr, tail);
     if (!alias) stage_load<SCALE, true>(rb, tB + k0, offB, strideB, SCALE ? scale + k0 : nullptr, tail);
-    stage_store<SCALE, true>(ra, lds, 0, SHA, tail);
-    if (!alias) stage_store<SCALE, true>(rb, lds, TILE_LDS, SHB, tail);
+    stage_store<CENTER, SCALE, true>(ra, lds, 0, SHA, tail);
+    if (!alias) stage_store<CENTER, SCALE, true>(rb, lds, TILE_LDS, SHB, tail);
   }
   __syncthreads();
   int cur = 0;
@@ -175,22 +194,43 @@ __device__ __forceinline__ void tile_mainloop(double4_t (&acc)[4][4], const doub
     stage_load<SCALE, false>(ra, tA + k + BK, offA, strideA, SCALE ? scale + k + BK : nullptr, BK);
     if (!alias) stage_load<SCALE, false>(rb, tB + k + BK, offB, strideB, SCALE ? scale + k + BK : nullptr, BK);
   }
+#ifdef VMC_GRAM_STAMPS
+  unsigned long long seg[4] = {0, 0, 0, 0}, segw = 0;
+  unsigned long long tprev = stamp();
+  const unsigned long long tstart = tprev;
+#endif
   for (int64_t s = 0; s + 1 < nfull; ++s, k += BK) {
     mma_part<0, BK / 8>(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc);
+    VMC_STAMP(0)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);   // let the short VALU/LDS staging burst win issue slots over the partner's MFMAs (+0.5 % measured)
-    stage_store<SCALE, false>(ra, lds, (cur ^ 1) * 2 * TILE_LDS, SHA, BK);
-    if (!alias) stage_store<SCALE, false>(rb, lds, (cur ^ 1) * 2 * TILE_LDS + TILE_LDS, SHB, BK);
+#ifdef VMC_GRAM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    { __builtin_amdgcn_sched_barrier(0); const unsigned long long _t = stamp(); segw += _t - tprev; tprev = _t; __builtin_amdgcn_sched_barrier(0); }
+#endif
+    stage_store<CENTER, SCALE, false>(ra, lds, (cur ^ 1) * 2 * TILE_LDS, SHA, BK);
+    if (!alias) stage_store<CENTER, SCALE, false>(rb, lds, (cur ^ 1) * 2 * TILE_LDS + TILE_LDS, SHB, BK);
     if (s + 2 < nfull) {
       stage_load<SCALE, false>(ra, tA + k + 2 * BK, offA, strideA, SCALE ? scale + k + 2 * BK : nullptr, BK);
       if (!alias) stage_load<SCALE, false>(rb, tB + k + 2 * BK, offB, strideB, SCALE ? scale + k + 2 * BK : nullptr, BK);
     }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+    VMC_STAMP(1)
     mma_part<BK / 8, BK / 4>(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc);
+    VMC_STAMP(2)
     __syncthreads();
+    VMC_STAMP(3)
     cur ^= 1;
   }
+#ifdef VMC_GRAM_STAMPS
+  if ((threadIdx.x & 63) == 0) {
+    const int w = threadIdx.x >> 6;
+    unsigned long long* o = g_stamps + ((size_t)(blockIdx.x % 4096) * 4 + w) * 8;
+    o[0] = seg[0]; o[1] = seg[1]; o[2] = seg[2]; o[3] = seg[3]; o[4] = (unsigned long long)(nfull > 0 ? nfull - 1 : 0); o[5] = tprev - tstart;
+    o[6] = segw; o[7] = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (31 << 11)) /* HW_ID */;
+  }
+#endif
   if (nfull > 0) {   // last full step; the ragged tail (if any) is staged behind it
     if (tail > 0) {
       stage_load<SCALE, true>(ra, tA + k + BK, offA, strideA, SCALE ? scale + k + BK : nullptr, tail);
@@ -198,14 +238,120 @@ __device__ __forceinline__ void tile_mainloop(double4_t (&acc)[4][4], const doub
     }
     mma_kstep(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc);
     if (tail > 0) {
-      stage_store<SCALE, true>(ra, lds, (cur ^ 1) * 2 * TILE_LDS, SHA, tail);
-      if (!alias) stage_store<SCALE, true>(rb, lds, (cur ^ 1) * 2 * TILE_LDS + TILE_LDS, SHB, tail);
+      stage_store<CENTER, SCALE, true>(ra, lds, (cur ^ 1) * 2 * TILE_LDS, SHA, tail);
+      if (!alias) stage_store<CENTER, SCALE, true>(rb, lds, (cur ^ 1) * 2 * TILE_LDS + TILE_LDS, SHB, tail);
     }
     __syncthreads();
     cur ^= 1;
   }
   if (tail > 0) {
     mma_kstep(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc);
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// DMA variant of the main loop (no centring, no weights): operands go global -> LDS directly (global_load_lds_dwordx4,
+// one 1-KiB piece = 8 rows x 128 B per wave-instruction), so a K-step's staging burst is 8 instructions per wave and no
+// VGPR, VALU or ds_write is spent on it -- on this chip every non-MFMA instruction of a wave waits ~one MFMA slot (64
+// cycles) behind the co-resident wave's fp64 MFMAs, so the burst length is what the matrix pipe idles on.
+// LDS image: unpadded rows of 16 doubles; the eight 16-B pairs of a row are XOR-swizzled with f(row) = (row>>1)&7, applied
+// on the per-lane SOURCE address (the DMA destination is lane-linear) and again on the fragment reads, which makes the 16
+// rows x 2 columns of a ds_read_b64 half-wave hit 32 distinct bank pairs.
+constexpr int DT = TILE * BK;                       // doubles per operand tile (16 KiB)
+constexpr size_t TILE_DMA_LDS_BYTES = 4 * DT * sizeof(double);
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+// issue the four pieces (32 rows) this wave owns of one 128 x 16 operand tile
+__device__ __forceinline__ void dma_tile(const double* __restrict__ tile_k /* row-block base + k */, const uint32_t (&boff)[4],
+                                         double* __restrict__ lds_tile, int wave) {
+  const char* __restrict__ base = reinterpret_cast<const char*>(tile_k);
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + boff[jj]), (lds_ptr_t)(lds_tile + (wave * 4 + jj) * 8 * BK), 16, 0, 0);
+}
+
+__device__ __forceinline__ void mma_kstep_swz(double4_t (&acc)[4][4], const double* __restrict__ lds, int offAs, int offBs, int wr, int wc,
+                                              const int (&koff)[BK / 4]) {
+  const int lr = threadIdx.x & 15;
+  const double* __restrict__ ap = lds + offAs + (64 * wr + lr) * BK;
+  const double* __restrict__ bp = lds + offBs + (64 * wc + lr) * BK;
+#pragma unroll
+  for (int k4 = 0; k4 < BK / 4; ++k4) {
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = ap[16 * i * BK + koff[k4]];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = bp[16 * j * BK + koff[k4]];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+// lds: 4 * DT doubles.  Same contract as tile_mainloop<false,false>.
+__device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const double* __restrict__ A, int64_t lda, int rowA0,
+                                                  const double* __restrict__ B, int64_t ldb, int rowB0, bool alias, int64_t k0,
+                                                  int64_t k1, double* __restrict__ lds) {
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), wr = wave >> 1, wc = wave & 1;
+  const double* __restrict__ tA = A + (int64_t)rowA0 * lda;
+  const double* __restrict__ tB = B + (int64_t)rowB0 * ldb;
+  // per-lane source byte offsets of this wave's four pieces: piece j covers rows 8j..8j+7, lane -> (row 8j + lane/8, slot lane%8)
+  uint32_t offA[4], offB[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int row = (wave * 4 + jj) * 8 + (lane >> 3);
+    const int pair = (lane & 7) ^ ((row >> 1) & 7);
+    offA[jj] = ((uint32_t)row * (uint32_t)lda + (uint32_t)pair * 2u) * 8u;
+    offB[jj] = ((uint32_t)row * (uint32_t)ldb + (uint32_t)pair * 2u) * 8u;
+  }
+  // fragment read offsets inside a row: element k = 4*k4 + lane/16 sits at pair (k/2) ^ f(row), f = (lane&15)/2 for every row block
+  int koff[BK / 4];
+  {
+    const int lk = lane >> 4, f = ((lane & 15) >> 1) & 7;
+#pragma unroll
+    for (int k4 = 0; k4 < BK / 4; ++k4) koff[k4] = (((2 * k4 + (lk >> 1)) ^ f) << 1) + (lk & 1);
+  }
+  const int boff = alias ? 0 : DT;
+  const int64_t nfull = (k1 - k0) / BK;
+  const int64_t tail = (k1 - k0) - nfull * BK;
+  int cur = 0;
+  int64_t k = k0;
+  if (nfull > 0) {
+    dma_tile(tA + k, offA, lds, wave);
+    if (!alias) dma_tile(tB + k, offB, lds + DT, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  for (int64_t s = 0; s < nfull; ++s, k += BK) {
+    if (s + 1 < nfull) {   // the other buffer was last read before the barrier that closed the previous iteration
+      dma_tile(tA + k + BK, offA, lds + (cur ^ 1) * 2 * DT, wave);
+      if (!alias) dma_tile(tB + k + BK, offB, lds + (cur ^ 1) * 2 * DT + DT, wave);
+    }
+    mma_kstep_swz(acc, lds, cur * 2 * DT, cur * 2 * DT + boff, wr, wc, koff);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (tail > 0) {   // ragged last step (N not a multiple of 16): masked register staging into the same swizzled image
+    Staged ra, rb;
+    const uint32_t oA = (uint32_t)(t >> 3) * (uint32_t)lda + (uint32_t)(t & 7) * 2u, sA = 32u * (uint32_t)lda;
+    const uint32_t oB = (uint32_t)(t >> 3) * (uint32_t)ldb + (uint32_t)(t & 7) * 2u, sB = 32u * (uint32_t)ldb;
+    stage_load<false, true>(ra, tA + k, oA, sA, nullptr, tail);
+    if (!alias) stage_load<false, true>(rb, tB + k, oB, sB, nullptr, tail);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = q * 32 + (t >> 3);
+      const int slot = (t & 7) ^ ((row >> 1) & 7);
+      *reinterpret_cast<double2_t*>(lds + cur * 2 * DT + row * BK + slot * 2) = ra.v[q];
+      if (!alias) *reinterpret_cast<double2_t*>(lds + cur * 2 * DT + DT + row * BK + slot * 2) = rb.v[q];
+    }
+    __syncthreads();
+    mma_kstep_swz(acc, lds, cur * 2 * DT, cur * 2 * DT + boff, wr, wc, koff);
     __syncthreads();
   }
 }

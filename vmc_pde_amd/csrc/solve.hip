@@ -294,21 +294,6 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, 
   }
 }
 
-// Panel solve: A[r0.., k0:k0+n] <- A[r0.., k0:k0+n] * L_kk^-T = B * Linv^T  (TN tile GEMM, K = n)
-__global__ __launch_bounds__(256, 2) void chol_trsm_kernel(double* __restrict__ A, int64_t lda, int P, int k0, int n,
-                                                           const double* __restrict__ Linv) {
-  extern __shared__ double lds[];
-  const int row0 = k0 + n + blockIdx.x * TILE;
-  const int rows = (P - row0 < TILE) ? (P - row0) : TILE;
-  double4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  tile_mainloop<false>(acc, A + k0, lda, row0, Linv, NB, 0, false, 0, n, nullptr, 0, nullptr, 0, nullptr, lds);
-  tile_store_global(acc, A + (int64_t)row0 * lda + k0, lda, rows, n, 0);
-}
-
 // Latency-optimised strip kernel for the two short dependent GEMMs of every panel (K = 128 exactly):
 //   mode 0 (panel solve):        A[row0.., k0:k0+128] <- A[row0.., k0:k0+128] * Linv^T          (B = Linv, 128 x 128)
 //   mode 1 (next-panel update):  A[row0.., c0:c0+128] -= A[row0.., k0:k0+128] * A[c0.., k0:k0+128]^T   (c0 = k0+128)
@@ -414,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double* __restrict__ 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  tile_mainloop<false>(acc, A + k0, lda, rowA0, A + k0, lda, rowB0, ti == tj, 0, n, nullptr, 0, nullptr, 0, nullptr, lds);
+  tile_mainloop_dma(acc, A + k0, lda, rowA0, A + k0, lda, rowB0, ti == tj, 0, n, lds);
   tile_store_global(acc, A + (int64_t)rowA0 * lda + rowB0, lda, rowsA, rowsB, 1);
 }
 

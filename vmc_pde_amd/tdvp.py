@@ -43,6 +43,11 @@ class TDVP:
     centering: str = "auto"       # "exact": global means before the Gram (an extra pass over J, + one tiny all-reduce when sharded)
                                   # "lagged": previous call's global mean as shift -> one pass, a single all-reduce per step
                                   # "auto": exact on the first call, lagged afterwards (algebraically identical, see finalize)
+    gramShift: str = "auto"       # "centred": the Gram kernel subtracts the shift while staging (as tdvp.py:42 centres first)
+                                  # "uncentred": raw sum J J^T, mean outer product removed in finalize (no VALU work in the
+                                  #   kernel's staging burst, which competes with the fp64 MFMAs for issue slots)
+                                  # "auto": uncentred once the previous call showed max_p mean_p^2/var_p < 1e3, i.e. the
+                                  #   cancellation costs < 3 of fp64's 16 digits; centred otherwise
 
     def __post_init__(self):
         self._buf = {}
@@ -50,6 +55,8 @@ class TDVP:
         self._lazy = None
         self._SExp = self._rhoVar = self._snr = self._S = None
         self.ev = self.V = self.VtF = None
+        self._ratio_host = self._ratio_event = None
+        self._uncentred_ok = False
 
     # ---- buffers ------------------------------------------------------------------------------------------------
     def _buffers(self, P, device):
@@ -130,14 +137,32 @@ class TDVP:
             # pass 2 (tdvp.py:40-45 in shifted form): sum (O - c), sum (O - c)(E - cE); then the syrk (tdvp.py:46)
             nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, P, n, nat.ptr(e), nat.ptr(b["c"]), nat.ptr(b["cE"]),
                      nat.ptr(b["rowsum"]), nat.ptr(b["rowdot"]), nat.stream())
-            self._gram(b, JT, ldj, P, n, b["c"], None, b["packed"])
+            shift_mode = self.gramShift
+            if shift_mode == "auto":
+                if self._ratio_event is not None:
+                    # the previous call's mean^2/var check; its copy precedes this call's flow kernels in the stream, so this
+                    # wait never idles the GPU, and it makes the choice identical on every rank (the packed sums must agree)
+                    self._ratio_event.synchronize()
+                    self._uncentred_ok = bool(self._ratio_host[0] < 1e3)
+                shift_mode = "uncentred" if self._uncentred_ok else "centred"
+            c_gram = b["c"] if shift_mode == "centred" else None
+            self._gram(b, JT, ldj, P, n, c_gram, None, b["packed"])
             mpi.allreduce_sum_(b["pack"])            # the one collective of the step (no-op on a single rank)
             use_chol = self._solver() == "cholesky"
             if use_chol and b["A"] is None:
                 b["A"] = torch.zeros((b["Ppad"], b["Ppad"]), dtype=global_defs.tReal, device=device)
             nat.call("vmcpde_gram_finalize", nat.ptr(b["packed"]), nat.ptr(b["rowsum"]), nat.ptr(b["rowdot"]), nat.ptr(b["sums"]),
-                     nat.ptr(b["c"]), nat.ptr(b["cE"]), P, Ntot, float(self.diagonalShift), nat.ptr(b["S"]), b["Ppad"],
+                     nat.ptr(b["c"]), nat.ptr(c_gram), nat.ptr(b["cE"]), P, Ntot, float(self.diagonalShift), nat.ptr(b["S"]), b["Ppad"],
                      nat.ptr(b["A"]) if use_chol else None, b["Ppad"], nat.ptr(b["F"]), nat.ptr(b["mean"]), nat.stream())
+            if self.gramShift == "auto":     # asynchronous safety check for the next call: no host sync here
+                diag = torch.diagonal(b["S"])[:P]
+                m2 = b["mean"] ** 2
+                ratio = torch.where(diag > 0, m2 / diag, torch.where(m2 > 0, torch.full_like(m2, float("inf")), torch.zeros_like(m2))).max()
+                if self._ratio_host is None:
+                    self._ratio_host = torch.empty(1, dtype=global_defs.tReal).pin_memory()
+                    self._ratio_event = torch.cuda.Event()
+                self._ratio_host.copy_(ratio.reshape(1), non_blocking=True)
+                self._ratio_event.record()
         sums = b["sums"]
         self.ElocMean = sums[0] / Ntot                                        # tdvp.py:37
         self.ElocMeanAbs = sums[2] / Ntot                                     # tdvp.py:38
@@ -162,7 +187,7 @@ class TDVP:
         with torch.cuda.device(w.device):
             self._gram(b, z["JT"], z["ldj"], P, z["n"], z["mean"], w.contiguous(), tmp)
             mpi.allreduce_sum_(tmp)
-            nat.call("vmcpde_gram_finalize", nat.ptr(tmp), nat.ptr(zero), None, None, None, None, P, z["Ntot"], 0.0, nat.ptr(out),
+            nat.call("vmcpde_gram_finalize", nat.ptr(tmp), nat.ptr(zero), None, None, None, None, None, P, z["Ntot"], 0.0, nat.ptr(out),
                      b["Ppad"], None, 0, None, None, nat.stream())
         return out[:P, :P]
 
