@@ -28,7 +28,7 @@ tot = a[..., 5] / np.maximum(it, 1)
 print("rc", rc, "workgroups with data", int(ok[:, 0].sum()), "iters", float(np.median(it[ok])))
 for w in range(4):
     m = ok[:, w]
-    print(f"wave {w}: cycles/iter median: mfma_half1 {np.median(seg[m, w, 0]):.0f}  stage {np.median(seg[m, w, 1]):.0f}  mfma_half2 {np.median(seg[m, w, 2]):.0f}  barrier {np.median(seg[m, w, 3]):.0f}  total {np.median(tot[m, w]):.0f}")
+    print(f"wave {w}: cycles/iter median: seg0 {np.median(seg[m, w, 0]):.0f}  seg1 {np.median(seg[m, w, 1]):.0f}  seg2 {np.median(seg[m, w, 2]):.0f}  seg3 {np.median(seg[m, w, 3]):.0f}  total {np.median(tot[m, w]):.0f}")
 t = tot[ok]
 print("centre", centre, "vmcnt wait at stage start, cycles/iter median:", float(np.median((a[..., 6] / np.maximum(it, 1))[ok])))
 print("total/iter percentiles 5/25/50/75/95:", np.percentile(t, [5, 25, 50, 75, 95]).round(0))

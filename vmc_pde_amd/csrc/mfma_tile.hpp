@@ -327,16 +327,37 @@ __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+#ifdef VMC_GRAM_STAMPS
+  unsigned long long seg[4] = {0, 0, 0, 0};
+  unsigned long long tprev = stamp();
+  const unsigned long long tstart = tprev;
+#endif
   for (int64_t s = 0; s < nfull; ++s, k += BK) {
     if (s + 1 < nfull) {   // the other buffer was last read before the barrier that closed the previous iteration
+      // raised priority: with the co-resident wave streaming fp64 MFMAs each of these eight instructions otherwise waits
+      // ~250 cycles for an issue slot (measured with in-kernel stamps; +1 % end to end).  Slotting the pieces between this
+      // wave's own MFMA groups instead was 6 % SLOWER.
+      __builtin_amdgcn_s_setprio(2);
       dma_tile(tA + k + BK, offA, lds + (cur ^ 1) * 2 * DT, wave);
       if (!alias) dma_tile(tB + k + BK, offB, lds + (cur ^ 1) * 2 * DT + DT, wave);
+      __builtin_amdgcn_s_setprio(0);
     }
+    VMC_STAMP(0)
     mma_kstep_swz(acc, lds, cur * 2 * DT, cur * 2 * DT + boff, wr, wc, koff);
+    VMC_STAMP(1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VMC_STAMP(2)
     __syncthreads();
+    VMC_STAMP(3)
     cur ^= 1;
   }
+#ifdef VMC_GRAM_STAMPS
+  if ((threadIdx.x & 63) == 0) {
+    const int w = threadIdx.x >> 6;
+    unsigned long long* o = g_stamps + ((size_t)(blockIdx.x % 4096) * 4 + w) * 8;
+    o[0] = seg[0]; o[1] = seg[1]; o[2] = seg[2]; o[3] = seg[3]; o[4] = (unsigned long long)nfull; o[5] = tprev - tstart; o[6] = 0; o[7] = 0;
+  }
+#endif
   if (tail > 0) {   // ragged last step (N not a multiple of 16): masked register staging into the same swizzled image
     Staged ra, rb;
     const uint32_t oA = (uint32_t)(t >> 3) * (uint32_t)lda + (uint32_t)(t & 7) * 2u, sA = 32u * (uint32_t)lda;
