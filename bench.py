@@ -143,11 +143,17 @@ def main():
     if args.gpus > 1 and world == 1:
         sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                  "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)          # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    backend = os.environ.get("VMCPDE_DIST_BACKEND", "nccl")     # "gloo": CPU-backend rehearsal of the multi-rank path
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import vmc_pde_amd as V
     from vmc_pde_amd import mpi_wrapper as mpi
@@ -176,7 +182,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert torch.isfinite(update).all(), "non-finite TDVP update"
