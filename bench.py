@@ -50,12 +50,13 @@ PEAK_F64_MFMA_TFLOPS = 78.6     # AMD MI355X spec, fp64 matrix (dense); the guid
 OUT_SCALE = 0.1                 # output kernels U(-0.1, 0.1) (the reference's 1e-5 makes J nearly degenerate)
 
 
-def build_problem(device, workload="C2", seed=1):
+def build_problem(device, workload="C2", seed=1, jacobian_dtype=torch.float64):
     import vmc_pde_amd as V
     w = WORKLOADS[workload]
     dim, off = w["dim"], np.asarray(w["offset"])
     sampler = V.Sampler(key=1234, dim=dim, name="Gauss", mcmc_info={"offset": off, "bound": 0.25})
-    vs = V.VarState(sampler, dim, seed, DEPTH, network_args=dict(intmediate=w["hidden"], offset=off, latentSpaceName="Gauss", dim=dim))
+    vs = V.VarState(sampler, dim, seed, DEPTH, network_args=dict(intmediate=w["hidden"], offset=off, latentSpaceName="Gauss", dim=dim),
+                    jacobian_dtype=jacobian_dtype)
     theta = vs.net.init(seed, out_scale=OUT_SCALE)
     vs.set_parameters(theta)
     eq = V.EvolutionEquation(dim=dim, name=EQ)
@@ -135,6 +136,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="BASELINE config (default C2, the headline)")
     ap.add_argument("--samples", type=int, default=0, help="samples per rank (default: the workload's)")
+    ap.add_argument("--jacobian", default="f64", choices=["f64", "f32"],
+                    help="storage type of the per-sample Jacobian (f32 = BASELINE config 5; S and F are accumulated in fp64 either way)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,7 +162,7 @@ def main():
     from vmc_pde_amd import mpi_wrapper as mpi
     if not args.samples:
         args.samples = WORKLOADS[args.workload]["n_samp"]
-    vs, eq, tdvp, theta = build_problem(device, args.workload)
+    vs, eq, tdvp, theta = build_problem(device, args.workload, jacobian_dtype=torch.float32 if args.jacobian == "f32" else torch.float64)
     P = vs.numParameters
     n_total = args.samples * world
     kwargs = dict(evolutionEq=eq, psi=vs, nSamplesTDVP=n_total, nSamplesObs=n_total, timings=None, observables=False)
@@ -209,9 +212,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64" if args.jacobian == "f64" else "f64 accumulate, f32 Jacobian storage (BASELINE config 5)", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload]["desc"],
-                       "n_param": P, "n_samp_per_gpu": args.samples, "n_samp_total": n_total, "solver": "cholesky", "gram_operands": ("uncentred+DMA" if tdvp._uncentred_ok else "centred in staging"),
+                       "n_param": P, "n_samp_per_gpu": args.samples, "n_samp_total": n_total, "solver": "cholesky", "gram_operands": (("uncentred+DMA" if args.jacobian == "f64" else "uncentred, fp32 widened in staging") if tdvp._uncentred_ok else "centred in staging"),
                        "mean2_over_var_max": (float(tdvp._ratio_host[0]) if tdvp._ratio_host is not None else None),
                        "diagonal_shift": DIAG_SHIFT, "solver_residual": resid, "parallelism": f"dp{world} (samples sharded, one all-reduce of (S,F) per step)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",

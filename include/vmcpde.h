@@ -109,10 +109,12 @@ int vmcpde_flow_sample(vmcpde_model* m, const double* theta, const double* z, in
                        double* x, double* logp, void* stream);
 /* var_state.py:29,31,32,34 (J1,J3,J4,J6): per sample logp, grad_x logp, directional second derivatives
  * hv[n][k] = v_k^T (Hessian_x logp) v_k for n_dirs caller-given directions dirs[k][d], and the parameter Jacobian.
- * Any of logp,g,hv,JT may be NULL (skipped).  JT: [dev] P * ldj, parameter-major.  dirs: [dev] n_dirs*d. */
+ * Any of logp,g,hv,JT may be NULL (skipped).  JT: [dev] P * ldj, parameter-major, fp64 or (jt_f32 != 0) fp32 -- BASELINE
+ * config 5 "fp32 Jacobian with fp64 S/F accumulate": only the stored Jacobian is rounded, S and F are accumulated in fp64.
+ * dirs: [dev] n_dirs*d. */
 int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const double* x, int64_t n_samples,
                      const double* dirs, int32_t n_dirs, double* logp, double* g, double* hv,
-                     double* JT, int64_t ldj, void* stream);
+                     void* JT, int64_t ldj, int32_t jt_f32, void* stream);
 
 /* ---- evolutionEq.py ------------------------------------------------------------------------------------ */
 /* evolutionEq.py:84-119 epilogue: Eloc_n from x, g and the directional second derivatives (J14 + eager einsums).
@@ -126,7 +128,7 @@ int vmcpde_rhs(const vmcpde_eq_consts* c, int32_t dim, const double* x, const do
 int vmcpde_eloc_stats(const double* eloc, int64_t n_samples, double* sums, void* stream);
 /* per parameter row p: rowsum[p] = sum_n (JT[p][n]-c[p]),  rowdot[p] = sum_n (JT[p][n]-c[p])*(E_n-cE)
  * (tdvp.py:41,44-45 in shifted one-pass form; c may be NULL = 0).  cE is read from cE_dev[0] if non-NULL. */
-int vmcpde_row_moments(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, const double* eloc,
+int vmcpde_row_moments(const void* JT, int64_t ldj, int32_t jt_f32, int32_t P, int64_t n_samples, const double* eloc,
                        const double* c, const double* cE_dev, double* rowsum, double* rowdot, void* stream);
 /* number of 128x128 lower-triangle tiles / doubles of the packed Gram buffer for P parameters */
 int64_t vmcpde_gram_packed_doubles(int32_t P);
@@ -134,8 +136,9 @@ int64_t vmcpde_gram_packed_doubles(int32_t P);
 int64_t vmcpde_gram_workspace_bytes(int32_t P, int64_t n_samples);
 /* the Gram ("syrk") contraction, tdvp.py:46-47 / mpi_wrapper.py:21-25 (J13) on fp64 MFMA:
  * packed[tile(i,j)][r][s] = sum_n w_n (JT[i*128+r][n]-c[..]) (JT[j*128+s][n]-c[..]),  j<=i,  w=NULL -> 1.
- * w = logp^2 gives SExp (tdvp.py:33,47); w = Etilde^2 gives the SNR Gram (tdvp.py:68-70). */
-int vmcpde_gram(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, const double* c, const double* w,
+ * w = logp gives SExp (tdvp.py:33,47: rows scaled by w, i.e. weight w^2); w = Etilde gives the SNR Gram (tdvp.py:68-70).
+ * jt_f32 != 0: JT holds fp32 values (ldj in elements), widened to fp64 while staging; accumulation stays fp64. */
+int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t P, int64_t n_samples, const double* c, const double* w,
                 double* packed, void* workspace, int64_t workspace_bytes, void* stream);
 /* tdvp.py:45-46,50-51: S[i][j] = packed/Ntot - d_i d_j (full symmetric, both triangles written) with
  * d = rowsum/Ntot + c - c_gram = (global mean) - (the shift vmcpde_gram was given; c_gram NULL = 0, i.e. uncentred Gram),

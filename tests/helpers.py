@@ -35,7 +35,7 @@ def random_theta(spec, seed, out_scale=0.05, latent_scale=0.3):
     return th
 
 
-def make_varstate(spec, theta, sampler=None):
+def make_varstate(spec, theta, sampler=None, jacobian_dtype=None):
     import vmc_pde_amd as V
     coupling = dict(jac_eq_1=spec.jac_eq_1, different_add=spec.different_add, no_add=spec.no_add)
     if sampler is None:
@@ -43,7 +43,8 @@ def make_varstate(spec, theta, sampler=None):
     vs = V.VarState(sampler, spec.dim, 1, spec.depth,
                     network_args=dict(intmediate=spec.intmediate, offset=np.asarray(spec.offset), latentSpaceName=spec.latentSpaceName,
                                       dim=spec.dim, **coupling),
-                    inds_up=spec.inds_up, inds_down=spec.inds_down)
+                    inds_up=spec.inds_up, inds_down=spec.inds_down,
+                    **({} if jacobian_dtype is None else {"jacobian_dtype": jacobian_dtype}))
     vs.set_parameters(theta)
     return vs
 

@@ -87,7 +87,7 @@ def test_empty_and_single_sample():
     from vmc_pde_amd import _native as nat
     x0 = torch.empty((0, 3), dtype=torch.float64, device=vs.device)
     th_d = vs.get_parameters()
-    nat.call("vmcpde_flow_eval", vs.net.handle, nat.ptr(th_d), nat.ptr(x0), 0, None, 0, None, None, None, None, 0, nat.stream())   # empty batch: no-op
+    nat.call("vmcpde_flow_eval", vs.net.handle, nat.ptr(th_d), nat.ptr(x0), 0, None, 0, None, None, None, None, 0, 0, nat.stream())   # empty batch: no-op
 
 
 @pytest.mark.parametrize("latent", ["Gauss", "Student_t"])

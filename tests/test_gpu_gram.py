@@ -22,12 +22,12 @@ def _jt(P, N, seed, scale=1.0, mean=0.0):
     return J, JT, ldj
 
 
-def _gram(JT, ldj, P, N, c=None, w=None):
+def _gram(JT, ldj, P, N, c=None, w=None, f32=0):
     npk = nat.lib().vmcpde_gram_packed_doubles(P)
     packed = torch.full((npk,), float("nan"), dtype=torch.float64, device=DEV)
     need = nat.lib().vmcpde_gram_workspace_bytes(P, N)
     ws = torch.empty(max(need // 8, 1), dtype=torch.float64, device=DEV)
-    nat.call("vmcpde_gram", nat.ptr(JT), ldj, P, N, nat.ptr(c), nat.ptr(w), nat.ptr(packed), nat.ptr(ws), ws.numel() * 8, nat.stream())
+    nat.call("vmcpde_gram", nat.ptr(JT), ldj, f32, P, N, nat.ptr(c), nat.ptr(w), nat.ptr(packed), nat.ptr(ws), ws.numel() * 8, nat.stream())
     return packed
 
 
@@ -69,6 +69,32 @@ def test_gram_parity_with_centring(P, N):
     assert np.linalg.norm(S0 - J.T @ J) / np.linalg.norm(J.T @ J) < 1e-13
 
 
+@pytest.mark.parametrize("P,N", [(129, 17), (411, 1000), (640, 4099)])
+def test_gram_fp32_operand_equals_fp64_path_on_fp32_values(P, N):
+    # config 5: the fp32 buffer is widened while staging, so on fp32-representable data all three variants
+    # (plain, centred, weighted) must be bit-identical to the fp64-operand kernel; row moments likewise
+    J, _, ldj = _jt(P, N, seed=P * 3 + N, mean=2.0)
+    J32 = J.astype(np.float32)
+    Ppad = _pad(P, 128)
+    JT32 = torch.zeros((Ppad, ldj), dtype=torch.float32, device=DEV)
+    JT32[:P, :N] = torch.as_tensor(J32.T)
+    JT64 = JT32.double()
+    c = torch.as_tensor(J32.astype(np.float64).mean(0)).to(DEV)
+    w = torch.as_tensor(np.random.default_rng(1).normal(size=N)).to(DEV)
+    for kw in (dict(), dict(c=c), dict(c=c, w=w)):
+        a = _gram(JT32, ldj, P, N, f32=1, **kw)
+        b = _gram(JT64, ldj, P, N, **kw)
+        assert torch.equal(a, b), kw
+    e = torch.as_tensor(np.random.default_rng(2).normal(size=N)).to(DEV)
+    outs = []
+    for buf, f32 in ((JT32, 1), (JT64, 0)):
+        cc, cE = torch.empty(P, dtype=torch.float64, device=DEV), torch.empty(P, dtype=torch.float64, device=DEV)
+        rs, rd = torch.empty(P, dtype=torch.float64, device=DEV), torch.empty(P, dtype=torch.float64, device=DEV)
+        nat.call("vmcpde_row_moments", nat.ptr(buf), ldj, f32, P, N, nat.ptr(e), nat.ptr(c), nat.ptr(cE), nat.ptr(rs), nat.ptr(rd), nat.stream())
+        outs.append((rs.clone(), rd.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_gram_weighted_is_SExp_form():
     # tdvp.py:33,47: (logp*O)^T (logp*O)
     P, N = 200, 777
@@ -107,7 +133,7 @@ def test_row_moments_eloc_stats_and_finalize():
     cE = torch.tensor([0.2], dtype=torch.float64, device=DEV)
     rowsum = torch.empty(P, dtype=torch.float64, device=DEV)
     rowdot = torch.empty(P, dtype=torch.float64, device=DEV)
-    nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, P, N, nat.ptr(e), nat.ptr(c), nat.ptr(cE), nat.ptr(rowsum), nat.ptr(rowdot), nat.stream())
+    nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, 0, P, N, nat.ptr(e), nat.ptr(c), nat.ptr(cE), nat.ptr(rowsum), nat.ptr(rowdot), nat.stream())
     Jc = J - c.cpu().numpy()
     assert np.allclose(rowsum.cpu().numpy(), Jc.sum(0), rtol=1e-12, atol=1e-10)
     assert np.allclose(rowdot.cpu().numpy(), (Jc * (E - 0.2)[:, None]).sum(0), rtol=1e-12, atol=1e-10)

@@ -30,7 +30,7 @@ def test_argument_validation_needs_no_gpu(lib_built):
     assert ws % ((33 * 34 // 2) * 128 * 128 * 8) == 0 and 8 <= ws // ((33 * 34 // 2) * 128 * 128 * 8) <= 12   # split-K factor
     assert L.vmcpde_chol_workspace_bytes(129) == 2 * 128 * 128 * 8
     assert L.vmcpde_num_parameters(None) == -1
-    rc = L.vmcpde_gram(None, 0, 0, 0, None, None, None, None, 0, None)
+    rc = L.vmcpde_gram(None, 0, 0, 0, 0, None, None, None, None, 0, None)
     assert rc == -1 and b"null" in L.vmcpde_last_error()
     with pytest.raises(nat.VmcpdeError):
         nat.call("vmcpde_cholesky", None, 0, 0, None, None, 0, None)

@@ -20,7 +20,7 @@ ts = []
 for it in range(reps + 1):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    nat.call("vmcpde_gram", nat.ptr(JT), ldj, P, N, nat.ptr(c) if centre else None, None, nat.ptr(packed), nat.ptr(ws), ws.numel() * 8, nat.stream())
+    nat.call("vmcpde_gram", nat.ptr(JT), ldj, 0, P, N, nat.ptr(c) if centre else None, None, nat.ptr(packed), nat.ptr(ws), ws.numel() * 8, nat.stream())
     e1.record()
     torch.cuda.synchronize()
     if it:

@@ -22,7 +22,7 @@ def run(buf, label):
     for it in range(13):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        nat.call("vmcpde_gram", nat.ptr(buf), ldj, P, N, None, None, nat.ptr(packed), nat.ptr(ws), ws.numel() * 8, nat.stream())
+        nat.call("vmcpde_gram", nat.ptr(buf), ldj, 0, P, N, None, None, nat.ptr(packed), nat.ptr(ws), ws.numel() * 8, nat.stream())
         e1.record(); torch.cuda.synchronize()
         if it: ts.append(e0.elapsed_time(e1))
     print(label, "median %.3f ms" % sorted(ts)[len(ts)//2], flush=True)

@@ -15,7 +15,7 @@ packed = torch.empty(nat.lib().vmcpde_gram_packed_doubles(P), dtype=torch.float6
 need = nat.lib().vmcpde_gram_workspace_bytes(P, N)
 ws = torch.empty(need // 8, dtype=torch.float64, device=dev)
 for it in range(3):
-    nat.call("vmcpde_gram", nat.ptr(JT), ldj, P, N, nat.ptr(c) if centre else None, None, nat.ptr(packed), nat.ptr(ws), ws.numel() * 8, nat.stream())
+    nat.call("vmcpde_gram", nat.ptr(JT), ldj, 0, P, N, nat.ptr(c) if centre else None, None, nat.ptr(packed), nat.ptr(ws), ws.numel() * 8, nat.stream())
 torch.cuda.synchronize()
 n = 4096 * 4 * 8
 buf = (C.c_ulonglong * n)()

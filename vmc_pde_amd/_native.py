@@ -61,13 +61,13 @@ _PROTOS = {
     "vmcpde_mcmc": (_int, [_u64, _u64, _i32, _i32, _f64, C.POINTER(_f64), _vp, _vp, _vp, _vp]),
     "vmcpde_mcmc_from_uniforms": (_int, [_vp, _vp, _vp, _i32, _i32, _f64, C.POINTER(_f64), _vp, _vp, _vp, _vp]),
     "vmcpde_flow_sample": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp]),
-    "vmcpde_flow_eval": (_int, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "vmcpde_flow_eval": (_int, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "vmcpde_rhs": (_int, [C.POINTER(EqConsts), _i32, _vp, _vp, _vp, _i32, _vp, _f64, _i64, _vp, _vp]),
     "vmcpde_eloc_stats": (_int, [_vp, _i64, _vp, _vp]),
-    "vmcpde_row_moments": (_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vmcpde_row_moments": (_int, [_vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vmcpde_gram_packed_doubles": (_i64, [_i32]),
     "vmcpde_gram_workspace_bytes": (_i64, [_i32, _i64]),
-    "vmcpde_gram": (_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "vmcpde_gram": (_int, [_vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "vmcpde_gram_finalize": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f64, _f64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "vmcpde_bench_mfma_f64": (_int, [_i32, _i32, _vp, _vp]),
     "vmcpde_chol_workspace_bytes": (_i64, [_i32]),

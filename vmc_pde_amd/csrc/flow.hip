@@ -95,11 +95,18 @@ struct Ctx {
   double* lds;
   int lanes;
   int lane;
+  int jt_f32;   // Jacobian rows are stored as float (BASELINE config 5) instead of double
   const double* __restrict__ th;
   const FlowProgram* __restrict__ fp;
 };
 
 #define LD(u) (c.lds[(u) * c.lanes + c.lane])
+
+// one Jacobian entry of this lane's sample: row `row` of the parameter-major buffer (fp64, or fp32 for config 5)
+__device__ __forceinline__ void jt_store(const Ctx& c, void* __restrict__ JT, int64_t ldj, int64_t row, int64_t n, double v) {
+  if (c.jt_f32) static_cast<float*>(JT)[row * ldj + n] = (float)v;
+  else static_cast<double*>(JT)[row * ldj + n] = v;
+}
 
 // y = tanh-layer(x): z_j = b_j + sum_i W[i][j] a_i (net.py:55-61), with NC Taylor components.
 template <int NC>
@@ -307,7 +314,7 @@ __device__ __forceinline__ void mlp_forward_store(const Ctx& c, const Trafo& T, 
 // Reverse pass through one SingleTrafo with output cotangent in uW: writes the parameter-gradient rows of this
 // sample into JT (bias: delta_j, kernel: a_i delta_j) and accumulates the input gradient into GAM.
 __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const Regions& r, int uOUT, int uW,
-                                             double* __restrict__ JT, int64_t ldj, int64_t n, bool active) {
+                                             void* __restrict__ JT, int64_t ldj, int64_t n, bool active) {
   const double alpha = c.fp->alpha;
   const int nl = T.n_layers;
   {
@@ -331,10 +338,9 @@ __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const
 #pragma unroll
       for (int jj = 0; jj < JB; ++jj) dl[jj] = (j0 + jj < n_out) ? LD(cur + j0 + jj) : 0.0;
       if (JT != nullptr && active) {
-        double* __restrict__ jb = JT + (int64_t)(L.off_bias + j0) * ldj + n;
 #pragma unroll
         for (int jj = 0; jj < JB; ++jj)
-          if (j0 + jj < n_out) jb[(int64_t)jj * ldj] = dl[jj];
+          if (j0 + jj < n_out) jt_store(c, JT, ldj, L.off_bias + j0 + jj, n, dl[jj]);
       }
       for (int i = 0; i < n_in; ++i) {
         const double a = LD(uin + i);
@@ -347,10 +353,9 @@ __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const
         }
         LD(r.EPS + i) += e;
         if (JT != nullptr && active) {
-          double* __restrict__ jk = JT + (int64_t)(L.off_kernel + i * n_out + j0) * ldj + n;
 #pragma unroll
           for (int jj = 0; jj < JB; ++jj)
-            if (j0 + jj < n_out) jk[(int64_t)jj * ldj] = a * dl[jj];
+            if (j0 + jj < n_out) jt_store(c, JT, ldj, L.off_kernel + i * n_out + j0 + jj, n, a * dl[jj]);
         }
       }
     }
@@ -369,7 +374,7 @@ __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const
 // Reverse sweep through one coupling half-step: on entry X holds the half-step's OUTPUT y and G = dlogp/dy;
 // on exit X holds its INPUT and G = dlogp/d(input).
 __device__ __forceinline__ void halfstep_backward(const Ctx& c, const HalfStep& h, const Regions& r,
-                                                  double* __restrict__ JT, int64_t ldj, int64_t n, bool active) {
+                                                  void* __restrict__ JT, int64_t ldj, int64_t n, bool active) {
   const int coupling = c.fp->coupling;
   for (int i = 0; i < h.n_a; ++i) LD(r.GAM + i) = 0.0;
   if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) {
@@ -410,7 +415,7 @@ __device__ __forceinline__ void halfstep_backward(const Ctx& c, const HalfStep& 
 
 // Adjoint of the latent log-density: G = dlogp/dz and the latent-parameter rows of JT (L, L_diag, dist_params, mu).
 __device__ __forceinline__ void latent_backward(const Ctx& c, const LatentCache* __restrict__ lc, const Regions& r,
-                                                double* __restrict__ JT, int64_t ldj, int64_t n, bool active) {
+                                                void* __restrict__ JT, int64_t ldj, int64_t n, bool active) {
   const FlowProgram& fp = *c.fp;
   const int d = fp.dim;
   double Q = 0.0;
@@ -439,14 +444,14 @@ __device__ __forceinline__ void latent_backward(const Ctx& c, const LatentCache*
     for (int i = 0; i < d; ++i) {
       const double qi = LD(r.Q + i);
       for (int j = i + 1; j < d; ++j, ++k)   // dQ/dU_ij = -2 q_i y_j ; row-major strict upper triangle (util.py:23-24)
-        JT[(int64_t)(fp.off_L + k) * ldj + n] = m2f1 * qi * LD(r.Y + j);
+        jt_store(c, JT, ldj, fp.off_L + k, n, m2f1 * qi * LD(r.Y + j));
       // U_ii = exp(L_diag_i); Gauss also carries -1/2 log det S = -sum L_diag (net.py:20)
-      JT[(int64_t)(fp.off_Ldiag + i) * ldj + n] = m2f1 * qi * LD(r.Y + i) * lc->U[i * MAX_DIM + i] - (gauss ? 1.0 : 0.0);
-      JT[(int64_t)(fp.off_mu + i) * ldj + n] = m2f1 * qi;
+      jt_store(c, JT, ldj, fp.off_Ldiag + i, n, m2f1 * qi * LD(r.Y + i) * lc->U[i * MAX_DIM + i] - (gauss ? 1.0 : 0.0));
+      jt_store(c, JT, ldj, fp.off_mu + i, n, m2f1 * qi);
     }
     if (!gauss) {
       const double dnu = -0.5 * log1p(Q / nu) + 0.5 * (nu + p) * Q / (nu * (nu + Q));
-      JT[(int64_t)fp.off_dist * ldj + n] = lc->dlognorm_dtau + (nu - 1.0) * dnu;   // nu = exp(tau)+1 (net.py:32)
+      jt_store(c, JT, ldj, fp.off_dist, n, lc->dlognorm_dtau + (nu - 1.0) * dnu);   // nu = exp(tau)+1 (net.py:32)
     }
   }
 }
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(64) void flow_eval_kernel(const FlowProgram* __rest
                                                       const double* __restrict__ th, const double* __restrict__ x,
                                                       int64_t N, const double* __restrict__ dirs, int n_dirs,
                                                       double* __restrict__ logp, double* __restrict__ g,
-                                                      double* __restrict__ hv, double* __restrict__ JT, int64_t ldj,
+                                                      double* __restrict__ hv, void* __restrict__ JT, int64_t ldj, int jt_f32,
                                                       int lanes, Regions r) {
   extern __shared__ double lds[];
   Ctx c;
@@ -464,6 +469,7 @@ __global__ __launch_bounds__(64) void flow_eval_kernel(const FlowProgram* __rest
   c.lane = threadIdx.x;
   c.th = th;
   c.fp = fp;
+  c.jt_f32 = jt_f32;
   if ((int)threadIdx.x >= lanes) return;  // no barriers are used: one wave per workgroup
   const int d = fp->dim;
   const int64_t n = (int64_t)blockIdx.x * lanes + threadIdx.x;
@@ -513,6 +519,7 @@ __global__ __launch_bounds__(64) void flow_sample_kernel(const FlowProgram* __re
   c.lane = threadIdx.x;
   c.th = th;
   c.fp = fp;
+  c.jt_f32 = 0;
   if ((int)threadIdx.x >= lanes) return;
   const int d = fp->dim;
   const int64_t n = (int64_t)blockIdx.x * lanes + threadIdx.x;
@@ -689,7 +696,7 @@ int vmcpde_prepare_latent_internal(vmcpde_model* m, const double* theta, hipStre
 
 extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const double* x, int64_t n_samples,
                                 const double* dirs, int32_t n_dirs, double* logp, double* g, double* hv,
-                                double* JT, int64_t ldj, void* stream) {
+                                void* JT, int64_t ldj, int32_t jt_f32, void* stream) {
   VMC_REQUIRE(n_samples >= 0, "negative sample count");
   if (n_samples == 0) return 0;   // empty batch (torch gives a NULL data pointer for it)
   VMC_REQUIRE(m && theta && x, "vmcpde_flow_eval: null argument");
@@ -707,7 +714,7 @@ extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const doub
     VMC_CHECK_HIP(hipFuncSetAttribute((const void*)flow_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   const int64_t grid = (n_samples + lanes - 1) / lanes;
   hipLaunchKernelGGL(flow_eval_kernel, dim3((unsigned)grid), dim3(64), bytes, st, m->dev, m->cache, theta, x, n_samples,
-                     dirs, (hv ? n_dirs : 0), logp, g, hv, JT, ldj, lanes, r);
+                     dirs, (hv ? n_dirs : 0), logp, g, hv, JT, ldj, (int)jt_f32, lanes, r);
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }

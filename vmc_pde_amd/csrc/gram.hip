@@ -62,8 +62,8 @@ GramPlan make_plan(int P, int64_t N) {
   return g;
 }
 
-template <bool CENTER, bool SCALE>
-__global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__ JT, int64_t ldj, int P, int64_t N,
+template <bool CENTER, bool SCALE, typename TIn>
+__global__ __launch_bounds__(256, 2) void gram_kernel(const TIn* __restrict__ JT, int64_t ldj, int P, int64_t N,
                                                       const double* __restrict__ c, const double* __restrict__ scale,
                                                       int ntiles, int nsplit, int64_t chunk, int total_units,
                                                       int units_per_xcd, int order, double* __restrict__ out) {
@@ -97,10 +97,10 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double* __restrict__
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  if (!CENTER && !SCALE)
+  if constexpr (!CENTER && !SCALE && sizeof(TIn) == 8)
     tile_mainloop_dma(acc, JT, ldj, rowA0, JT, ldj, rowB0, ti == tj, k0, k1, lds);
   else
-    tile_mainloop<CENTER, SCALE>(acc, JT, ldj, rowA0, JT, ldj, rowB0, ti == tj, k0, k1, c, rowsA, c, rowsB, scale, lds);
+    tile_mainloop<CENTER, SCALE, TIn>(acc, JT, ldj, rowA0, JT, ldj, rowB0, ti == tj, k0, k1, c, rowsA, c, rowsB, scale, lds);
   tile_store(acc, out + ((int64_t)split * ntiles + tile) * (TILE * TILE));
 }
 
@@ -139,7 +139,8 @@ __global__ __launch_bounds__(1024) void eloc_stats_kernel(const double* __restri
 }
 
 // one workgroup per parameter row: rowsum[p] = sum_n (JT[p][n]-c[p]), rowdot[p] = sum_n (JT[p][n]-c[p]) (E_n - cE)
-__global__ __launch_bounds__(256) void row_moments_kernel(const double* __restrict__ JT, int64_t ldj, int64_t N,
+template <typename TIn>
+__global__ __launch_bounds__(256) void row_moments_kernel(const TIn* __restrict__ JT, int64_t ldj, int64_t N,
                                                          const double* __restrict__ e, const double* __restrict__ c,
                                                          const double* __restrict__ cE_dev, double* __restrict__ rowsum,
                                                          double* __restrict__ rowdot) {
@@ -147,18 +148,18 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const double* __restri
   const int p = blockIdx.x;
   const double cp = c ? c[p] : 0.0;
   const double cE = cE_dev ? cE_dev[0] : 0.0;
-  const double* __restrict__ row = JT + (int64_t)p * ldj;
+  const TIn* __restrict__ row = JT + (int64_t)p * ldj;
   double s = 0, sd = 0;
   const int64_t N2 = N & ~(int64_t)1;
   for (int64_t i = (int64_t)threadIdx.x * 2; i < N2; i += 512) {
-    const double2_t v = *reinterpret_cast<const double2_t*>(row + i);
+    const typename PairOf<TIn>::type v = *reinterpret_cast<const typename PairOf<TIn>::type*>(row + i);
     const double2_t ev = *reinterpret_cast<const double2_t*>(e + i);
-    const double a = v.x - cp, b = v.y - cp;
+    const double a = (double)v.x - cp, b = (double)v.y - cp;
     s += a + b;
     sd += a * (ev.x - cE) + b * (ev.y - cE);
   }
   if (threadIdx.x == 0 && N2 < N) {
-    const double a = row[N2] - cp;
+    const double a = (double)row[N2] - cp;
     s += a;
     sd += a * (e[N2] - cE);
   }
@@ -279,17 +280,21 @@ extern "C" int vmcpde_eloc_stats(const double* eloc, int64_t n_samples, double* 
   return 0;
 }
 
-extern "C" int vmcpde_row_moments(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, const double* eloc,
+extern "C" int vmcpde_row_moments(const void* JT, int64_t ldj, int32_t jt_f32, int32_t P, int64_t n_samples, const double* eloc,
                                   const double* c, const double* cE_dev, double* rowsum, double* rowdot, void* stream) {
   VMC_REQUIRE(JT && eloc && rowsum && rowdot, "vmcpde_row_moments: null argument");
   VMC_REQUIRE(P >= 1 && n_samples >= 1 && ldj >= n_samples && (ldj % 2) == 0, "bad shape (ldj must be even and >= N)");
-  hipLaunchKernelGGL(row_moments_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, JT, ldj, n_samples, eloc, c, cE_dev, rowsum,
-                     rowdot);
+  if (jt_f32)
+    hipLaunchKernelGGL(row_moments_kernel<float>, dim3(P), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(JT), ldj, n_samples,
+                       eloc, c, cE_dev, rowsum, rowdot);
+  else
+    hipLaunchKernelGGL(row_moments_kernel<double>, dim3(P), dim3(256), 0, (hipStream_t)stream, static_cast<const double*>(JT), ldj, n_samples,
+                       eloc, c, cE_dev, rowsum, rowdot);
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-extern "C" int vmcpde_gram(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, const double* c, const double* w,
+extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t P, int64_t n_samples, const double* c, const double* w,
                            double* packed, void* workspace, int64_t workspace_bytes, void* stream) {
   VMC_REQUIRE(JT && packed, "vmcpde_gram: null argument");
   VMC_REQUIRE(P >= 1 && n_samples >= 1, "bad shape");
@@ -312,19 +317,25 @@ extern "C" int vmcpde_gram(const double* JT, int64_t ldj, int32_t P, int64_t n_s
   const size_t lds_bytes = TILE_LDS_BYTES + lds_pad;
   static bool attr_set = false;
   if (!attr_set) {
-    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+#define VMC_ATTR(CEN, SCA, T) VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<CEN, SCA, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes))
+    VMC_ATTR(false, false, double); VMC_ATTR(true, false, double); VMC_ATTR(false, true, double); VMC_ATTR(true, true, double);
+    VMC_ATTR(false, false, float); VMC_ATTR(true, false, float); VMC_ATTR(false, true, float); VMC_ATTR(true, true, float);
+#undef VMC_ATTR
     attr_set = true;
   }
-#define VMC_LAUNCH_GRAM(CEN, SCA)                                                                                              \
-  hipLaunchKernelGGL((gram_kernel<CEN, SCA>), dim3(grid), dim3(256), lds_bytes, st, JT, ldj, P, n_samples, c, w, g.ntiles, g.nsplit, \
-                     g.chunk, total, per_xcd, order, out)
-  if (c && w) VMC_LAUNCH_GRAM(true, true);
-  else if (c) VMC_LAUNCH_GRAM(true, false);
-  else if (w) VMC_LAUNCH_GRAM(false, true);
-  else VMC_LAUNCH_GRAM(false, false);
+#define VMC_LAUNCH_GRAM(CEN, SCA, T)                                                                                              \
+  hipLaunchKernelGGL((gram_kernel<CEN, SCA, T>), dim3(grid), dim3(256), lds_bytes, st, static_cast<const T*>(JT), ldj, P, n_samples, c, w, \
+                     g.ntiles, g.nsplit, g.chunk, total, per_xcd, order, out)
+#define VMC_LAUNCH_GRAM_T(T)                          \
+  do {                                                \
+    if (c && w) VMC_LAUNCH_GRAM(true, true, T);       \
+    else if (c) VMC_LAUNCH_GRAM(true, false, T);      \
+    else if (w) VMC_LAUNCH_GRAM(false, true, T);      \
+    else VMC_LAUNCH_GRAM(false, false, T);            \
+  } while (0)
+  if (jt_f32) VMC_LAUNCH_GRAM_T(float);
+  else VMC_LAUNCH_GRAM_T(double);
+#undef VMC_LAUNCH_GRAM_T
 #undef VMC_LAUNCH_GRAM
   VMC_CHECK_HIP(hipGetLastError());
   if (g.nsplit > 1) {

@@ -56,13 +56,21 @@ __device__ __forceinline__ void tri_decode(int t, int& ti, int& tj) {
 // `tile` is wave-uniform (row block base + k), `off` the per-thread element offset of slot 0; slots are 32 rows apart.
 // stage_load only ISSUES the loads (raw values stay in flight behind the MFMAs of the current K-step);
 // stage_store centres / scales them and writes the LDS image, so the vmcnt wait lands after the matrix work.
+typedef float float2_t __attribute__((ext_vector_type(2)));
+template <typename T> struct PairOf;
+template <> struct PairOf<double> { typedef double2_t type; };
+template <> struct PairOf<float> { typedef float2_t type; };
+
+// TIn = double: the fp64 Jacobian; TIn = float: BASELINE config 5 (fp32 Jacobian, fp64 S/F accumulation) -- the pairs are
+// widened to fp64 when they are committed to LDS, the MFMAs are the same v_mfma_f64.
+template <typename TIn>
 struct Staged {
-  double2_t v[4];
+  typename PairOf<TIn>::type v[4];
   double2_t sc;
 };
 
-template <bool SCALE, bool TAIL>
-__device__ __forceinline__ void stage_load(Staged& r, const double* __restrict__ tile, uint32_t off, uint32_t slot_stride,
+template <bool SCALE, bool TAIL, typename TIn>
+__device__ __forceinline__ void stage_load(Staged<TIn>& r, const TIn* __restrict__ tile, uint32_t off, uint32_t slot_stride,
                                            const double* __restrict__ scale_k /* scale + k, or null */, int64_t krem) {
   const int t = threadIdx.x;
   const int kp = (t & 7) * 2;
@@ -76,25 +84,25 @@ __device__ __forceinline__ void stage_load(Staged& r, const double* __restrict__
   const char* __restrict__ base = reinterpret_cast<const char*>(tile);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const uint32_t boff = (off + q * slot_stride) * 8u;
+    const uint32_t boff = (off + q * slot_stride) * (uint32_t)sizeof(TIn);
     if (!TAIL) {
-      r.v[q] = *reinterpret_cast<const double2_t*>(base + boff);
+      r.v[q] = *reinterpret_cast<const typename PairOf<TIn>::type*>(base + boff);
     } else {
-      const double* p = reinterpret_cast<const double*>(base + boff);
-      r.v[q].x = (kp < krem) ? p[0] : 0.0;
-      r.v[q].y = (kp + 1 < krem) ? p[1] : 0.0;
+      const TIn* p = reinterpret_cast<const TIn*>(base + boff);
+      r.v[q].x = (kp < krem) ? p[0] : (TIn)0;
+      r.v[q].y = (kp + 1 < krem) ? p[1] : (TIn)0;
     }
   }
 }
 
-template <bool CENTER, bool SCALE, bool TAIL>
-__device__ __forceinline__ void stage_store(const Staged& r, double* __restrict__ lds, int tile_off, const double (&sh)[4], int64_t krem) {
+template <bool CENTER, bool SCALE, bool TAIL, typename TIn>
+__device__ __forceinline__ void stage_store(const Staged<TIn>& r, double* __restrict__ lds, int tile_off, const double (&sh)[4], int64_t krem) {
   const int t = threadIdx.x;
   const int kp = (t & 7) * 2;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int row = q * 32 + (t >> 3);
-    double2_t v = r.v[q];
+    double2_t v = {(double)r.v[q].x, (double)r.v[q].y};
     if (CENTER) {
       v.x -= sh[q];
       v.y -= sh[q];
@@ -139,9 +147,9 @@ __device__ __forceinline__ void mma_kstep(double4_t (&acc)[4][4], const double* 
 // Main loop of one tile.  alias: the B tile is the A tile (diagonal tile of a syrk) -> only A is staged.
 // shiftA/shiftB may be null (no centring); they are read for `nshift*` valid rows and zero-extended.
 // lds: TILE_LDS_DOUBLES doubles.
-template <bool CENTER, bool SCALE>
-__device__ __forceinline__ void tile_mainloop(double4_t (&acc)[4][4], const double* __restrict__ A, int64_t lda, int rowA0,
-                                              const double* __restrict__ B, int64_t ldb, int rowB0, bool alias, int64_t k0,
+template <bool CENTER, bool SCALE, typename TIn = double>
+__device__ __forceinline__ void tile_mainloop(double4_t (&acc)[4][4], const TIn* __restrict__ A, int64_t lda, int rowA0,
+                                              const TIn* __restrict__ B, int64_t ldb, int rowB0, bool alias, int64_t k0,
                                               int64_t k1, const double* __restrict__ shiftA, int nshiftA,
                                               const double* __restrict__ shiftB, int nshiftB, const double* __restrict__ scale,
                                               double* __restrict__ lds) {
@@ -156,8 +164,8 @@ __device__ __forceinline__ void tile_mainloop(double4_t (&acc)[4][4], const doub
     shB[t] = (shiftB != nullptr && t < nshiftB) ? shiftB[rowB0 + t] : 0.0;
   }
   __syncthreads();
-  const double* __restrict__ tA = A + (int64_t)rowA0 * lda;
-  const double* __restrict__ tB = B + (int64_t)rowB0 * ldb;
+  const TIn* __restrict__ tA = A + (int64_t)rowA0 * lda;
+  const TIn* __restrict__ tB = B + (int64_t)rowB0 * ldb;
   const uint32_t offA = (uint32_t)(t >> 3) * (uint32_t)lda + (uint32_t)(t & 7) * 2u, strideA = 32u * (uint32_t)lda;
   const uint32_t offB = (uint32_t)(t >> 3) * (uint32_t)ldb + (uint32_t)(t & 7) * 2u, strideB = 32u * (uint32_t)ldb;
   const int64_t nfull = (k1 - k0) / BK;          // full K-steps
@@ -169,7 +177,7 @@ __device__ __forceinline__ void tile_mainloop(double4_t (&acc)[4][4], const doub
     SHB[q] = shB[q * 32 + (t >> 3)];
   }
   const int boff = alias ? 0 : TILE_LDS;
-  Staged ra, rb;
+  Staged<TIn> ra, rb;
 
   // prologue: stage the first K-step
   if (nfull > 0) {
@@ -359,7 +367,7 @@ __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const 
   }
 #endif
   if (tail > 0) {   // ragged last step (N not a multiple of 16): masked register staging into the same swizzled image
-    Staged ra, rb;
+    Staged<double> ra, rb;
     const uint32_t oA = (uint32_t)(t >> 3) * (uint32_t)lda + (uint32_t)(t & 7) * 2u, sA = 32u * (uint32_t)lda;
     const uint32_t oB = (uint32_t)(t >> 3) * (uint32_t)ldb + (uint32_t)(t & 7) * 2u, sB = 32u * (uint32_t)ldb;
     stage_load<false, true>(ra, tA + k, oA, sA, nullptr, tail);

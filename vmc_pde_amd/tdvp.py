@@ -86,8 +86,8 @@ class TDVP:
         if hook is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        nat.call("vmcpde_gram", nat.ptr(JT), ldj, P, n, nat.ptr(c), nat.ptr(w), nat.ptr(out), nat.ptr(b["gram_ws"]),
-                 b["gram_ws"].numel() * 8, nat.stream())
+        nat.call("vmcpde_gram", nat.ptr(JT), ldj, 1 if JT.dtype == torch.float32 else 0, P, n, nat.ptr(c), nat.ptr(w), nat.ptr(out),
+                 nat.ptr(b["gram_ws"]), b["gram_ws"].numel() * 8, nat.stream())
         if hook is not None:
             e1.record()
             hook(e0, e1)
@@ -104,7 +104,7 @@ class TDVP:
         jt = psi.jt_buffer_of(gradients) if psi is not None and hasattr(psi, "jt_buffer_of") else None
         if jt is None:   # generic input: repack once into the padded parameter-major layout the kernels consume
             ldj = _round_up(n, 16)
-            JT = torch.zeros((b["Ppad"], ldj), dtype=global_defs.tReal, device=device)
+            JT = torch.zeros((b["Ppad"], ldj), dtype=gradients.dtype if gradients.dtype == torch.float32 else global_defs.tReal, device=device)
             JT[:P, :n] = gradients.reshape(n, P).T
         else:
             JT, ldj = jt
@@ -121,7 +121,7 @@ class TDVP:
                 # pass 1: raw sums -> global means (tdvp.py:37,41); tiny all-reduce when sharded
                 b["c"].zero_()
                 b["cE"].zero_()
-                nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, P, n, nat.ptr(e), None, None, nat.ptr(b["rowsum"]),
+                nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, 1 if JT.dtype == torch.float32 else 0, P, n, nat.ptr(e), None, None, nat.ptr(b["rowsum"]),
                          nat.ptr(b["rowdot"]), nat.stream())
                 if world > 1:
                     small = torch.cat([b["rowsum"], b["sums"][:1], b["count"]])
@@ -135,7 +135,7 @@ class TDVP:
                 b["c"].copy_(self._c_prev)
                 b["cE"].copy_(self._cE_prev)
             # pass 2 (tdvp.py:40-45 in shifted form): sum (O - c), sum (O - c)(E - cE); then the syrk (tdvp.py:46)
-            nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, P, n, nat.ptr(e), nat.ptr(b["c"]), nat.ptr(b["cE"]),
+            nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, 1 if JT.dtype == torch.float32 else 0, P, n, nat.ptr(e), nat.ptr(b["c"]), nat.ptr(b["cE"]),
                      nat.ptr(b["rowsum"]), nat.ptr(b["rowdot"]), nat.stream())
             shift_mode = self.gramShift
             if shift_mode == "auto":

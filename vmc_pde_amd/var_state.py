@@ -27,10 +27,12 @@ def _round_up(v, m):
 
 class VarState:
 
-    def __init__(self, sampler, dim, *args, network_args={}, inds_up=None, inds_down=None):
+    def __init__(self, sampler, dim, *args, network_args={}, inds_up=None, inds_down=None, jacobian_dtype=torch.float64):
         self.sampler = sampler
         self.dim = dim
         self.device = global_defs.my_device()
+        assert jacobian_dtype in (torch.float64, torch.float32)
+        self.jacobian_dtype = jacobian_dtype      # float32 = BASELINE config 5 (fp32 Jacobian, fp64 S/F accumulation)
         self.net, self._theta = self.init_net(network_args, *args, inds_up=inds_up, inds_down=inds_down)
         self.numParameters = self.net.numParameters                       # var_state.py:27
         self.paramShapes = [(int(np.prod(s)), tuple(s)) for _, _, s in self.net.layout]   # var_state.py:25
@@ -45,7 +47,7 @@ class VarState:
             P = self.numParameters
             ldj = _round_up(max(n, 1), 16)
             ws = dict(ldj=ldj,
-                      JT=torch.zeros((_round_up(P, nat.GRAM_TILE), ldj), dtype=global_defs.tReal, device=self.device),
+                      JT=torch.zeros((_round_up(P, nat.GRAM_TILE), ldj), dtype=self.jacobian_dtype, device=self.device),
                       logp=torch.empty(n, dtype=global_defs.tReal, device=self.device),
                       g=torch.empty((n, self.dim), dtype=global_defs.tReal, device=self.device))
             if len(self._ws) >= 2:   # at most two sample counts alive (TDVP + observables)
@@ -78,7 +80,7 @@ class VarState:
         with torch.cuda.device(self.device):
             nat.call("vmcpde_flow_eval", self.net.handle, nat.ptr(self._theta), nat.ptr(x), n, nat.ptr(dirs_t), D,
                      nat.ptr(ws["logp"]), nat.ptr(ws["g"]) if want_g else None, nat.ptr(hv),
-                     nat.ptr(ws["JT"]) if want_J else None, ws["ldj"], nat.stream())
+                     nat.ptr(ws["JT"]) if want_J else None, ws["ldj"], 1 if self.jacobian_dtype == torch.float32 else 0, nat.stream())
         P = self.numParameters
         return dict(x=x, logp=ws["logp"], g=ws["g"], hv=hv, JT=ws["JT"], ldj=ws["ldj"], n=n,
                     J=ws["JT"][:P, :n].T[None, ...] if want_J else None)
