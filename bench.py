@@ -109,6 +109,7 @@ def cpu_baseline(theta_cpu, inds_up, inds_down):
     EO = (Eg - Eg.mean())[:, None] * Oc            # tdvp.py:44
     F0 = EO.mean(0)
     S0 = Oc.T @ Oc / n_gemm                        # tdvp.py:46
+    t_gram1 = time.perf_counter() - t0
     Ow = Eg[:, None] * Oc
     SExp = Ow.T @ Ow / n_gemm                      # tdvp.py:47
     t_gram = time.perf_counter() - t0
@@ -121,11 +122,14 @@ def cpu_baseline(theta_cpu, inds_up, inds_down):
     rho = EOV.var(0)
     t_eov = time.perf_counter() - t0
     total = t_ad * (N_SAMP / n_ad) + (t_gram + t_eov) * (N_SAMP / n_gemm) + t_eigh
+    fair = t_ad * (N_SAMP / n_ad) + t_gram1 * (N_SAMP / n_gemm) + t_eigh     # one Gram, no SExp, no EO@V
     return {"value": 1.0 / total, "unit": "TDVP steps/s", "cores": cores, "kind": "port",
             "sample": (f"reference algorithm as written on torch/numpy fp64 CPU: autodiff J+Hessian at N={n_ad} (x{N_SAMP // n_ad}), "
                        f"two Gram GEMMs + EO@V at N={n_gemm} (x{N_SAMP // n_gemm}), full P={P} eigh once; "
                        f"parts {t_ad:.2f}s/{t_gram:.2f}s/{t_eov:.2f}s/{t_eigh:.2f}s -> {total:.1f}s per 65536-sample step (extrapolated)"),
-            "seconds_per_step_extrapolated": total}
+            "seconds_per_step_extrapolated": total,
+            "fair_variant": {"value": 1.0 / fair, "unit": "TDVP steps/s",
+                             "what": "same port without the reference's redundant work (one centred Gram GEMM, no SExp, no EO@V)"}}
 
 
 def main():
@@ -192,6 +196,26 @@ def main():
     resid = float(tdvp.solverResidual)
 
     gram_ms = float(np.mean([a.elapsed_time(b) for a, b in gram_events])) if gram_events else float("nan")
+
+    # outside the timed region: per-stage wall times with a device sync at each section boundary (the reference's
+    # timing sections, tdvp.py:116-128), and one Heun integrator step = 2 TDVP steps (stepper.py:135-137)
+    tdvp._event_hook = None
+    ratio = float(tdvp._ratio_host[0]) if tdvp._ratio_host is not None else None
+    stage_ms, heun_ms = {}, None
+    if world == 1:
+        tm = V.util.Timings()
+        for _ in range(5):
+            tdvp(theta, 0.0, **{**kwargs, "timings": tm})
+        stage_ms = {k: {"median": float(np.median(v)) * 1e3, "min": float(np.min(v)) * 1e3} for k, v in tm.timing_dict.items()}
+        stepper = V.FixedStepper(timeStep=1e-4, mode="Heun", maxStep=1e-4, increase_fac=1.0)
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            stepper.step(0.0, tdvp, theta, **kwargs)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        heun_ms = float(np.median(ts)) * 1e3
     flops = float(args.samples) * P * (P + 1)
     achieved = flops / (gram_ms * 1e-3) / 1e12
     peak_meas = measure_mfma_peak(device)
@@ -199,7 +223,7 @@ def main():
     if rank == 0:
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "gram_pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.workload == "C2" and args.jacobian == "f64" and args.samples == N_SAMP:
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
@@ -215,13 +239,14 @@ def main():
             "dtype": "f64" if args.jacobian == "f64" else "f64 accumulate, f32 Jacobian storage (BASELINE config 5)", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload]["desc"],
                        "n_param": P, "n_samp_per_gpu": args.samples, "n_samp_total": n_total, "solver": "cholesky", "gram_operands": (("uncentred+DMA" if args.jacobian == "f64" else "uncentred, fp32 widened in staging") if tdvp._uncentred_ok else "centred in staging"),
-                       "mean2_over_var_max": (float(tdvp._ratio_host[0]) if tdvp._ratio_host is not None else None),
+                       "mean2_over_var_max": ratio,
                        "diagonal_shift": DIAG_SHIFT, "solver_residual": resid, "parallelism": f"dp{world} (samples sharded, one all-reduce of (S,F) per step)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": traffic,
                          "kernel": "gram_kernel (fp64 MFMA syrk, + split-K reduce)", "ms_per_launch": gram_ms,
                          "algorithmic_flops_per_launch": flops, "measured_mfma_f64_peak": peak_meas,
                          "frac_of_measured_peak": achieved / peak_meas if peak_meas > 0 else None},
+            "stages_ms": stage_ms, "heun_step_ms": heun_ms,
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "C2" and args.samples == N_SAMP:
             line["cpu_baseline"] = cpu_baseline(theta.cpu(), vs.net.inds_up, vs.net.inds_down)

@@ -1,0 +1,67 @@
+"""The committed oracle vectors (tests/golden/oracle_vectors.npz, made by tests/golden/make_oracle_fixtures.py) still come
+out of oracle/vmc_oracle.py: a silent edit of the restatement shows up here, on CPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_oracle_fixtures as M  # noqa: E402
+from oracle import vmc_oracle as O  # noqa: E402
+
+GOLD = np.load(os.path.join(HERE, "golden", "oracle_vectors.npz"))
+
+
+def _close(a, b, tol):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) <= tol * (np.linalg.norm(b) + 1e-300)
+
+
+@pytest.mark.parametrize("k", range(len(M.CASES)))
+def test_oracle_reproduces_committed_vectors(k):
+    tag, dim, depth, hidden, latent, coupling, eqs = M.CASES[k]
+    spec, th, z = M.case_inputs(tag, dim, depth, hidden, latent, coupling, seed=k + 1)
+    assert np.array_equal(th.numpy(), GOLD[f"{tag}/theta"]) and np.array_equal(z.numpy(), GOLD[f"{tag}/z"])
+    assert np.array_equal(np.asarray(spec.inds_up), GOLD[f"{tag}/inds_up"])
+    vo = O.VarStateOracle(spec, th)
+    x, logp_s = vo.flow_sample(z)
+    logp, g, J = vo(x, mode="eval_coordgrads")
+    H = vo.hessian(x)
+    for name, val in (("x", x), ("logp_sample", logp_s), ("logp", logp), ("grad_x", g), ("hessian", H), ("J", J)):
+        assert _close(val.numpy(), GOLD[f"{tag}/{name}"], 1e-13), name
+    # log p of the inverse flow equals log p of the forward evaluation at the same points (net.py:214-217 vs :209-213)
+    assert _close(logp_s.numpy(), logp.numpy(), 1e-12)
+    name = eqs[0]
+    eo = M.make_eq(dim, name)
+    to = O.TDVPOracle()
+    upd, aux = to.rhs(th, M.T_EVAL, vo, eo, z)
+    pre = f"{tag}/{name}"
+    assert _close(aux["Eloc"].numpy(), GOLD[f"{pre}/Eloc"], 1e-12)
+    assert _close(to.F0.numpy(), GOLD[f"{pre}/F0"], 1e-12)
+    P = th.numel()
+    for key in ("S0", "SExp"):
+        Mx = getattr(to, key)
+        if P <= M.FULL_MATRIX_MAX_P:
+            assert _close(Mx.numpy(), GOLD[f"{pre}/{key}"], 1e-12)
+        else:
+            assert _close(torch.diag(Mx).numpy(), GOLD[f"{pre}/{key}_diag"], 1e-12)
+            assert _close((Mx @ M.probe_vector(P)).numpy(), GOLD[f"{pre}/{key}_probe"], 1e-12)
+    # spectrum: the significant part (eigenvalues at round-off level depend on the LAPACK build)
+    ev, evg = to.ev.numpy(), GOLD[f"{pre}/ev"]
+    big = evg > 1e-9 * evg[-1]
+    assert np.allclose(ev[big], evg[big], rtol=1e-7, atol=0)
+    # S is rank deficient: the update is compared in the S-norm
+    du = upd.numpy() - GOLD[f"{pre}/update"]
+    S0 = to.S0.numpy()
+    assert np.linalg.norm(S0 @ du) <= 1e-8 * np.linalg.norm(GOLD[f"{pre}/F0"])
+    assert abs(float(to.tdvp_error) - float(GOLD[f"{pre}/tdvp_error"])) < 1e-7
+
+
+def test_heun_fixture_is_consistent():
+    h = np.load(os.path.join(HERE, "golden", "oracle_heun_step.npz"))
+    assert h["theta0"].shape == h["theta1"].shape == (37,)
+    assert float(h["dt"]) == O.fixed_stepper_dt(1e-5, 1.3, 1e-4)
+    assert 0 < np.linalg.norm(h["theta1"] - h["theta0"]) < 0.1
