@@ -88,7 +88,7 @@ def test_gram_fp32_operand_equals_fp64_path_on_fp32_values(P, N):
     e = torch.as_tensor(np.random.default_rng(2).normal(size=N)).to(DEV)
     outs = []
     for buf, f32 in ((JT32, 1), (JT64, 0)):
-        cc, cE = torch.empty(P, dtype=torch.float64, device=DEV), torch.empty(P, dtype=torch.float64, device=DEV)
+        cE = torch.full((1,), 0.25, dtype=torch.float64, device=DEV)          # the Eloc shift, read from cE[0]
         rs, rd = torch.empty(P, dtype=torch.float64, device=DEV), torch.empty(P, dtype=torch.float64, device=DEV)
         nat.call("vmcpde_row_moments", nat.ptr(buf), ldj, f32, P, N, nat.ptr(e), nat.ptr(c), nat.ptr(cE), nat.ptr(rs), nat.ptr(rd), nat.stream())
         outs.append((rs.clone(), rd.clone()))

@@ -37,6 +37,7 @@ __device__ __forceinline__ void tile_store_global(const double4_t (&acc)[4][4], 
 }
 
 constexpr int SB = 32;          // sub-block width inside a 128-wide panel
+constexpr int FUSED_MAX_TILES = 1024;   // trailing-update size up to which the next diagonal block rides in the same launch
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -72,99 +73,75 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double& d, double& inv_d) {
   inv_d = h + h;
 }
 
-// Wave 0: Cholesky of the 32x32 diagonal sub-block at (j0,j0) of the LDS block `a` and its triangular inverse.
-// Lane i keeps row i in registers (lanes 32..63 mirror 0..31); each column's multipliers are exchanged through a
-// 32-double LDS line read back as broadcasts (one wave: DS operations execute in issue order, no workgroup barrier).
-// The factor loop is fully unrolled (static register indices) and free of per-lane compares (the diagonal entry goes
-// through an LDS slot) because hipcc otherwise hoists the lane masks into SGPRs and spills; a sched_barrier closes every
-// column to keep the live set small.
+// Wave 0: Cholesky of the 32x32 diagonal sub-block at (j0,j0) of the LDS block `a` and, in the same sweep, its inverse.
+// Lanes 0..31 keep row i of the block in registers and eliminate column after column (right-looking).  Lanes 32..63
+// run the column-oriented forward substitution L x = e_q for column q = lane-32 of X = L^-1:  x_j = b_j / L[j][j],
+// b_k -= L[k][j] x_j (k > j).  Both halves need exactly the same broadcast per step -- the multipliers L[k][j] of column j
+// -- so one v_readlane pair per (j,k) feeds ONE 64-lane FMA as a scalar operand, with a per-lane multiplier (L[i][j] on
+// the lower half, x_j on the upper half).  The loop touches no LDS and has no dependent memory round trip.
+// It is fully unrolled (static register indices) and free of per-lane compares: lane-dependent 0/1 factors are built with
+// v_add_f64 ... clamp, because hipcc keeps compare results alive as SGPR lane masks and spills; there is no branch
+// inside (MachineSink would move the FMAs into later blocks and spill their scalar operands), and the broadcasts are
+// fenced in groups of 8 so that at most 16 SGPRs are in flight.
 // L goes to the lower triangle; X = L^-1 is kept transposed in the dead strict upper part: X[r][c] <-> a[c][r+1].
-// scr: 32-double exchange line followed by the 32 reciprocal diagonal entries.
-__device__ __forceinline__ int factor_inverse_32(double* a, int j0, double* scr, double* T1, bool do_inverse) {
-  const int i = threadIdx.x & 31;
+// scr: 64-double dump line for the masked-out stores.
+__device__ __forceinline__ int factor_inverse_32(double* a, int j0, double* scr, bool do_inverse) {
+  int lane = threadIdx.x & 63;
+  // opaque per call: otherwise LICM hoists the lane-only values below (delta, store addresses) out of the caller's
+  // sub-block loop and keeps them alive across it -- hundreds of spilled VGPRs
+  asm volatile("" : "+v"(lane));
+  const int i = lane & 31;                          // row (lower half) / column of X (upper half)
+  const bool lower = lane < 32;
   const int rowbase = (j0 + i) * DP + j0;
-  double* col = scr;
-  double r[SB];
+  const double di = (double)i;
+  double v[SB];
 #pragma unroll
-  for (int c = 0; c < SB; ++c) r[c] = a[rowbase + c];
+  for (int c = 0; c < SB; ++c) {
+    const double aic = a[rowbase + c];
+    const double delta = 1.0 - __builtin_fmin(__builtin_fabs(di - (double)c), 1.0);
+    v[c] = lower ? aic : delta;
+  }
   int pinned = 0;
 #pragma unroll
   for (int j = 0; j < SB; ++j) {
-    const double p = readlane_f64(r[j], j);
+    const double p = readlane_f64(v[j], j);
     const bool bad = !(p > 0.0) || !isfinite(p);     // wave-uniform: dead / padded parameter (H7) -> unit row
     pinned += bad ? 1 : 0;
     double d, inv_d;
     sqrt_rsqrt(p, d, inv_d);                         // one coupled iteration instead of sqrt + a division per column
     d = bad ? 1.0 : d;
-    inv_d = bad ? 0.0 : inv_d;
-    col[i] = r[j] * inv_d;                           // multipliers of the rows below (junk for rows above: harmless)
-    __builtin_amdgcn_wave_barrier();
-    col[j] = d;                                      // the diagonal entry, same value from every lane
-    col[SB + j] = bad ? 1.0 : inv_d;                 // 1/L[j][j] for the triangular inverse below (unit row when pinned)
-    __builtin_amdgcn_wave_barrier();
-    const double l = col[i];
-    r[j] = l;
+    inv_d = bad ? 0.0 : inv_d;                       // pinned: no multipliers below, unit diagonal for the inverse
+    const double scale = lower ? inv_d : (bad ? 1.0 : inv_d);
+    double m = v[j] * scale;                         // L[i][j] (junk for rows above j: never stored) | x_j of column q
+    m = (lane == j) ? d : m;                         // lane j keeps the diagonal entry itself (also when the pivot is NaN)
+    v[j] = m;
 #pragma unroll
-    for (int c = j + 1; c < SB; ++c) r[c] = fma(-l, col[c], r[c]);   // meaningful for lanes i >= c; others carry junk
-    __builtin_amdgcn_wave_barrier();
+    for (int k = j + 1; k < SB; ++k) {
+      v[k] = fma(-m, readlane_f64(m, k), v[k]);      // scalar operand L[k][j] from lower lane k
+      if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
-  // the junk above the diagonal is overwritten by X below, so the whole row can be stored unmasked
+  // lower lanes: L[i][c] for c <= i -> a[j0+i][j0+c];  upper lanes: X[k][q] for k >= q -> a[j0+q][j0+k+1].
+  // Everything else (junk above the diagonal, exact zeros that would land on L) is steered to a dump slot by address
+  // arithmetic instead of an exec mask (same SGPR-pressure reason as above).
+  const int dump = (int)(scr - a) + lane;
+  const int up = lower ? 0 : 1;
 #pragma unroll
-  for (int c = 0; c < SB; ++c) a[rowbase + c] = r[c];
+  for (int c = 0; c < SB; ++c) {
+    const int keep = lower ? min(max(i - c + 1, 0), 1) : (do_inverse ? min(max(c - i + 1, 0), 1) : 0);
+    const int real = rowbase + c + up;
+    a[dump + keep * (real - dump)] = v[c];
+  }
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  // the two 16x16 diagonal blocks of X = L^-1 by forward substitution, 16 columns each on lanes 0..15 / 16..31:
-  // x[k] = (delta_kc - sum_{c<=m<k} L[k][m] x[m]) / L[k][k].  x lives in its final place (shifted by one column); the
-  // inner loop is unrolled by 8 so eight LDS read pairs are in flight (a fully unrolled register-resident version makes
-  // hipcc spill ~600 VGPRs).  The off-diagonal 16x16 block is assembled by the whole workgroup (chol_diag_kernel).
-  if (do_inverse && (threadIdx.x & 63) < SB) {
-    // fixed trip counts + masks: hipcc can then issue all 32 LDS reads of a row at once (a loop with per-lane bounds
-    // degenerates into one dependent LDS round trip per element)
-    const int b0 = j0 + (i & 16), ci = i & 15;
-    double* xrow = a + (b0 + ci) * DP + b0 + 1;
-#pragma unroll 1
-    for (int k = 0; k < 16; ++k) {
-      const double* lrow = a + (b0 + k) * DP + b0;
-      double lv[16], xv[16];
-#pragma unroll
-      for (int m = 0; m < 16; ++m) {      // unconditional loads (all in bounds), masked afterwards
-        lv[m] = lrow[m];
-        xv[m] = xrow[m];
-      }
-      double acc0 = (k == ci) ? 1.0 : 0.0, acc1 = 0.0;
-#pragma unroll
-      for (int m = 0; m < 16; m += 2) {
-        acc0 = fma(-lv[m], (m >= ci && m < k) ? xv[m] : 0.0, acc0);
-        acc1 = fma(-lv[m + 1], (m + 1 >= ci && m + 1 < k) ? xv[m + 1] : 0.0, acc1);
-      }
-      if (k >= ci) xrow[k] = (acc0 + acc1) * col[SB + (b0 - j0) + k];
-    }
-  }
-  if (do_inverse) {
-    // off-diagonal 16x16 block X21 = -X22 (L21 X11) on the matrix pipe (this wave only; DS ops are in order)
-    __builtin_amdgcn_wave_barrier();
-    const int lane = threadIdx.x & 63;
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
-    mfma16(acc, 16, [&](int r, int k) { return a[(j0 + 16 + r) * DP + j0 + k]; },
-           [&](int c, int k) { return (k >= c) ? a[(j0 + c) * DP + j0 + k + 1] : 0.0; });          // X11[k][c]
-#pragma unroll
-    for (int q = 0; q < 4; ++q) T1[((lane >> 4) + 4 * q) * (SB + 1) + (lane & 15)] = acc[q];
-    __builtin_amdgcn_wave_barrier();
-    acc = (double4_t){0.0, 0.0, 0.0, 0.0};
-    mfma16(acc, 16, [&](int r, int k) { return (k <= r) ? a[(j0 + 16 + k) * DP + j0 + 16 + r + 1] : 0.0; },   // X22[r][k]
-           [&](int c, int k) { return T1[k * (SB + 1) + c]; });
-#pragma unroll
-    for (int q = 0; q < 4; ++q) a[(j0 + (lane & 15)) * DP + j0 + 16 + (lane >> 4) + 4 * q + 1] = -acc[q];
-  }
   return pinned;
 }
 
 // Factor the diagonal block A[k0:k0+n, k0:k0+n] = L L^T in LDS (four 32-wide sub-steps), write L back (lower triangle)
 // and X = L^-1 (dense lower triangular, zero elsewhere) to Linv.  One workgroup of 256 threads; rows/cols >= n are
 // padded with the identity.  LDS: the 128 x 129 block + three 32 x 33 scratch tiles.
-__global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, int64_t lda, int k0, int n, double* __restrict__ Linv,
-                                                       int* __restrict__ info, int phase /* diagnostic: 5 = everything */) {
+__device__ __forceinline__ void chol_diag_body(double* __restrict__ A, int64_t lda, int k0, int n, double* __restrict__ Linv,
+                                               int* __restrict__ info, int phase /* diagnostic: 5 = everything */) {
   extern __shared__ double a[];          // [NB][DP] followed by T[3][SB][SB+1]
   double* T = a + NB * DP;
   double* scr = T + 3 * SB * (SB + 1);   // exchange line of factor_inverse_32
@@ -193,7 +170,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, 
   for (int jb = 0; jb < NB / SB; ++jb) {
     const int j0 = jb * SB;
     if (phase >= 1 && t < 64) {
-      const int pinned = factor_inverse_32(a, j0, scr, T, phase >= 2);
+      const int pinned = factor_inverse_32(a, j0, scr, phase >= 2);
       if (t == 0 && pinned) atomicAdd(info, pinned);
     }
     __syncthreads();
@@ -248,9 +225,12 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, 
   }
 
   // write L back (lower triangle incl. diagonal)
-  for (int idx = t; idx < n * NB; idx += 256) {
-    const int i = idx / NB, j = idx - i * NB;
-    if (j <= i) A[(int64_t)(k0 + i) * lda + k0 + j] = a[i * DP + j];
+  // (fixed trip count + unroll: 16 LDS reads in flight per thread instead of one dependent read per iteration)
+#pragma unroll 16
+  for (int q = 0; q < NB * NB / 256; ++q) {
+    const int idx = t + 256 * q, i = idx / NB, j = idx - i * NB;
+    const double v = a[i * DP + j];
+    if (i < n && j <= i) A[(int64_t)(k0 + i) * lda + k0 + j] = v;
   }
 
   // off-diagonal 32x32 blocks of X = L^-1:  X_{ib,jb} = -X_{ib,ib} * sum_{mb=jb}^{ib-1} L_{ib,mb} X_{mb,jb},  by block
@@ -288,9 +268,11 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, 
       __syncthreads();
     }
   }
-  for (int idx = t; idx < NB * NB; idx += 256) {
-    const int i = idx / NB, c = idx - i * NB;
-    Linv[idx] = (i < n && c <= i) ? a[c * DP + i + 1] : 0.0;
+#pragma unroll 16
+  for (int q = 0; q < NB * NB / 256; ++q) {
+    const int idx = t + 256 * q, i = idx / NB, c = idx - i * NB;
+    const double v = a[c * DP + i + 1];
+    Linv[idx] = (i < n && c <= i) ? v : 0.0;
   }
 }
 
@@ -378,18 +360,19 @@ __global__ __launch_bounds__(256, 1) void chol_strip_kernel(double* __restrict__
       }
 }
 
-// Trailing update: A22 -= L21 L21^T on the lower-triangle tiles (syrk, K = n).
-// part 0: all tiles; part 1: only the first block column (ti, 0) -- the next panel; part 2: the remaining tiles (tj >= 1).
-__global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double* __restrict__ A, int64_t lda, int P, int k0, int n, int part) {
+// Trailing update A22 -= L21 L21^T on the lower-triangle tiles (syrk, K = n): see chol_syrk_diag_kernel.
+__global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, int64_t lda, int k0, int n, double* __restrict__ Linv,
+                                                       int* __restrict__ info, int phase) {
+  chol_diag_body(A, lda, k0, n, Linv, info, phase);
+}
+
+// One 128 x 128 tile (ti, tj >= 1: the first block column belongs to chol_strip_kernel mode 1) of A22 -= L21 L21^T.
+__device__ __forceinline__ void syrk_tile(double* __restrict__ A, int64_t lda, int P, int k0, int n, int tile) {
   extern __shared__ double lds[];
   int ti, tj;
-  if (part == 1) {
-    ti = blockIdx.x;
-    tj = 0;
-  } else {
-    tri_decode(blockIdx.x, ti, tj);
-    if (part == 2) { ++ti; ++tj; }
-  }
+  tri_decode(tile, ti, tj);
+  ++ti;
+  ++tj;
   const int base = k0 + n;
   const int rowA0 = base + ti * TILE, rowB0 = base + tj * TILE;
   const int rowsA = (P - rowA0 < TILE) ? (P - rowA0) : TILE;
@@ -401,6 +384,26 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double* __restrict__ 
     for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
   tile_mainloop_dma(acc, A + k0, lda, rowA0, A + k0, lda, rowB0, ti == tj, 0, n, lds);
   tile_store_global(acc, A + (int64_t)rowA0 * lda + rowB0, lda, rowsA, rowsB, 1);
+}
+
+// Lookahead, small trailing matrices: one launch holds the trailing update of panel k AND, as workgroup 0, the
+// factorisation of the next diagonal block, which depends only on the first block column (already updated by
+// chol_strip_kernel mode 1).  The ~75 us single-workgroup critical path then runs next to the update instead of after it,
+// with no cross-stream event (about 10 us each way).  Every workgroup carries the diagonal block's 140 KB of LDS, i.e.
+// one workgroup per CU -- fine while the update is a few rounds of tiles, too slow for large ones (see vmcpde_cholesky).
+__global__ __launch_bounds__(256) void chol_syrk_diag_kernel(double* __restrict__ A, int64_t lda, int P, int k0, int n,
+                                                            double* __restrict__ Linv_next, int* __restrict__ info, int phase) {
+  if (blockIdx.x == 0) {
+    const int k1 = k0 + n;
+    chol_diag_body(A, lda, k1, (P - k1 < NB) ? (P - k1) : NB, Linv_next, info, phase);
+    return;
+  }
+  syrk_tile(A, lda, P, k0, n, blockIdx.x - 1);
+}
+
+// Large trailing matrices: the update alone, two workgroups per CU; the next diagonal block is factored on a side stream.
+__global__ __launch_bounds__(256, 2) void chol_syrk_kernel(double* __restrict__ A, int64_t lda, int P, int k0, int n) {
+  syrk_tile(A, lda, P, k0, n, blockIdx.x);
 }
 
 // y_blk = Linv_blk * r_blk (trans=0) or Linv_blk^T * r_blk (trans=1), in place in r (n <= 128 valid entries).
@@ -561,21 +564,26 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
   hipStream_t st = (hipStream_t)stream;
   double* Linv = static_cast<double*>(workspace);
   const int nb = (P + NB - 1) / NB;
-  const size_t diag_lds = ((size_t)NB * DP + 3 * SB * (SB + 1) + 2 * SB) * sizeof(double);
-  const size_t tile_lds = TILE_LDS_BYTES;
+  const size_t diag_lds = ((size_t)NB * DP + 3 * SB * (SB + 1) + 2 * SB) * sizeof(double);   // block + 3 tiles + 64-slot dump line of factor_inverse_32
+  static_assert(((size_t)NB * DP + 3 * SB * (SB + 1) + 2 * SB) * sizeof(double) >= TILE_DMA_LDS_BYTES, "the fused launch sizes its LDS for the diagonal block");
   const size_t strip_lds = (size_t)(NB + 32) * SP * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
     VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds));
-    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
+    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_syrk_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
+    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_DMA_LDS_BYTES));
     attr_set = true;
   }
   VMC_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), st));
-  // Lookahead: the diagonal block of panel k+1 only depends on the first block column of panel k's trailing update, so it
-  // is factored on an internal side stream while the rest of that update runs on the caller's stream.  The fork/join is
-  // anchored on the caller's stream with events: from outside, all work is ordered in `stream` as usual.
+  // Lookahead: the diagonal block of panel k+1 only depends on the first block column of panel k's trailing update.
+  //  * up to FUSED_MAX_TILES tiles in the rest of that update: workgroup 0 of the same launch factors it
+  //    (chol_syrk_diag_kernel) -- the update is short, the single-workgroup factorisation is the critical path;
+  //  * more: the update is the critical path; it runs at two workgroups per CU on the caller's stream while the block is
+  //    factored on an internal side stream (fork/join with events anchored on the caller's stream, so that from outside
+  //    all work is ordered in `stream` as usual).
   static const int diag_phase = getenv("VMCPDE_DIAG_PHASE") ? atoi(getenv("VMCPDE_DIAG_PHASE")) : 5;   // timing diagnostics only
+  static const int fused_max = getenv("VMCPDE_CHOL_FUSED_MAX") ? atoi(getenv("VMCPDE_CHOL_FUSED_MAX")) : FUSED_MAX_TILES;
   static hipStream_t side = nullptr;
   static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   if (side == nullptr) {
@@ -596,17 +604,23 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
     // n == NB here (a panel with rows below it is always full); row strips of 32 over the zero-padded row range
     hipLaunchKernelGGL(chol_strip_kernel, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 0, Linv + (int64_t)k * NB * NB);
     hipLaunchKernelGGL(chol_strip_kernel, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 1, Linv);
-    VMC_CHECK_HIP(hipEventRecord(ev_fork, st));
-    VMC_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-    {
-      const int k1 = k0 + n;
-      const int n1 = (P - k1 < NB) ? (P - k1) : NB;
-      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), diag_lds, side, A, lda, k1, n1, Linv + (int64_t)(k + 1) * NB * NB, info, diag_phase);
+    double* Linv_next = Linv + (int64_t)(k + 1) * NB * NB;
+    const int k1 = k0 + n;
+    const int n1 = (P - k1 < NB) ? (P - k1) : NB;
+    const int64_t tiles = (nrem > 1) ? tri_count(nrem - 1) : 0;
+    if (tiles == 0) {
+      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), diag_lds, st, A, lda, k1, n1, Linv_next, info, diag_phase);
+    } else if (tiles <= fused_max) {
+      hipLaunchKernelGGL(chol_syrk_diag_kernel, dim3(1u + (unsigned)tiles), dim3(256), diag_lds, st, A, lda, P, k0, n, Linv_next, info,
+                         diag_phase);
+    } else {
+      VMC_CHECK_HIP(hipEventRecord(ev_fork, st));
+      VMC_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), diag_lds, side, A, lda, k1, n1, Linv_next, info, diag_phase);
+      VMC_CHECK_HIP(hipEventRecord(ev_join, side));
+      hipLaunchKernelGGL(chol_syrk_kernel, dim3((unsigned)tiles), dim3(256), TILE_DMA_LDS_BYTES, st, A, lda, P, k0, n);
+      VMC_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
     }
-    VMC_CHECK_HIP(hipEventRecord(ev_join, side));
-    if (nrem > 1)
-      hipLaunchKernelGGL(chol_syrk_kernel, dim3((unsigned)tri_count(nrem - 1)), dim3(256), tile_lds, st, A, lda, P, k0, n, 2);
-    VMC_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
   }
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
