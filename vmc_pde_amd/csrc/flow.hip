@@ -6,10 +6,15 @@
 //   variants), net.py:168-182 (INN), net.py:209-217 (INNwProb), net.py:10-36 (Gauss / Student_t),
 //   util.py:21-26 (covariance factor), evolutionEq.py:23-45, 84-119.
 //
-// Execution model (gfx950): ONE SAMPLE PER LANE, one 64-lane wave per workgroup.  Every per-sample vector
-// (state, MLP activations, tangents, adjoints) lives in LDS as [unit][lane] (lane-contiguous doubles, so each
-// ds_read_b64/ds_write_b64 is conflict-free); MLP weights are wave-uniform and are read through the scalar
-// cache (s_load) straight from the flat parameter vector; the output-blocked (JB=8) accumulators live in VGPRs.
+// Execution model (gfx950): ONE SAMPLE PER LANE, and up to four waves per workgroup that COOPERATE on the same 64 samples.
+// Every per-sample vector (state, MLP activations, tangents, adjoints) lives in LDS as [unit][lane] (lane-contiguous
+// doubles, so each ds_read_b64/ds_write_b64 is conflict-free) and is shared by the waves of the workgroup; MLP weights
+// are wave-uniform and are read through the scalar cache (s_load) straight from the flat parameter vector; the
+// output-blocked (JB) accumulators live in VGPRs.  The dense layers -- all the O(width^2) work -- are split between
+// the waves (forward: by output block; reverse: by input unit, which also splits the Jacobian rows), the O(d) coupling
+// algebra is done by wave 0, and workgroup barriers separate the stages.  The per-lane LDS footprint (75 KB per
+// 64 samples at hidden (21,21), 140 KB at (43,43)) allows only one or two such sample groups per CU, so without the
+// split three of the four SIMDs would idle and every LDS / scalar-load latency would be exposed.
 // The Jacobian is written as JT[p][n]: for a fixed parameter p the 64 lanes store 64 consecutive doubles
 // (one 512-B coalesced store per parameter per wave) -- no transposition pass is needed, and the Gram kernel
 // consumes exactly this K-contiguous layout.
@@ -25,7 +30,8 @@ using namespace vmcpde;
 
 namespace {
 
-constexpr int JB = 8;  // output block held in registers by the dense-layer loops
+constexpr int JB = 6;  // output block held in registers by the dense-layer loops (width 21 -> 4 blocks -> 4 waves)
+constexpr int MAX_WAVES = 4;
 
 struct Regions {
   // persistent
@@ -95,12 +101,15 @@ struct Ctx {
   double* lds;
   int lanes;
   int lane;
+  int wave, nw;   // this wave's index among the nw waves that share the workgroup's samples
   int jt_f32;   // Jacobian rows are stored as float (BASELINE config 5) instead of double
   const double* __restrict__ th;
   const FlowProgram* __restrict__ fp;
 };
 
 #define LD(u) (c.lds[(u) * c.lanes + c.lane])
+#define SYNC() __syncthreads()
+#define W0 (c.wave == 0)
 
 // one Jacobian entry of this lane's sample: row `row` of the parameter-major buffer (fp64, or fp32 for config 5)
 __device__ __forceinline__ void jt_store(const Ctx& c, void* __restrict__ JT, int64_t ldj, int64_t row, int64_t n, double v) {
@@ -109,12 +118,13 @@ __device__ __forceinline__ void jt_store(const Ctx& c, void* __restrict__ JT, in
 }
 
 // y = tanh-layer(x): z_j = b_j + sum_i W[i][j] a_i (net.py:55-61), with NC Taylor components.
+// Cooperative: the input must be visible to all waves on entry; the caller synchronises before the output is read.
 template <int NC>
 __device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, int uin, int uout, int cs, double scale) {
   const int n_in = L.n_in, n_out = L.n_out;
   const double* __restrict__ W = c.th + L.off_kernel;
   const double* __restrict__ Bv = c.th + L.off_bias;
-  for (int j0 = 0; j0 < n_out; j0 += JB) {
+  for (int j0 = c.wave * JB; j0 < n_out; j0 += c.nw * JB) {     // output blocks round-robin over the waves
     double acc[NC][JB];
 #pragma unroll
     for (int jj = 0; jj < JB; ++jj) {
@@ -156,6 +166,7 @@ __device__ __forceinline__ int mlp_forward(const Ctx& c, const Trafo& T, int uA,
   int cur = uA, nxt = uB;
   for (int k = 0; k < T.n_layers; ++k) {
     dense_layer<NC>(c, T.layer[k], cur, nxt, cs, (k == T.n_layers - 1) ? c.fp->alpha : 1.0);
+    SYNC();
     const int t = cur; cur = nxt; nxt = t;
   }
   return cur;
@@ -164,22 +175,29 @@ __device__ __forceinline__ int mlp_forward(const Ctx& c, const Trafo& T, int uA,
 // One coupling half-step in the forward direction (real -> latent), net.py:86-113, with NC Taylor components.
 template <int NC>
 __device__ __forceinline__ void halfstep_forward(const Ctx& c, const HalfStep& h, const Regions& r, double* lj) {
+  // wave 0 owns the state X and the log-jacobian accumulator lj; the other waves only take part in the MLPs
   const int d = c.fp->dim, cs = r.cs;
-  for (int i = 0; i < h.n_a; ++i)
+  if (W0)
+    for (int i = 0; i < h.n_a; ++i)
 #pragma unroll
-    for (int cc = 0; cc < NC; ++cc) LD(r.A + cc * cs + i) = LD(r.X + cc * d + h.idx_a[i]);
+      for (int cc = 0; cc < NC; ++cc) LD(r.A + cc * cs + i) = LD(r.X + cc * d + h.idx_a[i]);
+  SYNC();
   int us = mlp_forward<NC>(c, h.s, r.A, r.B, cs);
   int ut = 0;
   const int coupling = c.fp->coupling;
   if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) {
-    for (int k = 0; k < h.n_c; ++k)
+    if (W0) {
+      for (int k = 0; k < h.n_c; ++k)
 #pragma unroll
-      for (int cc = 0; cc < NC; ++cc) LD(r.SOUT + cc * d + k) = LD(us + cc * cs + k);
-    for (int i = 0; i < h.n_a; ++i)
+        for (int cc = 0; cc < NC; ++cc) LD(r.SOUT + cc * d + k) = LD(us + cc * cs + k);
+      for (int i = 0; i < h.n_a; ++i)
 #pragma unroll
-      for (int cc = 0; cc < NC; ++cc) LD(r.A + cc * cs + i) = LD(r.X + cc * d + h.idx_a[i]);
+        for (int cc = 0; cc < NC; ++cc) LD(r.A + cc * cs + i) = LD(r.X + cc * d + h.idx_a[i]);
+    }
+    SYNC();
     ut = mlp_forward<NC>(c, h.t, r.A, r.B, cs);
   }
+  if (!W0) return;     // (the next stage starts with a barrier that wave 0 reaches after the update below)
   for (int k = 0; k < h.n_c; ++k) {
     double s[3] = {0, 0, 0}, t[3] = {0, 0, 0}, cv[3] = {0, 0, 0}, y[3] = {0, 0, 0};
     const int ix = h.idx_c[k];
@@ -220,15 +238,21 @@ __device__ __forceinline__ void halfstep_forward(const Ctx& c, const HalfStep& h
 // One coupling half-step in the inverse direction (latent -> real), values only, net.py:121-148.
 __device__ __forceinline__ void halfstep_inverse(const Ctx& c, const HalfStep& h, const Regions& r, double& lj) {
   const int cs = r.cs;
-  for (int i = 0; i < h.n_a; ++i) LD(r.A + i) = LD(r.X + h.idx_a[i]);
+  if (W0)
+    for (int i = 0; i < h.n_a; ++i) LD(r.A + i) = LD(r.X + h.idx_a[i]);
+  SYNC();
   int us = mlp_forward<1>(c, h.s, r.A, r.B, cs);
   int ut = 0;
   const int coupling = c.fp->coupling;
   if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) {
-    for (int k = 0; k < h.n_c; ++k) LD(r.SOUT + k) = LD(us + k);
-    for (int i = 0; i < h.n_a; ++i) LD(r.A + i) = LD(r.X + h.idx_a[i]);
+    if (W0) {
+      for (int k = 0; k < h.n_c; ++k) LD(r.SOUT + k) = LD(us + k);
+      for (int i = 0; i < h.n_a; ++i) LD(r.A + i) = LD(r.X + h.idx_a[i]);
+    }
+    SYNC();
     ut = mlp_forward<1>(c, h.t, r.A, r.B, cs);
   }
+  if (!W0) return;
   for (int k = 0; k < h.n_c; ++k) {
     const int ix = h.idx_c[k];
     const double v = LD(r.X + ix);
@@ -307,23 +331,28 @@ __device__ __forceinline__ void mlp_forward_store(const Ctx& c, const Trafo& T, 
     const bool last = (k == T.n_layers - 1);
     const int out = last ? uOUT : in + L.n_in;
     dense_layer<1>(c, L, in, out, 0, last ? c.fp->alpha : 1.0);
+    SYNC();
     in = out;
   }
 }
 
 // Reverse pass through one SingleTrafo with output cotangent in uW: writes the parameter-gradient rows of this
 // sample into JT (bias: delta_j, kernel: a_i delta_j) and accumulates the input gradient into GAM.
+// Cooperative: every layer is split by INPUT unit i (wave w owns i = w, w+nw, ...): the owner forms
+// eps_i = sum_j W[i][j] delta_j, stores the kernel rows (i, :) of JT, and turns eps_i into the next delta_i; bias rows go
+// round-robin by output block.  On entry OUT/ACT are visible to all waves and uW was written by wave 0.
 __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const Regions& r, int uOUT, int uW,
                                              void* __restrict__ JT, int64_t ldj, int64_t n, bool active) {
   const double alpha = c.fp->alpha;
   const int nl = T.n_layers;
-  {
+  if (W0) {
     const DenseLayer& L = T.layer[nl - 1];
     for (int j = 0; j < L.n_out; ++j) {
       const double th = LD(uOUT + j) / alpha;
       LD(r.DEL0 + j) = LD(uW + j) * alpha * (1.0 - th * th);
     }
   }
+  SYNC();
   int in_off = T.n_in + T.sum_hidden;  // one past the last layer input
   int cur = r.DEL0, nxt = r.DEL1;
   for (int k = nl - 1; k >= 0; --k) {
@@ -332,17 +361,17 @@ __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const
     in_off -= n_in;
     const int uin = r.ACT + in_off;
     const double* __restrict__ W = c.th + L.off_kernel;
-    for (int i = 0; i < n_in; ++i) LD(r.EPS + i) = 0.0;
-    for (int j0 = 0; j0 < n_out; j0 += JB) {
+    for (int i = c.wave; i < n_in; i += c.nw) LD(r.EPS + i) = 0.0;
+    for (int j0 = 0, blk = 0; j0 < n_out; j0 += JB, ++blk) {
       double dl[JB];
 #pragma unroll
       for (int jj = 0; jj < JB; ++jj) dl[jj] = (j0 + jj < n_out) ? LD(cur + j0 + jj) : 0.0;
-      if (JT != nullptr && active) {
+      if (JT != nullptr && active && (blk % c.nw) == c.wave) {
 #pragma unroll
         for (int jj = 0; jj < JB; ++jj)
           if (j0 + jj < n_out) jt_store(c, JT, ldj, L.off_bias + j0 + jj, n, dl[jj]);
       }
-      for (int i = 0; i < n_in; ++i) {
+      for (int i = c.wave; i < n_in; i += c.nw) {
         const double a = LD(uin + i);
         const double* __restrict__ wr = W + i * n_out + j0;
         double e = 0.0;
@@ -360,14 +389,15 @@ __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const
       }
     }
     if (k > 0) {
-      for (int i = 0; i < n_in; ++i) {
+      for (int i = c.wave; i < n_in; i += c.nw) {
         const double a = LD(uin + i);
         LD(nxt + i) = (1.0 - a * a) * LD(r.EPS + i);
       }
       const int t = cur; cur = nxt; nxt = t;
     } else {
-      for (int i = 0; i < n_in; ++i) LD(r.GAM + i) += LD(r.EPS + i);
+      for (int i = c.wave; i < n_in; i += c.nw) LD(r.GAM + i) += LD(r.EPS + i);
     }
+    SYNC();
   }
 }
 
@@ -375,42 +405,50 @@ __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const
 // on exit X holds its INPUT and G = dlogp/d(input).
 __device__ __forceinline__ void halfstep_backward(const Ctx& c, const HalfStep& h, const Regions& r,
                                                   void* __restrict__ JT, int64_t ldj, int64_t n, bool active) {
+  // wave 0 owns X, G, GAM, DW between the cooperative MLP passes (each of which ends with a barrier)
   const int coupling = c.fp->coupling;
-  for (int i = 0; i < h.n_a; ++i) LD(r.GAM + i) = 0.0;
+  if (W0) {
+    for (int i = 0; i < h.n_a; ++i) LD(r.GAM + i) = 0.0;
+    for (int i = 0; i < h.n_a; ++i) LD(r.ACT + i) = LD(r.X + h.idx_a[i]);
+  }
+  SYNC();
   if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) {
     // t enters additively (net.py:94): its output cotangent is G_c itself
-    for (int i = 0; i < h.n_a; ++i) LD(r.ACT + i) = LD(r.X + h.idx_a[i]);
     mlp_forward_store(c, h.t, r.ACT, r.OUTT);
-    for (int k = 0; k < h.n_c; ++k) LD(r.DW + k) = LD(r.G + h.idx_c[k]);
-    mlp_backward(c, h.t, r, r.OUTT, r.DW, JT, ldj, n, active);
+    if (W0)
+      for (int k = 0; k < h.n_c; ++k) LD(r.DW + k) = LD(r.G + h.idx_c[k]);
+    mlp_backward(c, h.t, r, r.OUTT, r.DW, JT, ldj, n, active);     // (starts with wave 0's part, then a barrier)
+    // ACT[0..n_a) still holds the half-step input for the s network
   }
-  for (int i = 0; i < h.n_a; ++i) LD(r.ACT + i) = LD(r.X + h.idx_a[i]);
   mlp_forward_store(c, h.s, r.ACT, r.OUTS);
-  for (int k = 0; k < h.n_c; ++k) {
-    const int ix = h.idx_c[k];
-    const double s = LD(r.OUTS + k);
-    const double y = LD(r.X + ix);
-    const double gk = LD(r.G + ix);
-    double cin, w, gnew;
-    if (coupling == VMCPDE_COUPLING_JAC_EQ_1) {
-      cin = y - s; w = gk; gnew = gk;
-    } else {
-      const double E = exp(s);
-      double ces;  // c * exp(s)
-      if (coupling == VMCPDE_COUPLING_NO_ADD) ces = y;
-      else if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) ces = y - LD(r.OUTT + k);
-      else ces = y - s;
-      cin = ces / E;
-      w = gk * ces + 1.0;                                   // d/ds [ G_c c e^s + s ]
-      if (coupling == VMCPDE_COUPLING_PLAIN) w += gk;       // + G_c d(s)/ds of the additive s (net.py:98)
-      gnew = gk * E;
+  if (W0) {
+    for (int k = 0; k < h.n_c; ++k) {
+      const int ix = h.idx_c[k];
+      const double s = LD(r.OUTS + k);
+      const double y = LD(r.X + ix);
+      const double gk = LD(r.G + ix);
+      double cin, w, gnew;
+      if (coupling == VMCPDE_COUPLING_JAC_EQ_1) {
+        cin = y - s; w = gk; gnew = gk;
+      } else {
+        const double E = exp(s);
+        double ces;  // c * exp(s)
+        if (coupling == VMCPDE_COUPLING_NO_ADD) ces = y;
+        else if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) ces = y - LD(r.OUTT + k);
+        else ces = y - s;
+        cin = ces / E;
+        w = gk * ces + 1.0;                                   // d/ds [ G_c c e^s + s ]
+        if (coupling == VMCPDE_COUPLING_PLAIN) w += gk;       // + G_c d(s)/ds of the additive s (net.py:98)
+        gnew = gk * E;
+      }
+      LD(r.DW + k) = w;
+      LD(r.X + ix) = cin;
+      LD(r.G + ix) = gnew;
     }
-    LD(r.DW + k) = w;
-    LD(r.X + ix) = cin;
-    LD(r.G + ix) = gnew;
   }
   mlp_backward(c, h.s, r, r.OUTS, r.DW, JT, ldj, n, active);
-  for (int i = 0; i < h.n_a; ++i) LD(r.G + h.idx_a[i]) += LD(r.GAM + i);
+  if (W0)
+    for (int i = 0; i < h.n_a; ++i) LD(r.G + h.idx_a[i]) += LD(r.GAM + i);
 }
 
 // Adjoint of the latent log-density: G = dlogp/dz and the latent-parameter rows of JT (L, L_diag, dist_params, mu).
@@ -456,7 +494,7 @@ __device__ __forceinline__ void latent_backward(const Ctx& c, const LatentCache*
   }
 }
 
-__global__ __launch_bounds__(64) void flow_eval_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
+__global__ __launch_bounds__(64 * MAX_WAVES) void flow_eval_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
                                                       const double* __restrict__ th, const double* __restrict__ x,
                                                       int64_t N, const double* __restrict__ dirs, int n_dirs,
                                                       double* __restrict__ logp, double* __restrict__ g,
@@ -466,49 +504,61 @@ __global__ __launch_bounds__(64) void flow_eval_kernel(const FlowProgram* __rest
   Ctx c;
   c.lds = lds;
   c.lanes = lanes;
-  c.lane = threadIdx.x;
+  c.wave = (int)threadIdx.x >> 6;
+  c.nw = (int)blockDim.x >> 6;
   c.th = th;
   c.fp = fp;
   c.jt_f32 = jt_f32;
-  if ((int)threadIdx.x >= lanes) return;  // no barriers are used: one wave per workgroup
+  // lanes beyond `lanes` (narrow workgroups of very wide networks) shadow lane 0: same sample, same LDS slots, same
+  // values, in lockstep with it inside the wave -- they must stay alive for the workgroup barriers
+  const int lane = (int)threadIdx.x & 63;
+  const bool lane_ok = lane < lanes;
+  c.lane = lane_ok ? lane : 0;
   const int d = fp->dim;
-  const int64_t n = (int64_t)blockIdx.x * lanes + threadIdx.x;
-  const bool active = n < N;
-  const int64_t nn = active ? n : (N - 1);
+  const int64_t n = (int64_t)blockIdx.x * lanes + c.lane;
+  const bool active = lane_ok && n < N;
+  const int64_t nn = (n < N) ? n : (N - 1);
 
+  // wave 0 owns the per-sample state and the scalar results; all waves walk the same sequence of stages
   double lp_val = 0.0;
   if (n_dirs > 0 && hv != nullptr) {
     for (int k = 0; k < n_dirs; ++k) {
-      for (int i = 0; i < d; ++i) {
-        LD(r.X + i) = x[nn * d + i];
-        LD(r.X + d + i) = dirs[k * d + i];
-        LD(r.X + 2 * d + i) = 0.0;
-      }
+      if (W0)
+        for (int i = 0; i < d; ++i) {
+          LD(r.X + i) = x[nn * d + i];
+          LD(r.X + d + i) = dirs[k * d + i];
+          LD(r.X + 2 * d + i) = 0.0;
+        }
       double lj[3] = {0, 0, 0}, lp[3];
       for (int s = 0; s < fp->n_half; ++s) halfstep_forward<3>(c, fp->hs[s], r, lj);
-      latent_forward<3>(c, lc, r, r.X, lp);
-      lp_val = lp[0] + lj[0];
-      if (active) hv[n * n_dirs + k] = lp[2] + lj[2];
+      if (W0) {
+        latent_forward<3>(c, lc, r, r.X, lp);
+        lp_val = lp[0] + lj[0];
+        if (active) hv[n * n_dirs + k] = lp[2] + lj[2];
+      }
     }
   } else {
-    for (int i = 0; i < d; ++i) LD(r.X + i) = x[nn * d + i];
+    if (W0)
+      for (int i = 0; i < d; ++i) LD(r.X + i) = x[nn * d + i];
     double lj[1] = {0}, lp[1];
     for (int s = 0; s < fp->n_half; ++s) halfstep_forward<1>(c, fp->hs[s], r, lj);
-    latent_forward<1>(c, lc, r, r.X, lp);
-    lp_val = lp[0] + lj[0];
+    if (W0) {
+      latent_forward<1>(c, lc, r, r.X, lp);
+      lp_val = lp[0] + lj[0];
+    }
   }
-  if (logp != nullptr && active) logp[n] = lp_val;
+  if (logp != nullptr && active && W0) logp[n] = lp_val;
   if (g == nullptr && JT == nullptr) return;
 
   // reverse sweep: X currently holds z
-  latent_backward(c, lc, r, JT, ldj, n, active);
+  if (W0) latent_backward(c, lc, r, JT, ldj, n, active);
   for (int s = fp->n_half - 1; s >= 0; --s) halfstep_backward(c, fp->hs[s], r, JT, ldj, n, active);
-  if (g != nullptr && active)
+  if (g != nullptr && active && W0)
     for (int i = 0; i < d; ++i) g[n * d + i] = LD(r.G + i);
 }
 
 // var_state.py:33 / net.py:214-217: (y, latent(x_in - offset) - log_jac) for either direction.
-__global__ __launch_bounds__(64) void flow_sample_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
+__global__ __launch_bounds__(64 * MAX_WAVES) void flow_sample_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
                                                         const double* __restrict__ th, const double* __restrict__ zin,
                                                         int64_t N, int inv, double* __restrict__ xout,
                                                         double* __restrict__ logp, int lanes, Regions r) {
@@ -516,18 +566,23 @@ __global__ __launch_bounds__(64) void flow_sample_kernel(const FlowProgram* __re
   Ctx c;
   c.lds = lds;
   c.lanes = lanes;
-  c.lane = threadIdx.x;
+  c.wave = (int)threadIdx.x >> 6;
+  c.nw = (int)blockDim.x >> 6;
   c.th = th;
   c.fp = fp;
   c.jt_f32 = 0;
-  if ((int)threadIdx.x >= lanes) return;
+  const int lane = (int)threadIdx.x & 63;
+  const bool lane_ok = lane < lanes;
+  c.lane = lane_ok ? lane : 0;            // see flow_eval_kernel
   const int d = fp->dim;
-  const int64_t n = (int64_t)blockIdx.x * lanes + threadIdx.x;
-  const bool active = n < N;
-  const int64_t nn = active ? n : (N - 1);
-  for (int i = 0; i < d; ++i) LD(r.X + i) = zin[nn * d + i];
-  double lp[1];
-  latent_forward<1>(c, lc, r, r.X, lp);   // density of the INPUT point (net.py:215)
+  const int64_t n = (int64_t)blockIdx.x * lanes + c.lane;
+  const bool active = lane_ok && n < N && W0;
+  const int64_t nn = (n < N) ? n : (N - 1);
+  double lp[1] = {0.0};
+  if (W0) {
+    for (int i = 0; i < d; ++i) LD(r.X + i) = zin[nn * d + i];
+    latent_forward<1>(c, lc, r, r.X, lp);   // density of the INPUT point (net.py:215)
+  }
   double lj = 0.0;
   if (inv) {
     for (int s = fp->n_half - 1; s >= 0; --s) halfstep_inverse(c, fp->hs[s], r, lj);
@@ -665,6 +720,12 @@ __global__ void rhs_kernel(vmcpde_eq_consts c, int d, const double* __restrict__
   eloc[n] = e;
 }
 
+// waves that share one workgroup's samples: one per output block of the widest layer, at most four (one per SIMD)
+int pick_waves(const FlowProgram& fp) {
+  const int blocks = (fp.max_width + JB - 1) / JB;
+  return blocks < 1 ? 1 : (blocks > MAX_WAVES ? MAX_WAVES : blocks);
+}
+
 int pick_lanes(int total_units, int* lds_bytes) {
   // largest power-of-two sample count per wave whose per-lane vectors fit in LDS; prefer two waves per CU
   const int LDS_CU = 160 * 1024;
@@ -713,7 +774,7 @@ extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const doub
   if (bytes > 64 * 1024)
     VMC_CHECK_HIP(hipFuncSetAttribute((const void*)flow_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   const int64_t grid = (n_samples + lanes - 1) / lanes;
-  hipLaunchKernelGGL(flow_eval_kernel, dim3((unsigned)grid), dim3(64), bytes, st, m->dev, m->cache, theta, x, n_samples,
+  hipLaunchKernelGGL(flow_eval_kernel, dim3((unsigned)grid), dim3(64 * pick_waves(m->host)), bytes, st, m->dev, m->cache, theta, x, n_samples,
                      dirs, (hv ? n_dirs : 0), logp, g, hv, JT, ldj, (int)jt_f32, lanes, r);
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
@@ -732,7 +793,7 @@ extern "C" int vmcpde_flow_sample(vmcpde_model* m, const double* theta, const do
   if (bytes > 64 * 1024)
     VMC_CHECK_HIP(hipFuncSetAttribute((const void*)flow_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   const int64_t grid = (n_samples + lanes - 1) / lanes;
-  hipLaunchKernelGGL(flow_sample_kernel, dim3((unsigned)grid), dim3(64), bytes, st, m->dev, m->cache, theta, z, n_samples,
+  hipLaunchKernelGGL(flow_sample_kernel, dim3((unsigned)grid), dim3(64 * pick_waves(m->host)), bytes, st, m->dev, m->cache, theta, z, n_samples,
                      inv, x, logp, lanes, r);
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
