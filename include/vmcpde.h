@@ -136,6 +136,8 @@ int64_t vmcpde_gram_packed_doubles(int32_t P);
 int64_t vmcpde_gram_workspace_bytes(int32_t P, int64_t n_samples);
 /* the Gram ("syrk") contraction, tdvp.py:46-47 / mpi_wrapper.py:21-25 (J13) on fp64 MFMA:
  * packed[tile(i,j)][r][s] = sum_n w_n (JT[i*128+r][n]-c[..]) (JT[j*128+s][n]-c[..]),  j<=i,  w=NULL -> 1.
+ * Diagonal tiles (j == i) define their lower triangle r >= s only; entries above it are unspecified (vmcpde_gram_finalize
+ * mirrors them).
  * w = logp gives SExp (tdvp.py:33,47: rows scaled by w, i.e. weight w^2); w = Etilde gives the SNR Gram (tdvp.py:68-70).
  * jt_f32 != 0: JT holds fp32 values (ldj in elements), widened to fp64 while staging; accumulation stays fp64. */
 int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t P, int64_t n_samples, const double* c, const double* w,

@@ -38,7 +38,7 @@ def _unpack(packed, P):
     t = 0
     for i in range(nb):
         for j in range(i + 1):
-            S[i * 128:(i + 1) * 128, j * 128:(j + 1) * 128] = pk[t]
+            S[i * 128:(i + 1) * 128, j * 128:(j + 1) * 128] = pk[t] if i != j else np.tril(pk[t]) + np.tril(pk[t], -1).T
             if i != j:
                 S[j * 128:(j + 1) * 128, i * 128:(i + 1) * 128] = pk[t].T
             t += 1

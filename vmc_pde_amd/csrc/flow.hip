@@ -6,7 +6,7 @@
 //   variants), net.py:168-182 (INN), net.py:209-217 (INNwProb), net.py:10-36 (Gauss / Student_t),
 //   util.py:21-26 (covariance factor), evolutionEq.py:23-45, 84-119.
 //
-// Execution model (gfx950): ONE SAMPLE PER LANE, and up to four waves per workgroup that COOPERATE on the same 64 samples.
+// Execution model (gfx950): ONE SAMPLE PER LANE, and up to eight waves per workgroup that COOPERATE on the same 64 samples.
 // Every per-sample vector (state, MLP activations, tangents, adjoints) lives in LDS as [unit][lane] (lane-contiguous
 // doubles, so each ds_read_b64/ds_write_b64 is conflict-free) and is shared by the waves of the workgroup; MLP weights
 // are wave-uniform and are read through the scalar cache (s_load) straight from the flat parameter vector; the
@@ -30,8 +30,14 @@ using namespace vmcpde;
 
 namespace {
 
-constexpr int JB = 6;  // output block held in registers by the dense-layer loops (width 21 -> 4 blocks -> 4 waves)
-constexpr int MAX_WAVES = 4;
+#ifndef VMC_FLOW_JB
+#define VMC_FLOW_JB 6
+#endif
+#ifndef VMC_FLOW_MAX_WAVES
+#define VMC_FLOW_MAX_WAVES 8
+#endif
+constexpr int JB = VMC_FLOW_JB;  // output block held in registers by the dense-layer loops (measured: 6 x up-to-8 waves is the best compromise over C2/C3/C4)
+constexpr int MAX_WAVES = VMC_FLOW_MAX_WAVES;
 
 struct Regions {
   // persistent
@@ -720,7 +726,7 @@ __global__ void rhs_kernel(vmcpde_eq_consts c, int d, const double* __restrict__
   eloc[n] = e;
 }
 
-// waves that share one workgroup's samples: one per output block of the widest layer, at most four (one per SIMD)
+// waves that share one workgroup's samples: one per output block of the widest layer, at most MAX_WAVES (two per SIMD)
 int pick_waves(const FlowProgram& fp) {
   const int blocks = (fp.max_width + JB - 1) / JB;
   return blocks < 1 ? 1 : (blocks > MAX_WAVES ? MAX_WAVES : blocks);

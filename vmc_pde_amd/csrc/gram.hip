@@ -194,13 +194,15 @@ __global__ __launch_bounds__(256) void finalize_S_kernel(const double* __restric
       // delta = (global mean) - (shift the Gram kernel used) = rowsum/N + c - c_gram
       const double di = rowsum[gi] * inv_n + (c ? c[gi] : 0.0) - (cg ? cg[gi] : 0.0);
       const double dj = rowsum[gj] * inv_n + (c ? c[gj] : 0.0) - (cg ? cg[gj] : 0.0);
-      v = tile[r * TILE + cidx] * inv_n - di * dj;
+      // diagonal tiles define only their lower triangle (the Gram kernel skips the blocks above it): mirror
+      const double raw = (ti == tj && cidx > r) ? tile[cidx * TILE + r] : tile[r * TILE + cidx];
+      v = raw * inv_n - di * dj;
       S[(int64_t)gi * lds_ + gj] = v;
       if (A2) A2[(int64_t)gi * lda2 + gj] = (gi == gj) ? v + shift * v : v;
     }
     tr[ty + 8 * q][tx] = v;
   }
-  if (ti == tj) return;   // the diagonal tile already holds both triangles (bitwise symmetric: same products, same order)
+  if (ti == tj) return;   // the diagonal tile was written with both triangles above
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; ++q) {

@@ -118,9 +118,10 @@ __device__ __forceinline__ void stage_store(const Staged<TIn>& r, double* __rest
 }
 
 // acc[i][j] += A_tile(64 rows of this wave) * B_tile(64 rows of this wave)^T over K-columns [4*K4A, 4*K4B) of one staged K-step
-template <int K4A, int K4B>
-__device__ __forceinline__ void mma_part(double4_t (&acc)[4][4], const double* __restrict__ lds, int offAs, int offBs,
-                                         int wr, int wc) {
+// LOWER: this wave's quadrant sits on the diagonal of a diagonal tile -- only the 16 x 16 blocks with j <= i are formed.
+template <int K4A, int K4B, bool LOWER>
+__device__ __forceinline__ void mma_part_blocks(double4_t (&acc)[4][4], const double* __restrict__ lds, int offAs, int offBs,
+                                                int wr, int wc) {
   const int lane = threadIdx.x & 63;
   const int lr = lane & 15, lk = lane >> 4;
   const double* __restrict__ ap = lds + offAs + (64 * wr + lr) * LDP + lk;
@@ -135,13 +136,21 @@ __device__ __forceinline__ void mma_part(double4_t (&acc)[4][4], const double* _
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j)
+        if (!LOWER || j <= i) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
   }
 }
 
+// On a diagonal tile (alias) the quadrant above the diagonal is skipped; consumers mirror the lower triangle.
+template <int K4A, int K4B>
+__device__ __forceinline__ void mma_part(double4_t (&acc)[4][4], const double* __restrict__ lds, int offAs, int offBs,
+                                         int wr, int wc, bool alias) {
+  if (!alias || wr >= wc) mma_part_blocks<K4A, K4B, false>(acc, lds, offAs, offBs, wr, wc);
+}
+
 __device__ __forceinline__ void mma_kstep(double4_t (&acc)[4][4], const double* __restrict__ lds, int offAs, int offBs,
-                                          int wr, int wc) {
-  mma_part<0, BK / 4>(acc, lds, offAs, offBs, wr, wc);
+                                          int wr, int wc, bool alias) {
+  mma_part<0, BK / 4>(acc, lds, offAs, offBs, wr, wc, alias);
 }
 
 // Main loop of one tile.  alias: the B tile is the A tile (diagonal tile of a syrk) -> only A is staged.
@@ -208,7 +217,7 @@ __device__ __forceinline__ void tile_mainloop(double4_t (&acc)[4][4], const TIn*
   const unsigned long long tstart = tprev;
 #endif
   for (int64_t s = 0; s + 1 < nfull; ++s, k += BK) {
-    mma_part<0, BK / 8>(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc);
+    mma_part<0, BK / 8>(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc, alias);
     VMC_STAMP(0)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);   // let the short VALU/LDS staging burst win issue slots over the partner's MFMAs (+0.5 % measured)
@@ -225,7 +234,7 @@ __device__ __forceinline__ void tile_mainloop(double4_t (&acc)[4][4], const TIn*
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     VMC_STAMP(1)
-    mma_part<BK / 8, BK / 4>(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc);
+    mma_part<BK / 8, BK / 4>(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc, alias);
     VMC_STAMP(2)
     __syncthreads();
     VMC_STAMP(3)
@@ -244,7 +253,7 @@ __device__ __forceinline__ void tile_mainloop(double4_t (&acc)[4][4], const TIn*
       stage_load<SCALE, true>(ra, tA + k + BK, offA, strideA, SCALE ? scale + k + BK : nullptr, tail);
       if (!alias) stage_load<SCALE, true>(rb, tB + k + BK, offB, strideB, SCALE ? scale + k + BK : nullptr, tail);
     }
-    mma_kstep(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc);
+    mma_kstep(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc, alias);
     if (tail > 0) {
       stage_store<CENTER, SCALE, true>(ra, lds, (cur ^ 1) * 2 * TILE_LDS, SHA, tail);
       if (!alias) stage_store<CENTER, SCALE, true>(rb, lds, (cur ^ 1) * 2 * TILE_LDS + TILE_LDS, SHB, tail);
@@ -253,7 +262,7 @@ __device__ __forceinline__ void tile_mainloop(double4_t (&acc)[4][4], const TIn*
     cur ^= 1;
   }
   if (tail > 0) {
-    mma_kstep(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc);
+    mma_kstep(acc, lds, cur * 2 * TILE_LDS, cur * 2 * TILE_LDS + boff, wr, wc, alias);
     __syncthreads();
   }
 }
@@ -281,6 +290,9 @@ __device__ __forceinline__ void dma_tile(const double* __restrict__ tile_k /* ro
     __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + boff[jj]), (lds_ptr_t)(lds_tile + (wave * 4 + jj) * 8 * BK), 16, 0, 0);
 }
 
+// LOWER: this wave's 64 x 64 quadrant sits on the diagonal of a diagonal tile -- only the 16 x 16 blocks with j <= i are
+// formed (the rest of the tile's upper triangle is never read: consumers mirror the lower one).
+template <bool LOWER>
 __device__ __forceinline__ void mma_kstep_swz(double4_t (&acc)[4][4], const double* __restrict__ lds, int offAs, int offBs, int wr, int wc,
                                               const int (&koff)[BK / 4]) {
   const int lr = threadIdx.x & 15;
@@ -296,11 +308,22 @@ __device__ __forceinline__ void mma_kstep_swz(double4_t (&acc)[4][4], const doub
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j)
+        if (!LOWER || j <= i) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
   }
 }
 
-// lds: 4 * DT doubles.  Same contract as tile_mainloop<false,false>.
+// One K step of this wave's quadrant.  On a diagonal tile (alias) the quadrant above the diagonal is skipped (a quarter of
+// the tile's MFMAs; the freed matrix-pipe slots go to the co-resident workgroup's waves).  Also forming only the lower
+// 16 x 16 blocks of the two quadrants ON the diagonal (LOWER) needs a second copy of the K step, and with two copies hipcc
+// spills ~190 of the 128 accumulator VGPRs' neighbours -- measured 2x slower, so it is not used.
+__device__ __forceinline__ void mma_kstep_sym(double4_t (&acc)[4][4], const double* __restrict__ lds, int offAs, int offBs, int wr, int wc,
+                                              const int (&koff)[BK / 4], bool alias) {
+  if (!alias || wr >= wc) mma_kstep_swz<false>(acc, lds, offAs, offBs, wr, wc, koff);
+}
+
+// lds: 4 * DT doubles.  Same contract as tile_mainloop<false,false>; with alias (diagonal tile) only the lower triangle of
+// the tile (row >= col) is accumulated.
 __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const double* __restrict__ A, int64_t lda, int rowA0,
                                                   const double* __restrict__ B, int64_t ldb, int rowB0, bool alias, int64_t k0,
                                                   int64_t k1, double* __restrict__ lds) {
@@ -351,7 +374,7 @@ __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const 
       __builtin_amdgcn_s_setprio(0);
     }
     VMC_STAMP(0)
-    mma_kstep_swz(acc, lds, cur * 2 * DT, cur * 2 * DT + boff, wr, wc, koff);
+    mma_kstep_sym(acc, lds, cur * 2 * DT, cur * 2 * DT + boff, wr, wc, koff, alias);
     VMC_STAMP(1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     VMC_STAMP(2)
@@ -380,7 +403,7 @@ __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const 
       if (!alias) *reinterpret_cast<double2_t*>(lds + cur * 2 * DT + DT + row * BK + slot * 2) = rb.v[q];
     }
     __syncthreads();
-    mma_kstep_swz(acc, lds, cur * 2 * DT, cur * 2 * DT + boff, wr, wc, koff);
+    mma_kstep_sym(acc, lds, cur * 2 * DT, cur * 2 * DT + boff, wr, wc, koff, alias);
     __syncthreads();
   }
 }
