@@ -7,6 +7,8 @@ from /opt/conda/bin/python3.9 -- the reference code itself is not imported or ex
 Sources (SURVEY.md section 6 / BASELINE.md section 1):
   vmc_fluids/paper_plot/data_diffusion/dim8_Gauss_NsamplesTDVP10000_NsamplesObs10000/infos.hdf5
   vmc_fluids/paper_plot/data_diffusion/dim8_StudentT_nu2_NsamplesTDVP10000_NsamplesObs10000/infos.hdf5
+  vmc_fluids/paper_plot/data_phaseSpace/Wiener/Nsamples10000_T10.0/infos.hdf5      (exact_dyn.py Langevin ensemble, T = 10)
+  vmc_fluids/paper_plot/data_phaseSpace/INN/NsamplesTDVP10000_NsamplesObs10000_Tdifferent/infos.hdf5   (step schedule, diagnostics)
 """
 import os
 
@@ -27,6 +29,18 @@ def main():
         s = dict(times=f["times"][:], entropy=f["entropy"][:], dist_params=f["dist_params"][:, 0], tdvp_error=f["tdvp_error"][:],
                  solver_res=f["solver_res"][:], covar_diag=np.diagonal(f["covar"][:], axis1=1, axis2=2).copy())
     np.savez_compressed(os.path.join(OUT, "published_diffusion_d8_student_t.npz"), **s)
+    # phase space (3 damped oscillators, evolutionEq.py:107-119): the reference's own Langevin ensemble for T = 10 up to t = 5,
+    # every 10th record; and the flow run's step schedule / solver diagnostics (its temperatures differ per oscillator and
+    # are not recorded, so its moments are not used)
+    with h5py.File(REF + "data_phaseSpace/Wiener/Nsamples10000_T10.0/infos.hdf5", "r") as f:
+        sel = slice(0, 501, 10)
+        w = dict(times=f["times"][sel], x1=f["x1"][sel], covar=f["covar"][sel])
+    with h5py.File(REF + "data_phaseSpace/INN/NsamplesTDVP10000_NsamplesObs10000_Tdifferent/infos.hdf5", "r") as f:
+        w.update(inn_times=f["times"][:], inn_tdvp_error=f["tdvp_error"][:], inn_solver_res=f["solver_res"][:],
+                 inn_n_param=np.int64(f["ev"].shape[1]))
+    np.savez_compressed(os.path.join(OUT, "published_phase_space.npz"), **w)
+    print("phase space: wiener", w["times"].shape, "covar diag at t=5", np.diagonal(w["covar"][-1]), "inn steps", w["inn_times"].shape,
+          "tdvp_error median/max", np.median(w["inn_tdvp_error"]), w["inn_tdvp_error"].max())
     for k, v in g.items():
         print("gauss", k, v.shape)
     dt = np.diff(g["times"])

@@ -75,3 +75,70 @@ def test_student_t_diffusion_d8_follows_published_nu():
     assert run["nu"][-1] > 2.5                                                       # 2.00 -> 2.55 over these steps in the published run
     # the ansatz cannot follow this flow exactly: the published TDVP error is 0.22 -> 0.11 over these steps
     assert np.all(run["tdvp_error"] < 2 * ref["tdvp_error"][:n] + 0.02) and np.all(run["tdvp_error"] > 0.4 * ref["tdvp_error"][:n])
+
+
+def _oscillator_moments(times, T, gamma=1.0, m=1.0, omega=1.0, mean0=(1.0, 0.0)):
+    """Exact mean and covariance of one damped, thermally driven oscillator (evolutionEq.py:107-119 with lam = 0) started
+    from N(mean0, I): dm/dt = A m, dC/dt = A C + C A^T + Q, A = [[0, 1/m], [-m w^2, -gamma]], Q = diag(0, 2 m gamma T)."""
+    from scipy.linalg import expm
+    A = np.array([[0.0, 1.0 / m], [-m * omega ** 2, -gamma]])
+    Q = np.diag([0.0, 2.0 * m * gamma * T])
+    # Van Loan: exp([[A, Q], [0, -A^T]] t) gives Phi and the driven part of the covariance in one go
+    M = np.zeros((4, 4))
+    M[:2, :2], M[:2, 2:], M[2:, 2:] = A, Q, -A.T
+    means, covs = [], []
+    for t in times:
+        E = expm(M * t)
+        Phi = E[:2, :2]
+        means.append(Phi @ np.asarray(mean0))
+        covs.append(Phi @ np.eye(2) @ Phi.T + E[:2, 2:] @ Phi.T)
+    return np.asarray(means), np.asarray(covs)
+
+
+def test_phase_space_three_oscillators_matches_exact_moments_and_published_ensemble():
+    """KA-6: the driver's 'harmonicOsc_diff' mode -- d = 6, three damped oscillators in contact with a
+    bath (advection_hamiltonian_wDiss, the equation of BASELINE config C2/C4), 4 blocks x hidden (3,), different_add,
+    P = 411, N = 10 000, Heun with dt = 1e-4 * 1.3^n up to 1e-2, 515 steps to t = 5.  The Gaussian state stays Gaussian,
+    so first and second moments obey closed linear ODEs; the run is compared with them and with the reference's own
+    published Langevin ensemble for T = 10 (exact_dyn.py, 10 000 walkers)."""
+    import vmc_pde_amd as V
+    ref = np.load(os.path.join(GOLD, "published_phase_space.npz"))
+    dim, offset = 6, np.array([1.0, 0.0, 1.0, 0.0, 1.0, 0.0])          # exact_dyn.py:100
+    sampler = V.Sampler(key=1, dim=dim, numChains=30, name="Gauss", mcmc_info={"offset": offset, "bound": 0.25})
+    vs = V.VarState(sampler, dim, 1, 4, network_args={"intmediate": (dim // 2,), "offset": offset, "latentSpaceName": "Gauss", "dim": dim,
+                                                     "different_add": True})
+    assert vs.numParameters == int(ref["inn_n_param"]) == 411          # width of the published `ev` records (KA-7)
+    stepper = V.FixedStepper(timeStep=1e-4, mode="Heun", maxStep=1e-2, increase_fac=1.3)      # main.py:51,113
+    tdvp = V.TDVP(diagonalizeOnDevice=True)
+    eq = V.EvolutionEquation(dim=dim, name="advection_hamiltonian_wDiss")                     # T = 10, gamma = m = omega = 1, lam = 0
+    n_steps = len(ref["inn_times"])
+    t, times, x1, cov, terr = 0.0, [], [], [], []
+    for n in range(n_steps):
+        dp, dt, info = stepper.step(0, tdvp, vs.get_parameters(), evolutionEq=eq, psi=vs, nSamplesTDVP=10000, nSamplesObs=10000,
+                                    normFunction=lambda v, S: v @ S @ v, timings=None, integrals=None)
+        vs.set_parameters(dp)
+        times.append(t)
+        x1.append(info["x1"].cpu().numpy())
+        cov.append(info["covar"].cpu().numpy())
+        terr.append(float(tdvp.tdvp_error))
+        t += dt
+    times, x1, cov = np.asarray(times), np.asarray(x1), np.asarray(cov)
+    assert np.allclose(times, ref["inn_times"], rtol=0, atol=1e-9)     # stepper.py:131 schedule of the published flow run
+    assert np.all(np.isfinite(cov)) and np.all(np.isfinite(terr))
+    # exact moments: every oscillator is the same 2 x 2 problem
+    m_ex, c_ex = _oscillator_moments(times, T=10.0)
+    for o in range(3):
+        sl = slice(2 * o, 2 * o + 2)
+        assert np.abs(x1[:, sl] - m_ex).max() < 0.12, o                 # MC noise of a 10^4-sample mean at variance ~10: 0.03
+        rel = np.abs(cov[:, sl, sl] - c_ex) / np.sqrt(np.einsum("tii,tjj->tij", c_ex, c_ex))
+        assert rel.max() < 0.12, (o, rel.max())                         # published flow-vs-ensemble agreement is ~3 %
+    # different oscillators stay uncorrelated
+    off = cov[-1].copy()
+    for o in range(3):
+        off[2 * o:2 * o + 2, 2 * o:2 * o + 2] = 0.0
+    assert np.abs(off).max() < 0.06 * np.diagonal(cov[-1]).max()
+    # the reference's published Langevin ensemble at its own record times (every 0.1 up to t = 5)
+    idx = [int(np.argmin(np.abs(times - tw))) for tw in ref["times"]]
+    dw = np.abs(np.diagonal(cov[idx], axis1=1, axis2=2) - np.diagonal(ref["covar"], axis1=1, axis2=2))
+    assert (dw / np.diagonal(ref["covar"], axis1=1, axis2=2)).max() < 0.15
+    assert np.abs(x1[idx] - ref["x1"]).max() < 0.2
