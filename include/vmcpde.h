@@ -165,6 +165,11 @@ int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info, void* work
 /* u = (L L^T)^{-1} F with the factor from vmcpde_cholesky. u may alias F. */
 int vmcpde_chol_solve(const double* L, int64_t lda, int32_t P, const double* F, double* u,
                       void* workspace, int64_t workspace_bytes, void* stream);
+/* second half only: u = L^-T y.  Used with the bordered factorisation: the Cholesky of [[A, F], [F^T, beta]] (size P+1,
+ * beta large) carries y = L^-1 F in its last row, so the forward substitution costs no launches of its own; the
+ * workspace may be the one filled by that (P+1)-sized factorisation. */
+int vmcpde_chol_backsolve(const double* L, int64_t lda, int32_t P, const double* y, double* u,
+                          void* workspace, int64_t workspace_bytes, void* stream);
 /* y = A x for symmetric full-storage A (tdvp.py:66,91,93,94 mat-vecs); trans=1 uses A^T (V^T F) */
 int vmcpde_gemv(const double* A, int64_t lda, int32_t rows, int32_t cols, int trans, const double* x, double* y, void* stream);
 /* tdvp.py:82-91: coef_k = invEv_k * regularizer_k * VtF_k with the hard 1e-14 and soft svdTol cut-offs,

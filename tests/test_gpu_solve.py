@@ -98,3 +98,37 @@ def test_gemv_and_pinv_coeffs():
         nat.call("vmcpde_pinv_coeffs", nat.ptr(ev_d), nat.ptr(VtF_d), nat.ptr(snr_d) if use_snr else None, P, 1e-11, 2.0,
                  nat.ptr(coef), nat.stream())
         assert np.allclose(coef.cpu().numpy(), inv * r * VtF, rtol=1e-13, atol=0)
+
+
+@pytest.mark.parametrize("P", [5, 127, 129, 300, 1000])
+def test_bordered_factorisation_carries_the_forward_substitution(P):
+    # Cholesky of [[A, F], [F^T, beta]]: the last row of the factor is y = L^-1 F, so u = L^-T y needs only the back
+    # substitution (vmcpde_chol_backsolve); must agree with factor + vmcpde_chol_solve and with a dense solve
+    Amat = _spd(P, P + 7, cond=1e5)
+    rng = np.random.default_rng(P + 2)
+    F = rng.standard_normal(P)
+    Pp = _pad(P + 1, 128)
+    A = torch.zeros((Pp, Pp), dtype=torch.float64, device=DEV)
+    A[:P, :P] = torch.as_tensor(Amat)
+    A[P, :P] = torch.as_tensor(F)
+    A[P, P] = 1e200
+    need = nat.lib().vmcpde_chol_workspace_bytes(P + 1)
+    ws = torch.empty(need // 8, dtype=torch.float64, device=DEV)
+    info = torch.zeros(1, dtype=torch.int32, device=DEV)
+    nat.call("vmcpde_cholesky", nat.ptr(A), Pp, P + 1, nat.ptr(info), nat.ptr(ws), need, nat.stream())
+    assert int(info.item()) == 0
+    Lref = np.linalg.cholesky(Amat)
+    yref = np.linalg.solve(Lref, F)
+    y = A[P, :P].cpu().numpy()
+    assert np.linalg.norm(y - yref) / np.linalg.norm(yref) < 1e-9
+    u = torch.empty(P, dtype=torch.float64, device=DEV)
+    nat.call("vmcpde_chol_backsolve", nat.ptr(A), Pp, P, nat.ptr(A[P]), nat.ptr(u), nat.ptr(ws), need, nat.stream())
+    uref = np.linalg.solve(Amat, F)
+    assert np.linalg.norm(Amat @ u.cpu().numpy() - F) / np.linalg.norm(F) < 1e-9
+    assert np.linalg.norm(u.cpu().numpy() - uref) / np.linalg.norm(uref) < 1e-7
+    # the two-call path on the same matrix
+    A2, Pp2, ws2, need2, _ = _chol(Amat, P)
+    u2 = torch.empty(P, dtype=torch.float64, device=DEV)
+    F_d = torch.as_tensor(F).to(DEV)
+    nat.call("vmcpde_chol_solve", nat.ptr(A2), Pp2, P, nat.ptr(F_d), nat.ptr(u2), nat.ptr(ws2), need2, nat.stream())
+    assert np.linalg.norm((u - u2).cpu().numpy()) / np.linalg.norm(uref) < 1e-9

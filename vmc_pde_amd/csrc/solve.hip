@@ -646,6 +646,22 @@ extern "C" int vmcpde_chol_solve(const double* L, int64_t lda, int32_t P, const 
   return 0;
 }
 
+extern "C" int vmcpde_chol_backsolve(const double* L, int64_t lda, int32_t P, const double* y, double* u, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+  VMC_REQUIRE(L && y && u && workspace, "vmcpde_chol_backsolve: null argument");
+  VMC_REQUIRE(P >= 1 && lda >= P, "bad shape");
+  VMC_REQUIRE(workspace_bytes >= vmcpde_chol_workspace_bytes(P), "workspace must be the one vmcpde_cholesky filled");
+  hipStream_t st = (hipStream_t)stream;
+  const double* Linv = static_cast<const double*>(workspace);
+  const int nb = (P + NB - 1) / NB;
+  if (u != y) VMC_CHECK_HIP(hipMemcpyAsync(u, y, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, st));
+  // L^T u = y
+  hipLaunchKernelGGL(solve_diag_only, dim3(1), dim3(256), 0, st, u, P, nb - 1, 1, Linv);
+  for (int k = nb - 1; k >= 1; --k) hipLaunchKernelGGL(solve_bwd_step, dim3(k), dim3(256), 0, st, L, lda, P, k, u, Linv);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int vmcpde_gemv(const double* A, int64_t lda, int32_t rows, int32_t cols, int trans, const double* x, double* y,
                            void* stream) {
   VMC_REQUIRE(A && x && y, "vmcpde_gemv: null argument");

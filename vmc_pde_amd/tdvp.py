@@ -28,6 +28,9 @@ from . import global_defs
 from . import mpi_wrapper as mpi
 
 
+_BORDER_PIVOT = 1e200    # corner of the bordered matrix: any value above F^T A^-1 F keeps the last pivot positive
+
+
 def _round_up(v, m):
     return (v + m - 1) // m * m
 
@@ -256,12 +259,22 @@ class TDVP:
         update = torch.empty(P, dtype=global_defs.tReal, device=device)
         with torch.cuda.device(device):
             if self._solver() == "cholesky":
-                need = nat.lib().vmcpde_chol_workspace_bytes(P)
+                A, Ppad = b["A"], b["Ppad"]
+                bordered = P < Ppad          # a spare padded row: factor [[A, F], [F^T, beta]] -> its last row is y = L^-1 F
+                Pf = P + 1 if bordered else P
+                need = nat.lib().vmcpde_chol_workspace_bytes(Pf)
                 if b["chol_ws"] is None or b["chol_ws"].numel() * 8 < need:
                     b["chol_ws"] = torch.empty(need // 8, dtype=global_defs.tReal, device=device)
-                nat.call("vmcpde_cholesky", nat.ptr(b["A"]), b["Ppad"], P, nat.ptr(b["info"]), nat.ptr(b["chol_ws"]), need, nat.stream())
-                nat.call("vmcpde_chol_solve", nat.ptr(b["A"]), b["Ppad"], P, nat.ptr(F), nat.ptr(update), nat.ptr(b["chol_ws"]), need,
-                         nat.stream())
+                if bordered:
+                    A[P, :P].copy_(F)
+                    A[P, P] = _BORDER_PIVOT
+                nat.call("vmcpde_cholesky", nat.ptr(A), Ppad, Pf, nat.ptr(b["info"]), nat.ptr(b["chol_ws"]), need, nat.stream())
+                if bordered:     # the forward substitution rode along with the factorisation (32 dependent launches less)
+                    nat.call("vmcpde_chol_backsolve", nat.ptr(A), Ppad, P, nat.ptr(A[P]), nat.ptr(update), nat.ptr(b["chol_ws"]), need,
+                             nat.stream())
+                else:
+                    nat.call("vmcpde_chol_solve", nat.ptr(A), Ppad, P, nat.ptr(F), nat.ptr(update), nat.ptr(b["chol_ws"]), need,
+                             nat.stream())
                 self.ev = self.V = self.VtF = None
                 self.cholInfo = b["info"]
             else:
