@@ -61,7 +61,7 @@ def build_problem(device, workload="C2", seed=1, jacobian_dtype=torch.float64):
     vs.set_parameters(theta)
     eq = V.EvolutionEquation(dim=dim, name=EQ)
     eq.eqParams[EQ]["params"]["lam"] = LAM
-    tdvp = V.TDVP(diagonalShift=DIAG_SHIFT, solver="cholesky")
+    tdvp = V.TDVP(diagonalShift=DIAG_SHIFT, solver="cholesky", fuseMoments=os.environ.get("VMCPDE_FUSE_MOMENTS", "1") != "0")
     return vs, eq, tdvp, theta
 
 

@@ -51,6 +51,7 @@ class TDVP:
                                   #   kernel's staging burst, which competes with the fp64 MFMAs for issue slots)
                                   # "auto": uncentred once the previous call showed max_p mean_p^2/var_p < 1e3, i.e. the
                                   #   cancellation costs < 3 of fp64's 16 digits; centred otherwise
+    fuseMoments: bool = True      # uncentred path: sum O and sum O (E - cE) ride in the syrk as two appended Jacobian rows
 
     def __post_init__(self):
         self._buf = {}
@@ -137,9 +138,6 @@ class TDVP:
             else:
                 b["c"].copy_(self._c_prev)
                 b["cE"].copy_(self._cE_prev)
-            # pass 2 (tdvp.py:40-45 in shifted form): sum (O - c), sum (O - c)(E - cE); then the syrk (tdvp.py:46)
-            nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, 1 if JT.dtype == torch.float32 else 0, P, n, nat.ptr(e), nat.ptr(b["c"]), nat.ptr(b["cE"]),
-                     nat.ptr(b["rowsum"]), nat.ptr(b["rowdot"]), nat.stream())
             shift_mode = self.gramShift
             if shift_mode == "auto":
                 if self._ratio_event is not None:
@@ -149,8 +147,27 @@ class TDVP:
                     self._uncentred_ok = bool(self._ratio_host[0] < 1e3)
                 shift_mode = "uncentred" if self._uncentred_ok else "centred"
             c_gram = b["c"] if shift_mode == "centred" else None
-            self._gram(b, JT, ldj, P, n, c_gram, None, b["packed"])
+            # pass 2 (tdvp.py:40-45 in shifted form): sum (O - c), sum (O - c)(E - cE); and the syrk (tdvp.py:46).
+            # Uncentred fp64 path with two spare padded rows: E - cE and 1 are appended to the Jacobian as rows P and P+1, so
+            # the syrk's last tile row carries sum_n O (E - cE) and sum_n O and the separate pass over J is not needed
+            # (uncentred mode already requires mean^2/var < 1e3, which also bounds the cancellation in sum O - N c).
+            bordered = (self.fuseMoments and c_gram is None and JT.dtype == global_defs.tReal and JT.shape[0] >= P + 2
+                        and P + 2 <= b["Ppad"])
+            if bordered:
+                torch.sub(e, b["cE"], out=JT[P, :n])
+                JT[P + 1, :n].fill_(1.0)
+            else:
+                nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, 1 if JT.dtype == torch.float32 else 0, P, n, nat.ptr(e), nat.ptr(b["c"]),
+                         nat.ptr(b["cE"]), nat.ptr(b["rowsum"]), nat.ptr(b["rowdot"]), nat.stream())
+            self._gram(b, JT, ldj, P + 2 if bordered else P, n, c_gram, None, b["packed"])
             mpi.allreduce_sum_(b["pack"])            # the one collective of the step (no-op on a single rank)
+            if bordered:
+                nb = b["Ppad"] // nat.GRAM_TILE
+                last = b["packed"].view(-1, nat.GRAM_TILE, nat.GRAM_TILE)[-nb:]          # tiles (nb-1, 0..nb-1)
+                r = P - (nb - 1) * nat.GRAM_TILE
+                # shifted sums the finalize step expects: sum (O - c) and sum (O - c)(E - cE), over all ranks
+                torch.sub(last[:, r + 1, :].reshape(-1)[:P], b["c"] * Ntot, out=b["rowsum"])
+                torch.sub(last[:, r, :].reshape(-1)[:P], b["c"] * (b["sums"][0] - Ntot * b["cE"][0]), out=b["rowdot"])
             use_chol = self._solver() == "cholesky"
             if use_chol and b["A"] is None:
                 b["A"] = torch.zeros((b["Ppad"], b["Ppad"]), dtype=global_defs.tReal, device=device)
