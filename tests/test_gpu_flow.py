@@ -218,3 +218,16 @@ def test_rhs_advection_paper_time_dependent():
         E_o, _, _ = O.EvolutionEquationOracle(2, "advection_paper")(vo, x, t)
         E_p, _, _ = V.EvolutionEquation(dim=2, name="advection_paper")(vs, x, t)
         assert rel_err(E_p, E_o) < 1e-11
+
+
+def test_ka3_density_is_normalised_on_the_reference_grid():
+    # main.py:100-105 / var_state.py:88-91: integral of exp(logp) over the reference's regular grid (same spacing 0.1), for an active flow (every coupling
+    # variant changes the density, none may change its mass)
+    import vmc_pde_amd as V
+    from vmc_pde_amd import grid as G
+    for coupling in ("no_add", "different_add", "jac_eq_1", "plain"):
+        spec = make_spec(2, 3, (4,), coupling=coupling, offset=[0.3, -0.2], seed=5)
+        th = random_theta(spec, 5, out_scale=0.02, latent_scale=0.2)
+        vs = make_varstate(spec, th)
+        grid = G.Grid(np.array([30.0, 30.0]), 600, sym=True)     # the multiplicative variants spread mass beyond +-10
+        assert abs(float(vs.integrate(grid)) - 1.0) < 1e-5, coupling
