@@ -56,6 +56,7 @@ struct Regions {
   int Y, Q; // whitened residual y = U^-1 r and q = U^-T y (d each)
   int cs;   // component stride of A/B = widest layer
   int total;
+  int wgt;  // doubles of the workgroup-shared weight stage behind the per-lane vectors (kernel + bias of one layer)
 };
 
 // values-only passes (flow_sample): state, two single-component MLP buffers, the s stash and the latent line
@@ -70,6 +71,7 @@ Regions make_regions_values(const FlowProgram& fp) {
   r.SOUT = u; u += d;
   r.LAT = u; u += d;
   r.total = u;
+  r.wgt = W * W + W;
   return r;
 }
 
@@ -100,11 +102,13 @@ Regions make_regions(const FlowProgram& fp) {
   r.Y = u; u += d;
   r.Q = u; u += d;
   r.total = (u > end_taylor) ? u : end_taylor;
+  r.wgt = W * W + W;
   return r;
 }
 
 struct Ctx {
   double* lds;
+  double* wl;     // weight stage: kernel [n_in][n_out] then bias [n_out] of the layer being evaluated
   int lanes;
   int lane;
   int wave, nw;   // this wave's index among the nw waves that share the workgroup's samples
@@ -123,13 +127,23 @@ __device__ __forceinline__ void jt_store(const Ctx& c, void* __restrict__ JT, in
   else static_cast<double*>(JT)[row * ldj + n] = v;
 }
 
+// Copy one layer's kernel and bias from the flat parameter vector into the workgroup's weight stage (all threads; the caller
+// synchronises).  The layer loops then read weights as LDS broadcasts: in-order returns that hipcc can pipeline against the
+// per-lane LDS reads, where scalar loads (out-of-order, 33 KB of weights against a 16 KB scalar cache) forced a full
+// lgkmcnt(0) stall of several hundred cycles per input unit.
+__device__ __forceinline__ void stage_weights(const Ctx& c, const DenseLayer& L) {
+  const int nk = L.n_in * L.n_out;
+  for (int idx = threadIdx.x; idx < nk + L.n_out; idx += blockDim.x)
+    c.wl[idx] = c.th[(idx < nk) ? (L.off_kernel + idx) : (L.off_bias + idx - nk)];
+}
+
 // y = tanh-layer(x): z_j = b_j + sum_i W[i][j] a_i (net.py:55-61), with NC Taylor components.
 // Cooperative: the input must be visible to all waves on entry; the caller synchronises before the output is read.
 template <int NC>
 __device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, int uin, int uout, int cs, double scale) {
   const int n_in = L.n_in, n_out = L.n_out;
-  const double* __restrict__ W = c.th + L.off_kernel;
-  const double* __restrict__ Bv = c.th + L.off_bias;
+  const double* __restrict__ W = c.wl;                  // staged by the caller (stage_weights + barrier)
+  const double* __restrict__ Bv = c.wl + n_in * n_out;
   for (int j0 = c.wave * JB; j0 < n_out; j0 += c.nw * JB) {     // output blocks round-robin over the waves
     double acc[NC][JB];
 #pragma unroll
@@ -138,6 +152,7 @@ __device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, i
 #pragma unroll
       for (int cc = 1; cc < NC; ++cc) acc[cc][jj] = 0.0;
     }
+#pragma unroll 1
     for (int i = 0; i < n_in; ++i) {
       double a[NC];
 #pragma unroll
@@ -171,6 +186,8 @@ template <int NC>
 __device__ __forceinline__ int mlp_forward(const Ctx& c, const Trafo& T, int uA, int uB, int cs) {
   int cur = uA, nxt = uB;
   for (int k = 0; k < T.n_layers; ++k) {
+    stage_weights(c, T.layer[k]);
+    SYNC();
     dense_layer<NC>(c, T.layer[k], cur, nxt, cs, (k == T.n_layers - 1) ? c.fp->alpha : 1.0);
     SYNC();
     const int t = cur; cur = nxt; nxt = t;
@@ -336,6 +353,8 @@ __device__ __forceinline__ void mlp_forward_store(const Ctx& c, const Trafo& T, 
     const DenseLayer& L = T.layer[k];
     const bool last = (k == T.n_layers - 1);
     const int out = last ? uOUT : in + L.n_in;
+    stage_weights(c, L);
+    SYNC();
     dense_layer<1>(c, L, in, out, 0, last ? c.fp->alpha : 1.0);
     SYNC();
     in = out;
@@ -358,7 +377,6 @@ __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const
       LD(r.DEL0 + j) = LD(uW + j) * alpha * (1.0 - th * th);
     }
   }
-  SYNC();
   int in_off = T.n_in + T.sum_hidden;  // one past the last layer input
   int cur = r.DEL0, nxt = r.DEL1;
   for (int k = nl - 1; k >= 0; --k) {
@@ -366,7 +384,9 @@ __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const
     const int n_in = L.n_in, n_out = L.n_out;
     in_off -= n_in;
     const int uin = r.ACT + in_off;
-    const double* __restrict__ W = c.th + L.off_kernel;
+    stage_weights(c, L);
+    SYNC();                                   // also publishes wave 0's DEL0 (first layer) / the previous layer's deltas
+    const double* __restrict__ W = c.wl;
     for (int i = c.wave; i < n_in; i += c.nw) LD(r.EPS + i) = 0.0;
     for (int j0 = 0, blk = 0; j0 < n_out; j0 += JB, ++blk) {
       double dl[JB];
@@ -500,7 +520,7 @@ __device__ __forceinline__ void latent_backward(const Ctx& c, const LatentCache*
   }
 }
 
-__global__ __launch_bounds__(64 * MAX_WAVES) void flow_eval_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
+__global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_eval_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
                                                       const double* __restrict__ th, const double* __restrict__ x,
                                                       int64_t N, const double* __restrict__ dirs, int n_dirs,
                                                       double* __restrict__ logp, double* __restrict__ g,
@@ -509,6 +529,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void flow_eval_kernel(const FlowPro
   extern __shared__ double lds[];
   Ctx c;
   c.lds = lds;
+  c.wl = lds + (size_t)r.total * lanes;
   c.lanes = lanes;
   c.wave = (int)threadIdx.x >> 6;
   c.nw = (int)blockDim.x >> 6;
@@ -564,13 +585,14 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void flow_eval_kernel(const FlowPro
 }
 
 // var_state.py:33 / net.py:214-217: (y, latent(x_in - offset) - log_jac) for either direction.
-__global__ __launch_bounds__(64 * MAX_WAVES) void flow_sample_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
+__global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_sample_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
                                                         const double* __restrict__ th, const double* __restrict__ zin,
                                                         int64_t N, int inv, double* __restrict__ xout,
                                                         double* __restrict__ logp, int lanes, Regions r) {
   extern __shared__ double lds[];
   Ctx c;
   c.lds = lds;
+  c.wl = lds + (size_t)r.total * lanes;
   c.lanes = lanes;
   c.wave = (int)threadIdx.x >> 6;
   c.nw = (int)blockDim.x >> 6;
@@ -732,13 +754,24 @@ int pick_waves(const FlowProgram& fp) {
   return blocks < 1 ? 1 : (blocks > MAX_WAVES ? MAX_WAVES : blocks);
 }
 
-int pick_lanes(int total_units, int* lds_bytes) {
-  // largest power-of-two sample count per wave whose per-lane vectors fit in LDS; prefer two waves per CU
-  const int LDS_CU = 160 * 1024;
-  int lanes = 64;
-  while (lanes > 8 && (int64_t)total_units * lanes * 8 > LDS_CU / 2) lanes >>= 1;
-  while (lanes > 1 && (int64_t)total_units * lanes * 8 > LDS_CU) lanes >>= 1;
-  *lds_bytes = total_units * lanes * 8;
+int pick_lanes(int total_units, int wgt_doubles, int waves, int* lds_bytes) {
+  // samples per workgroup (a power of two <= 64): the choice that keeps most samples in flight per CU, counting how many
+  // workgroups fit in the 160 KB of LDS (per-lane vectors + the shared weight stage) and in the 16 waves per CU the
+  // kernels' 128-VGPR budget allows; ties go to the wider workgroup (fewer half-empty waves).  Measured at hidden (43,43):
+  // 64 lanes x 1 workgroup 2.9 ms, 32 x 1 5.0 ms, 16 x 3 6.2 ms.
+  const int64_t LDS_CU = 160 * 1024, fixed = (int64_t)wgt_doubles * 8;
+  const int max_wg = (16 / waves) > 0 ? (16 / waves) : 1;
+  int lanes = 1;
+  int64_t best = 0;
+  for (int l = 64; l >= 1; l >>= 1) {
+    const int64_t bytes = (int64_t)total_units * l * 8 + fixed;
+    if (bytes > LDS_CU) continue;
+    int64_t wg = LDS_CU / bytes;
+    if (wg > max_wg) wg = max_wg;
+    if (l * wg > best) { best = l * wg; lanes = l; }
+  }
+  if (const char* e = getenv("VMCPDE_FLOW_LANES")) lanes = atoi(e);   // tuning knob
+  *lds_bytes = (int)((int64_t)total_units * lanes * 8 + fixed);
   return lanes;
 }
 
@@ -749,7 +782,7 @@ extern "C" int vmcpde_flow_eval_config(const vmcpde_model* m, int n_dirs, int* l
   (void)n_dirs;
   Regions r = make_regions(m->host);
   int bytes = 0;
-  int l = pick_lanes(r.total, &bytes);
+  int l = pick_lanes(r.total, r.wgt, pick_waves(m->host), &bytes);
   if (lanes) *lanes = l;
   if (lds_bytes) *lds_bytes = bytes;
   return 0;
@@ -775,7 +808,7 @@ extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const doub
   if (int rc = vmcpde_prepare_latent_internal(m, theta, st)) return rc;
   Regions r = make_regions(m->host);
   int bytes = 0;
-  const int lanes = pick_lanes(r.total, &bytes);
+  const int lanes = pick_lanes(r.total, r.wgt, pick_waves(m->host), &bytes);
   VMC_REQUIRE(bytes <= 160 * 1024, "network too wide for the LDS-resident flow kernel (%d B per sample lane)", r.total * 8);
   if (bytes > 64 * 1024)
     VMC_CHECK_HIP(hipFuncSetAttribute((const void*)flow_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -794,7 +827,7 @@ extern "C" int vmcpde_flow_sample(vmcpde_model* m, const double* theta, const do
   if (int rc = vmcpde_prepare_latent_internal(m, theta, st)) return rc;
   Regions r = make_regions_values(m->host);
   int bytes = 0;
-  const int lanes = pick_lanes(r.total, &bytes);
+  const int lanes = pick_lanes(r.total, r.wgt, pick_waves(m->host), &bytes);
   VMC_REQUIRE(bytes <= 160 * 1024, "network too wide for the LDS-resident flow kernel");
   if (bytes > 64 * 1024)
     VMC_CHECK_HIP(hipFuncSetAttribute((const void*)flow_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
