@@ -82,7 +82,8 @@ def test_flow_and_rhs_against_committed_vectors(case):
         # S is rank deficient: the update is compared in the S-norm
         du = upd.cpu() - torch.as_tensor(GOLD[f"{pre}/update"])
         assert float(torch.linalg.norm(tp.S0.cpu() @ du)) < 1e-8 * np.linalg.norm(GOLD[f"{pre}/F0"]), name
-        assert abs(float(tp.tdvp_error) - float(GOLD[f"{pre}/tdvp_error"])) < 1e-7, name
+        # tdvp_error = 1 - F^T S^+ F / <E^2> feels the eigenvalues that sit on the soft cut-off (round-off level, H2)
+        assert abs(float(tp.tdvp_error) - float(GOLD[f"{pre}/tdvp_error"])) < 1e-6, name
 
 
 def test_heun_step_against_committed_vector():

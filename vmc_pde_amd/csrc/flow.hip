@@ -127,6 +127,40 @@ __device__ __forceinline__ void jt_store(const Ctx& c, void* __restrict__ JT, in
   else static_cast<double*>(JT)[row * ldj + n] = v;
 }
 
+// tanh with absolute error ~2e-16 and no lane-divergent branches (ocml's tanh costs about as much as a 21 x 6 block of the
+// layer product and takes both of its branches in most waves): t = exp(-2|x|) by range reduction + degree-13 Taylor
+// (|r| <= ln2/2: remainder 4e-18), tanh|x| = (1 - t)/(1 + t) with v_rcp_f64 refined by two Newton steps and a residual
+// correction.  Activations are consumed linearly downstream, so absolute (not relative) accuracy near 0 is what matters.
+__device__ __forceinline__ double fast_tanh(double x) {
+  const double ax = fmin(fabs(x), 20.0);                   // tanh(20) = 1 - 3e-18
+  const double y = -2.0 * ax;
+  const double n = rint(y * 1.4426950408889634074);
+  double r = fma(n, -6.93147180369123816490e-01, y);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;                       // 1/13!
+  p = fma(p, r, 2.08767569878681e-09);                     // 1/12!
+  p = fma(p, r, 2.505210838544172e-08);
+  p = fma(p, r, 2.755731922398589e-07);
+  p = fma(p, r, 2.755731922398589e-06);
+  p = fma(p, r, 2.48015873015873e-05);
+  p = fma(p, r, 1.984126984126984e-04);
+  p = fma(p, r, 1.388888888888889e-03);
+  p = fma(p, r, 8.333333333333333e-03);
+  p = fma(p, r, 4.166666666666666e-02);
+  p = fma(p, r, 1.666666666666667e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const double t = ldexp(p, (int)n);
+  const double num = 1.0 - t, den = 1.0 + t;
+  double q = __builtin_amdgcn_rcp(den);
+  q = fma(fma(-den, q, 1.0), q, q);
+  q = fma(fma(-den, q, 1.0), q, q);
+  double h = num * q;
+  h = fma(fma(-den, h, num), q, h);
+  return copysign(h, x);
+}
+
 // Copy one layer's kernel and bias from the flat parameter vector into the workgroup's weight stage (all threads; the caller
 // synchronises).  The layer loops then read weights as LDS broadcasts: in-order returns that hipcc can pipeline against the
 // per-lane LDS reads, where scalar loads (out-of-order, 33 KB of weights against a 16 KB scalar cache) forced a full
@@ -168,7 +202,11 @@ __device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, i
 #pragma unroll
     for (int jj = 0; jj < JB; ++jj) {
       if (j0 + jj < n_out) {
+        #ifdef VMC_FLOW_OCML_TANH
         const double h = tanh(acc[0][jj]);
+#else
+        const double h = fast_tanh(acc[0][jj]);
+#endif
         LD(uout + j0 + jj) = scale * h;
         if (NC == 3) {
           const double hp = 1.0 - h * h;
