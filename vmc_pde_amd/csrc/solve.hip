@@ -115,12 +115,21 @@ __device__ __forceinline__ int factor_inverse_32(double* a, int j0, double* scr,
     double m = v[j] * scale;                         // L[i][j] (junk for rows above j: never stored) | x_j of column q
     m = (lane == j) ? d : m;                         // lane j keeps the diagonal entry itself (also when the pivot is NaN)
     v[j] = m;
+    // groups of 8: all broadcasts of a group first (16 distinct SGPRs), then its FMAs -- left to itself hipcc chains
+    // readlane, readlane, s_nop, fma through one SGPR pair, which serialises the whole column
 #pragma unroll
-    for (int k = j + 1; k < SB; ++k) {
-      v[k] = fma(-m, readlane_f64(m, k), v[k]);      // scalar operand L[k][j] from lower lane k
-      if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    for (int g = 0; g < SB / 8; ++g) {
+      if (8 * g + 7 > j) {                                     // (compile-time after unrolling)
+        double lk[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lk[q] = (8 * g + q > j) ? readlane_f64(m, 8 * g + q) : 0.0;   // L[k][j] from lower lane k
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (8 * g + q > j) v[8 * g + q] = fma(-m, lk[q], v[8 * g + q]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
   // lower lanes: L[i][c] for c <= i -> a[j0+i][j0+c];  upper lanes: X[k][q] for k >= q -> a[j0+q][j0+k+1].
   // Everything else (junk above the diagonal, exact zeros that would land on L) is steered to a dump slot by address
