@@ -24,6 +24,14 @@ using namespace vmcpde;
 
 namespace {
 
+#ifndef VMC_GRAM_BKD
+#define VMC_GRAM_BKD 16
+#endif
+// K step of the DMA-staged Gram kernel: 16 -> 64 KiB of LDS, two workgroups per CU; 8 -> 32 KiB and <= 168 VGPRs, three.
+// Measured equal (18.7 ms both on the same box): the kernel sits on the chip's power-managed fp64 MFMA rate, not on issue
+// slots, so the smaller split count and workspace of 16 win.
+constexpr int GRAM_BKD = VMC_GRAM_BKD;
+
 struct GramPlan {
   int nb;          // row blocks of 128
   int ntiles;      // nb(nb+1)/2
@@ -31,14 +39,14 @@ struct GramPlan {
   int64_t chunk;   // samples per split (multiple of BK)
 };
 
-GramPlan make_plan(int P, int64_t N) {
+GramPlan make_plan(int P, int64_t N, int slots /* resident workgroups: 256 CUs x 2 (register-staged) or x 3 (DMA) */) {
   GramPlan g;
   g.nb = (P + TILE - 1) / TILE;
   g.ntiles = (int)tri_count(g.nb);
-  // aim at >= 8 rounds of the 512 resident workgroup slots (256 CUs x 2) but keep each unit >= 64 K-steps so
+  // aim at >= 8 rounds of the resident workgroup slots but keep each unit >= 64 K-steps so
   // prologue/epilogue stay negligible; among the next few split factors take the one whose last round is fullest
   const int64_t ksteps = (N + BK - 1) / BK;
-  int64_t want = (8 * 512 + g.ntiles - 1) / g.ntiles;
+  int64_t want = (8 * (int64_t)slots + g.ntiles - 1) / g.ntiles;
   int64_t maxsplit = ksteps / 64;
   if (maxsplit < 1) maxsplit = 1;
   int64_t ns = want < maxsplit ? want : maxsplit;
@@ -48,7 +56,7 @@ GramPlan make_plan(int P, int64_t N) {
     double best = 1e30;
     int64_t pick = ns;
     for (int64_t c = ns; c <= ns + 4 && c <= maxsplit && c <= 64; ++c) {
-      const double rounds = (double)(g.ntiles * c) / 512.0;
+      const double rounds = (double)(g.ntiles * c) / (double)slots;
       const double waste = (double)(int64_t)(rounds + 0.999999) / rounds;   // ceil(rounds) / rounds
       if (waste < best - 1e-9) { best = waste; pick = c; }
     }
@@ -62,29 +70,34 @@ GramPlan make_plan(int P, int64_t N) {
   return g;
 }
 
+// XCD-aware mapping of a workgroup to its (sample split, tile) unit.  Workgroups are dealt round-robin over the 8 XCDs
+// (blockIdx % 8 share an L2) and started in blockIdx order, so slot = blockIdx / 8 is "time".  order 1 (default): all XCDs
+// sweep the SAME sample chunk at the same time -- slot -> (split, local tile), XCD x owns a contiguous run of that split's
+// tiles -- which keeps the chip-wide working set at one or two chunks of J (Infinity-Cache sized) and neighbouring tiles
+// (shared operand panels) on one L2.  order 0: one sample chunk per XCD (eight chunks in flight).
+__device__ __forceinline__ bool gram_unit(int ntiles, int nsplit, int total_units, int units_per_xcd, int order, int& split, int& tile) {
+  if (order == 1) {
+    const int slot = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
+    split = slot / units_per_xcd;                      // units_per_xcd = tiles per XCD per split here
+    tile = xcd * units_per_xcd + (slot - split * units_per_xcd);
+    return tile < ntiles && split < nsplit;
+  }
+  const int unit = (int)(blockIdx.x & 7) * units_per_xcd + (int)(blockIdx.x >> 3);
+  if (unit >= total_units) return false;
+  split = unit / ntiles;
+  tile = unit - split * ntiles;
+  return true;
+}
+
+// centred / weighted / fp32-operand variants: register-staged main loop, two workgroups per CU
 template <bool CENTER, bool SCALE, typename TIn>
 __global__ __launch_bounds__(256, 2) void gram_kernel(const TIn* __restrict__ JT, int64_t ldj, int P, int64_t N,
                                                       const double* __restrict__ c, const double* __restrict__ scale,
                                                       int ntiles, int nsplit, int64_t chunk, int total_units,
                                                       int units_per_xcd, int order, double* __restrict__ out) {
   extern __shared__ double lds[];
-  // XCD-aware order.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2) and started in
-  // blockIdx order, so slot = blockIdx / 8 is "time".  order 1 (default): all XCDs sweep the SAME sample chunk at the
-  // same time -- slot -> (split, local tile), XCD x owns a contiguous run of that split's tiles -- which keeps the
-  // chip-wide working set at one or two chunks of J (Infinity-Cache sized) and neighbouring tiles (shared operand
-  // panels) on one L2.  order 0: one sample chunk per XCD (eight chunks in flight).
   int split, tile;
-  if (order == 1) {
-    const int slot = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
-    split = slot / units_per_xcd;                      // units_per_xcd = tiles per XCD per split here
-    tile = xcd * units_per_xcd + (slot - split * units_per_xcd);
-    if (tile >= ntiles || split >= nsplit) return;
-  } else {
-    const int unit = (int)(blockIdx.x & 7) * units_per_xcd + (int)(blockIdx.x >> 3);
-    if (unit >= total_units) return;
-    split = unit / ntiles;
-    tile = unit - split * ntiles;
-  }
+  if (!gram_unit(ntiles, nsplit, total_units, units_per_xcd, order, split, tile)) return;
   int ti, tj;
   tri_decode(tile, ti, tj);
   const int64_t k0 = (int64_t)split * chunk;
@@ -97,10 +110,27 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const TIn* __restrict__ JT
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  if constexpr (!CENTER && !SCALE && sizeof(TIn) == 8)
-    tile_mainloop_dma(acc, JT, ldj, rowA0, JT, ldj, rowB0, ti == tj, k0, k1, lds);
-  else
-    tile_mainloop<CENTER, SCALE, TIn>(acc, JT, ldj, rowA0, JT, ldj, rowB0, ti == tj, k0, k1, c, rowsA, c, rowsB, scale, lds);
+  tile_mainloop<CENTER, SCALE, TIn>(acc, JT, ldj, rowA0, JT, ldj, rowB0, ti == tj, k0, k1, c, rowsA, c, rowsB, scale, lds);
+  tile_store(acc, out + ((int64_t)split * ntiles + tile) * (TILE * TILE));
+}
+
+// the steady-state variant (fp64, uncentred, unweighted): DMA-staged main loop
+__global__ __launch_bounds__(256, GRAM_BKD == 8 ? 3 : 2) void gram_dma_kernel(const double* __restrict__ JT, int64_t ldj, int64_t N, int ntiles, int nsplit,
+                                                          int64_t chunk, int total_units, int units_per_xcd, int order,
+                                                          double* __restrict__ out) {
+  extern __shared__ double lds[];
+  int split, tile;
+  if (!gram_unit(ntiles, nsplit, total_units, units_per_xcd, order, split, tile)) return;
+  int ti, tj;
+  tri_decode(tile, ti, tj);
+  const int64_t k0 = (int64_t)split * chunk;
+  const int64_t k1 = (k0 + chunk < N) ? (k0 + chunk) : N;
+  double4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  tile_mainloop_dma<GRAM_BKD>(acc, JT, ldj, ti * TILE, JT, ldj, tj * TILE, ti == tj, k0, k1, lds);
   tile_store(acc, out + ((int64_t)split * ntiles + tile) * (TILE * TILE));
 }
 
@@ -269,10 +299,13 @@ extern "C" int64_t vmcpde_gram_packed_doubles(int32_t P) {
   return tri_count(nb) * TILE * TILE;
 }
 
+constexpr int SLOTS_STAGED = 512, SLOTS_DMA = (GRAM_BKD == 8) ? 768 : 512;
+
 extern "C" int64_t vmcpde_gram_workspace_bytes(int32_t P, int64_t n_samples) {
   if (P <= 0 || n_samples <= 0) return 0;
-  GramPlan g = make_plan(P, n_samples);
-  return (int64_t)g.nsplit * g.ntiles * TILE * TILE * (int64_t)sizeof(double);
+  const GramPlan a = make_plan(P, n_samples, SLOTS_STAGED), b = make_plan(P, n_samples, SLOTS_DMA);   // either variant may run
+  const int ns = a.nsplit > b.nsplit ? a.nsplit : b.nsplit;
+  return (int64_t)ns * a.ntiles * TILE * TILE * (int64_t)sizeof(double);
 }
 
 extern "C" int vmcpde_eloc_stats(const double* eloc, int64_t n_samples, double* sums, void* stream) {
@@ -302,7 +335,8 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
   VMC_REQUIRE(P >= 1 && n_samples >= 1, "bad shape");
   VMC_REQUIRE(ldj >= n_samples && (ldj % 2) == 0 && ldj < (1 << 22), "ldj must be even, >= n_samples and < 2^22");
   VMC_REQUIRE((reinterpret_cast<uintptr_t>(JT) & 15) == 0, "JT must be 16-byte aligned");
-  GramPlan g = make_plan(P, n_samples);
+  const bool dma = !jt_f32 && !c && !w;       // the steady-state variant
+  GramPlan g = make_plan(P, n_samples, dma ? SLOTS_DMA : SLOTS_STAGED);
   const int64_t need = (int64_t)g.nsplit * g.ntiles * TILE * TILE * (int64_t)sizeof(double);
   double* out = packed;
   if (g.nsplit > 1) {
@@ -335,7 +369,16 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
     else if (w) VMC_LAUNCH_GRAM(false, true, T);      \
     else VMC_LAUNCH_GRAM(false, false, T);            \
   } while (0)
-  if (jt_f32) VMC_LAUNCH_GRAM_T(float);
+  if (dma) {
+    static const size_t dma_lds = 4 * DmaGeom<GRAM_BKD>::DT * sizeof(double) + lds_pad;
+    static bool dma_attr = false;
+    if (!dma_attr && dma_lds > 64 * 1024) {
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds));
+      dma_attr = true;
+    }
+    hipLaunchKernelGGL(gram_dma_kernel, dim3(grid), dim3(256), dma_lds, st, static_cast<const double*>(JT), ldj, n_samples, g.ntiles,
+                       g.nsplit, g.chunk, total, per_xcd, order, out);
+  } else if (jt_f32) VMC_LAUNCH_GRAM_T(float);
   else VMC_LAUNCH_GRAM_T(double);
 #undef VMC_LAUNCH_GRAM_T
 #undef VMC_LAUNCH_GRAM

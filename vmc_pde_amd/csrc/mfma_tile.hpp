@@ -275,86 +275,103 @@ __device__ __forceinline__ void tile_mainloop(double4_t (&acc)[4][4], const TIn*
 // LDS image: unpadded rows of 16 doubles; the eight 16-B pairs of a row are XOR-swizzled with f(row) = (row>>1)&7, applied
 // on the per-lane SOURCE address (the DMA destination is lane-linear) and again on the fragment reads, which makes the 16
 // rows x 2 columns of a ds_read_b64 half-wave hit 32 distinct bank pairs.
-constexpr int DT = TILE * BK;                       // doubles per operand tile (16 KiB)
-constexpr size_t TILE_DMA_LDS_BYTES = 4 * DT * sizeof(double);
+// The DMA path is templated on its own K-step BKD (doubles per row of the LDS image):
+//   BKD = 16: rows of 128 B, 64 KiB per workgroup -> two workgroups per CU   (the Cholesky's K = 128 updates)
+//   BKD =  8: rows of  64 B, 32 KiB per workgroup -> three workgroups per CU (VGPR-bound; the Gram kernel): a third wave per
+//             SIMD fills the matrix-pipe slots the other two leave while they issue DMA pieces or wait at a barrier.
+template <int BKD> struct DmaGeom {
+  static constexpr int DT = TILE * BKD;                       // doubles per operand tile
+  static constexpr int PAIRS = BKD / 2;                       // 16-B pairs per row (8 or 4)
+  static constexpr int ROWS_PER_PIECE = 64 / PAIRS;           // rows one 1-KiB wave-instruction covers (8 or 16)
+  static constexpr int PIECES = TILE / ROWS_PER_PIECE / 4;    // pieces per wave per operand tile (4 or 2)
+  // XOR swizzle of the pair index: rows whose images share banks (128-B rows: r, r+2, ..; 64-B rows: r, r+4, ..) get
+  // different pair slots, so the 16 rows x 2 columns of a ds_read_b64 half-wave hit 32 distinct bank pairs
+  __device__ static constexpr int f(int row) { return BKD == 16 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+};
+constexpr int DT = DmaGeom<16>::DT;
+constexpr size_t TILE_DMA_LDS_BYTES = 4 * DT * sizeof(double);           // BKD = 16
+constexpr size_t TILE_DMA8_LDS_BYTES = 4 * DmaGeom<8>::DT * sizeof(double);
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-// issue the four pieces (32 rows) this wave owns of one 128 x 16 operand tile
-__device__ __forceinline__ void dma_tile(const double* __restrict__ tile_k /* row-block base + k */, const uint32_t (&boff)[4],
+// issue the pieces this wave owns of one 128 x BKD operand tile
+template <int BKD>
+__device__ __forceinline__ void dma_tile(const double* __restrict__ tile_k /* row-block base + k */, const uint32_t (&boff)[DmaGeom<BKD>::PIECES],
                                          double* __restrict__ lds_tile, int wave) {
+  using G = DmaGeom<BKD>;
   const char* __restrict__ base = reinterpret_cast<const char*>(tile_k);
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj)
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + boff[jj]), (lds_ptr_t)(lds_tile + (wave * 4 + jj) * 8 * BK), 16, 0, 0);
+  for (int jj = 0; jj < G::PIECES; ++jj)
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + boff[jj]), (lds_ptr_t)(lds_tile + (wave * G::PIECES + jj) * G::ROWS_PER_PIECE * BKD), 16, 0, 0);
 }
 
-// LOWER: this wave's 64 x 64 quadrant sits on the diagonal of a diagonal tile -- only the 16 x 16 blocks with j <= i are
-// formed (the rest of the tile's upper triangle is never read: consumers mirror the lower one).
-template <bool LOWER>
+template <int BKD>
 __device__ __forceinline__ void mma_kstep_swz(double4_t (&acc)[4][4], const double* __restrict__ lds, int offAs, int offBs, int wr, int wc,
-                                              const int (&koff)[BK / 4]) {
+                                              const int (&koff)[BKD / 4]) {
   const int lr = threadIdx.x & 15;
-  const double* __restrict__ ap = lds + offAs + (64 * wr + lr) * BK;
-  const double* __restrict__ bp = lds + offBs + (64 * wc + lr) * BK;
+  const double* __restrict__ ap = lds + offAs + (64 * wr + lr) * BKD;
+  const double* __restrict__ bp = lds + offBs + (64 * wc + lr) * BKD;
 #pragma unroll
-  for (int k4 = 0; k4 < BK / 4; ++k4) {
+  for (int k4 = 0; k4 < BKD / 4; ++k4) {
     double a[4], b[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = ap[16 * i * BK + koff[k4]];
+    for (int i = 0; i < 4; ++i) a[i] = ap[16 * i * BKD + koff[k4]];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = bp[16 * j * BK + koff[k4]];
+    for (int j = 0; j < 4; ++j) b[j] = bp[16 * j * BKD + koff[k4]];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (!LOWER || j <= i) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
   }
 }
 
 // One K step of this wave's quadrant.  On a diagonal tile (alias) the quadrant above the diagonal is skipped (a quarter of
-// the tile's MFMAs; the freed matrix-pipe slots go to the co-resident workgroup's waves).  Also forming only the lower
-// 16 x 16 blocks of the two quadrants ON the diagonal (LOWER) needs a second copy of the K step, and with two copies hipcc
-// spills ~190 of the 128 accumulator VGPRs' neighbours -- measured 2x slower, so it is not used.
+// the tile's MFMAs; the freed matrix-pipe slots go to the co-resident workgroups' waves).  Also forming only the lower
+// 16 x 16 blocks of the two quadrants ON the diagonal needs a second copy of the K step, and with two copies hipcc spills
+// ~190 VGPRs around the 128 accumulator registers -- measured 2x slower, so it is not done.
+template <int BKD>
 __device__ __forceinline__ void mma_kstep_sym(double4_t (&acc)[4][4], const double* __restrict__ lds, int offAs, int offBs, int wr, int wc,
-                                              const int (&koff)[BK / 4], bool alias) {
-  if (!alias || wr >= wc) mma_kstep_swz<false>(acc, lds, offAs, offBs, wr, wc, koff);
+                                              const int (&koff)[BKD / 4], bool alias) {
+  if (!alias || wr >= wc) mma_kstep_swz<BKD>(acc, lds, offAs, offBs, wr, wc, koff);
 }
 
-// lds: 4 * DT doubles.  Same contract as tile_mainloop<false,false>; with alias (diagonal tile) only the lower triangle of
-// the tile (row >= col) is accumulated.
+// lds: 4 * DmaGeom<BKD>::DT doubles.  Same contract as tile_mainloop<false,false>; with alias (diagonal tile) only the lower
+// triangle of the tile (row >= col) is accumulated.
+template <int BKD>
 __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const double* __restrict__ A, int64_t lda, int rowA0,
                                                   const double* __restrict__ B, int64_t ldb, int rowB0, bool alias, int64_t k0,
                                                   int64_t k1, double* __restrict__ lds) {
+  using G = DmaGeom<BKD>;
+  constexpr int DTB = G::DT;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), wr = wave >> 1, wc = wave & 1;
   const double* __restrict__ tA = A + (int64_t)rowA0 * lda;
   const double* __restrict__ tB = B + (int64_t)rowB0 * ldb;
-  // per-lane source byte offsets of this wave's four pieces: piece j covers rows 8j..8j+7, lane -> (row 8j + lane/8, slot lane%8)
-  uint32_t offA[4], offB[4];
+  // per-lane source byte offsets of this wave's pieces: lane -> (row in piece = lane / PAIRS, slot = lane % PAIRS)
+  uint32_t offA[G::PIECES], offB[G::PIECES];
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int row = (wave * 4 + jj) * 8 + (lane >> 3);
-    const int pair = (lane & 7) ^ ((row >> 1) & 7);
+  for (int jj = 0; jj < G::PIECES; ++jj) {
+    const int row = (wave * G::PIECES + jj) * G::ROWS_PER_PIECE + lane / G::PAIRS;
+    const int pair = (lane % G::PAIRS) ^ G::f(row);
     offA[jj] = ((uint32_t)row * (uint32_t)lda + (uint32_t)pair * 2u) * 8u;
     offB[jj] = ((uint32_t)row * (uint32_t)ldb + (uint32_t)pair * 2u) * 8u;
   }
-  // fragment read offsets inside a row: element k = 4*k4 + lane/16 sits at pair (k/2) ^ f(row), f = (lane&15)/2 for every row block
-  int koff[BK / 4];
+  // fragment read offsets inside a row: element k = 4*k4 + lane/16 sits at pair (k/2) ^ f(row); f depends on lane&15 only
+  int koff[BKD / 4];
   {
-    const int lk = lane >> 4, f = ((lane & 15) >> 1) & 7;
+    const int lk = lane >> 4, f = G::f(lane & 15);
 #pragma unroll
-    for (int k4 = 0; k4 < BK / 4; ++k4) koff[k4] = (((2 * k4 + (lk >> 1)) ^ f) << 1) + (lk & 1);
+    for (int k4 = 0; k4 < BKD / 4; ++k4) koff[k4] = (((2 * k4 + (lk >> 1)) ^ f) << 1) + (lk & 1);
   }
-  const int boff = alias ? 0 : DT;
-  const int64_t nfull = (k1 - k0) / BK;
-  const int64_t tail = (k1 - k0) - nfull * BK;
+  const int boff = alias ? 0 : DTB;
+  const int64_t nfull = (k1 - k0) / BKD;
+  const int64_t tail = (k1 - k0) - nfull * BKD;
   int cur = 0;
   int64_t k = k0;
   if (nfull > 0) {
-    dma_tile(tA + k, offA, lds, wave);
-    if (!alias) dma_tile(tB + k, offB, lds + DT, wave);
+    dma_tile<BKD>(tA + k, offA, lds, wave);
+    if (!alias) dma_tile<BKD>(tB + k, offB, lds + DTB, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -363,18 +380,18 @@ __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const 
   unsigned long long tprev = stamp();
   const unsigned long long tstart = tprev;
 #endif
-  for (int64_t s = 0; s < nfull; ++s, k += BK) {
+  for (int64_t s = 0; s < nfull; ++s, k += BKD) {
     if (s + 1 < nfull) {   // the other buffer was last read before the barrier that closed the previous iteration
-      // raised priority: with the co-resident wave streaming fp64 MFMAs each of these eight instructions otherwise waits
+      // raised priority: with the co-resident waves streaming fp64 MFMAs each of these instructions otherwise waits
       // ~250 cycles for an issue slot (measured with in-kernel stamps; +1 % end to end).  Slotting the pieces between this
       // wave's own MFMA groups instead was 6 % SLOWER.
       __builtin_amdgcn_s_setprio(2);
-      dma_tile(tA + k + BK, offA, lds + (cur ^ 1) * 2 * DT, wave);
-      if (!alias) dma_tile(tB + k + BK, offB, lds + (cur ^ 1) * 2 * DT + DT, wave);
+      dma_tile<BKD>(tA + k + BKD, offA, lds + (cur ^ 1) * 2 * DTB, wave);
+      if (!alias) dma_tile<BKD>(tB + k + BKD, offB, lds + (cur ^ 1) * 2 * DTB + DTB, wave);
       __builtin_amdgcn_s_setprio(0);
     }
     VMC_STAMP(0)
-    mma_kstep_sym(acc, lds, cur * 2 * DT, cur * 2 * DT + boff, wr, wc, koff, alias);
+    mma_kstep_sym<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff, alias);
     VMC_STAMP(1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     VMC_STAMP(2)
@@ -389,21 +406,23 @@ __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const 
     o[0] = seg[0]; o[1] = seg[1]; o[2] = seg[2]; o[3] = seg[3]; o[4] = (unsigned long long)nfull; o[5] = tprev - tstart; o[6] = 0; o[7] = 0;
   }
 #endif
-  if (tail > 0) {   // ragged last step (N not a multiple of 16): masked register staging into the same swizzled image
-    Staged<double> ra, rb;
-    const uint32_t oA = (uint32_t)(t >> 3) * (uint32_t)lda + (uint32_t)(t & 7) * 2u, sA = 32u * (uint32_t)lda;
-    const uint32_t oB = (uint32_t)(t >> 3) * (uint32_t)ldb + (uint32_t)(t & 7) * 2u, sB = 32u * (uint32_t)ldb;
-    stage_load<false, true>(ra, tA + k, oA, sA, nullptr, tail);
-    if (!alias) stage_load<false, true>(rb, tB + k, oB, sB, nullptr, tail);
+  if (tail > 0) {   // ragged last step (N not a multiple of BKD): masked loads through registers into the same swizzled image
+    constexpr int PER_THREAD = TILE * G::PAIRS / 256;      // pairs per thread (4 or 2)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = q * 32 + (t >> 3);
-      const int slot = (t & 7) ^ ((row >> 1) & 7);
-      *reinterpret_cast<double2_t*>(lds + cur * 2 * DT + row * BK + slot * 2) = ra.v[q];
-      if (!alias) *reinterpret_cast<double2_t*>(lds + cur * 2 * DT + DT + row * BK + slot * 2) = rb.v[q];
+    for (int q = 0; q < PER_THREAD; ++q) {
+      const int idx = t + 256 * q, row = idx / G::PAIRS, pr = idx % G::PAIRS;
+      const int kk = 2 * pr;
+      const double* __restrict__ pa = tA + (int64_t)row * lda + k + kk;
+      double2_t va = {(kk < tail) ? pa[0] : 0.0, (kk + 1 < tail) ? pa[1] : 0.0};
+      *reinterpret_cast<double2_t*>(lds + cur * 2 * DTB + row * BKD + ((pr ^ G::f(row)) << 1)) = va;
+      if (!alias) {
+        const double* __restrict__ pb = tB + (int64_t)row * ldb + k + kk;
+        double2_t vb = {(kk < tail) ? pb[0] : 0.0, (kk + 1 < tail) ? pb[1] : 0.0};
+        *reinterpret_cast<double2_t*>(lds + cur * 2 * DTB + DTB + row * BKD + ((pr ^ G::f(row)) << 1)) = vb;
+      }
     }
     __syncthreads();
-    mma_kstep_sym(acc, lds, cur * 2 * DT, cur * 2 * DT + boff, wr, wc, koff, alias);
+    mma_kstep_sym<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff, alias);
     __syncthreads();
   }
 }

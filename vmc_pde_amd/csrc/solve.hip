@@ -391,7 +391,7 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int64_t lda, i
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  tile_mainloop_dma(acc, A + k0, lda, rowA0, A + k0, lda, rowB0, ti == tj, 0, n, lds);
+  tile_mainloop_dma<16>(acc, A + k0, lda, rowA0, A + k0, lda, rowB0, ti == tj, 0, n, lds);
   tile_store_global(acc, A + (int64_t)rowA0 * lda + rowB0, lda, rowsA, rowsB, 1);
 }
 
