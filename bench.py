@@ -46,7 +46,9 @@ WORKLOADS = {
                desc="C4: 6-D Fokker-Planck (three damped oscillators), coupling flow d=6 x 4 blocks x hidden (19,19), 32768 samples per GPU"),
 }
 DIAG_SHIFT = 1e-6
+F32BLOCKS_DIAG_SHIFT = 1e-4     # --jacobian f32blocks only (vmc_pde_amd.tdvp.F32_BLOCK_MIN_SHIFT)
 PEAK_F64_MFMA_TFLOPS = 78.6     # AMD MI355X spec, fp64 matrix (dense); the guide has no measured f64 MFMA figure
+PEAK_F32_MFMA_TFLOPS = 157.3    # fp32 matrix (MI355X_MICROARCH.md: 157.3 spec / 155 measured) -- only for --jacobian f32blocks
 OUT_SCALE = 0.1                 # output kernels U(-0.1, 0.1) (the reference's 1e-5 makes J nearly degenerate)
 
 
@@ -140,8 +142,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="BASELINE config (default C2, the headline)")
     ap.add_argument("--samples", type=int, default=0, help="samples per rank (default: the workload's)")
-    ap.add_argument("--jacobian", default="f64", choices=["f64", "f32"],
-                    help="storage type of the per-sample Jacobian (f32 = BASELINE config 5; S and F are accumulated in fp64 either way)")
+    ap.add_argument("--jacobian", default="f64", choices=["f64", "f32", "f32blocks"],
+                    help="storage type of the per-sample Jacobian (f32 = BASELINE config 5: fp32 storage, fp64 products and sums; "
+                         "f32blocks: fp32 MFMA sums over blocks of 128 samples, fp64 across blocks)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,7 +169,10 @@ def main():
     from vmc_pde_amd import mpi_wrapper as mpi
     if not args.samples:
         args.samples = WORKLOADS[args.workload]["n_samp"]
-    vs, eq, tdvp, theta = build_problem(device, args.workload, jacobian_dtype=torch.float32 if args.jacobian == "f32" else torch.float64)
+    vs, eq, tdvp, theta = build_problem(device, args.workload, jacobian_dtype=torch.float64 if args.jacobian == "f64" else torch.float32)
+    if args.jacobian == "f32blocks":     # fp32 accumulation inside 128-sample blocks is not exactly PSD: needs the stronger shift
+        tdvp.f32BlockGram = True
+        tdvp.diagonalShift = F32BLOCKS_DIAG_SHIFT
     P = vs.numParameters
     n_total = args.samples * world
     kwargs = dict(evolutionEq=eq, psi=vs, nSamplesTDVP=n_total, nSamplesObs=n_total, timings=None, observables=False)
@@ -221,6 +227,7 @@ def main():
     peak_meas = measure_mfma_peak(device)
 
     if rank == 0:
+        peak_spec = PEAK_F32_MFMA_TFLOPS if args.jacobian == "f32blocks" else PEAK_F64_MFMA_TFLOPS
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "gram_pmc_traffic.json")
         if os.path.exists(pmc) and args.workload == "C2" and args.jacobian == "f64" and args.samples == N_SAMP:
@@ -236,14 +243,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64" if args.jacobian == "f64" else "f64 accumulate, f32 Jacobian storage (BASELINE config 5)", "data": "synthetic",
+            "dtype": {"f64": "f64", "f32": "f64 accumulate, f32 Jacobian storage (BASELINE config 5)",
+                      "f32blocks": "f32 Jacobian, f32 MFMA sums over 128-sample blocks, f64 across blocks (BASELINE config 5, fast variant)"}[args.jacobian], "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload]["desc"],
-                       "n_param": P, "n_samp_per_gpu": args.samples, "n_samp_total": n_total, "solver": "cholesky", "gram_operands": (("uncentred+DMA" if args.jacobian == "f64" else "uncentred, fp32 widened in staging") if tdvp._uncentred_ok else "centred in staging"),
+                       "n_param": P, "n_samp_per_gpu": args.samples, "n_samp_total": n_total, "solver": "cholesky", "gram_operands": ({"f64": "uncentred+DMA", "f32": "uncentred, fp32 widened in staging", "f32blocks": "uncentred+DMA, fp32 MFMA blocks"}[args.jacobian] if tdvp._uncentred_ok else "centred in staging"),
                        "mean2_over_var_max": ratio,
-                       "diagonal_shift": DIAG_SHIFT, "solver_residual": resid, "parallelism": f"dp{world} (samples sharded, one all-reduce of (S,F) per step)"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": "gram_kernel (fp64 MFMA syrk, + split-K reduce)", "ms_per_launch": gram_ms,
+                       "diagonal_shift": float(tdvp.diagonalShift), "solver_residual": resid, "parallelism": f"dp{world} (samples sharded, one all-reduce of (S,F) per step)"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak_spec, "unit": "TFLOP/s",
+                         "frac": achieved / peak_spec, "traffic": traffic,
+                         "kernel": ("gram_f32_kernel (fp32 MFMA block sums, fp64 across blocks, + split-K reduce)" if args.jacobian == "f32blocks"
+                                    else "gram_kernel (fp64 MFMA syrk, + split-K reduce)"), "ms_per_launch": gram_ms,
                          "algorithmic_flops_per_launch": flops, "measured_mfma_f64_peak": peak_meas,
                          "frac_of_measured_peak": achieved / peak_meas if peak_meas > 0 else None},
             "stages_ms": stage_ms, "heun_step_ms": heun_ms,

@@ -95,6 +95,31 @@ def test_gram_fp32_operand_equals_fp64_path_on_fp32_values(P, N):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("P,N", [(129, 17), (256, 64), (411, 1000), (640, 4099), (1000, 16384)])
+def test_gram_f32_blocks_variant(P, N):
+    """jt_f32 = 2: fp32 MFMA sums over blocks of <= 128 samples, fp64 across blocks.  (a) On small integers every partial sum is
+    exact in fp32, so the result must equal the integer Gram bit for bit -- any slip in the fp32 fragment / C-D maps, the
+    sample-pair packing or the tail masking shows up; (b) on real data it agrees with the fp64 kernel on the same fp32
+    values to ~1e-7 (asserted 1e-6 = the config-5 tolerance for S)."""
+    rng = np.random.default_rng(P + 5 * N)
+    Ppad, ldj = _pad(P, 128), _pad(N, 16)
+    Ji = rng.integers(-3, 4, size=(N, P)).astype(np.float32)
+    JT32 = torch.zeros((Ppad, ldj), dtype=torch.float32, device=DEV)
+    JT32[:P, :N] = torch.as_tensor(Ji.T)
+    S = _unpack(_gram(JT32, ldj, P, N, f32=2), P)
+    assert np.array_equal(S, Ji.astype(np.float64).T @ Ji.astype(np.float64))
+    Jr = rng.standard_normal((N, P)).astype(np.float32) + 0.3
+    JT32[:P, :N] = torch.as_tensor(Jr.T)
+    S2 = _unpack(_gram(JT32, ldj, P, N, f32=2), P)
+    S1 = _unpack(_gram(JT32, ldj, P, N, f32=1), P)
+    rel = np.linalg.norm(S2 - S1) / np.linalg.norm(S1)
+    assert rel < 1e-6 and np.array_equal(S2, S2.T)
+    assert rel > 0            # (it really is the fp32-block path)
+    # centred / weighted requests fall back to the widening kernel
+    c = torch.as_tensor(Jr.astype(np.float64).mean(0)).to(DEV)
+    assert torch.equal(_gram(JT32, ldj, P, N, c=c, f32=2), _gram(JT32, ldj, P, N, c=c, f32=1))
+
+
 def test_gram_weighted_is_SExp_form():
     # tdvp.py:33,47: (logp*O)^T (logp*O)
     P, N = 200, 777

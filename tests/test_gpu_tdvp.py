@@ -272,3 +272,40 @@ def test_fp32_jacobian_storage_config5(case):
         # (b) same rounding on both sides
         assert rel_err(tp.S0, t32.S0) < 1e-11 and rel_err(tp.F0, t32.F0) < 1e-10
         assert float(torch.linalg.norm(to.S0 @ (upd_p.cpu() - upd_o32)) / nF) < 1e-8
+
+
+def test_fp32_block_gram_config5_fast_variant():
+    """Config 5 with the fp32-MFMA block sums (TDVP(f32BlockGram=True)): same tolerances as the widening variant -- S, F 1e-6,
+    update 1e-5 in the S-norm at svdTol = 1e-8 -- against the fp64 oracle."""
+    import vmc_pde_amd as V
+    dim, depth, hidden, latent, coupling, eq, N = CASES[2]
+    N = 2048
+    spec, th, nrm, chi2, eo, ep = _problem(dim, depth, hidden, latent, coupling, eq, N, lam=0.1)
+    z = O.latent_from_normals(spec, th, nrm, chi2)
+    vo = O.VarStateOracle(spec, th)
+    to = O.TDVPOracle(svdTol=1e-8)
+    upd_o, _ = to.rhs(th, 0.2, vo, eo, z)
+    vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()), jacobian_dtype=torch.float32)
+    tp = V.TDVP(solver="eigh", svdTol=1e-8, f32BlockGram=True, gramShift="uncentred")
+    upd_p, _ = tp(th.cuda(), 0.2, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None)
+    assert rel_err(tp.S0, to.S0) < 1e-6 and rel_err(tp.F0, to.F0) < 1e-6
+    assert float(torch.linalg.norm(to.S0 @ (upd_p.cpu() - upd_o)) / torch.linalg.norm(to.F0)) < 1e-5
+    tw = V.TDVP(solver="eigh", svdTol=1e-8, gramShift="uncentred")           # widening variant on the same Jacobian
+    tw(th.cuda(), 0.2, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None)
+    assert 0 < rel_err(tp.S0, tw.S0) < 1e-6
+
+
+def test_fp32_block_gram_refuses_small_shift_with_cholesky():
+    import vmc_pde_amd as V
+    dim, depth, hidden, latent, coupling, eq, N = CASES[1]
+    spec, th, nrm, chi2, eo, ep = _problem(dim, depth, hidden, latent, coupling, eq, N, lam=0.1)
+    z = O.latent_from_normals(spec, th, nrm, chi2)
+    vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()), jacobian_dtype=torch.float32)
+    with pytest.raises(ValueError, match="f32BlockGram needs diagonalShift"):
+        V.TDVP(diagonalShift=1e-6, f32BlockGram=True, gramShift="uncentred")(th.cuda(), 0.2, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None)
+    tp = V.TDVP(diagonalShift=1e-4, f32BlockGram=True, gramShift="uncentred")
+    upd, _ = tp(th.cuda(), 0.2, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None)
+    tw = V.TDVP(diagonalShift=1e-4, gramShift="uncentred")
+    upd_w, _ = tw(th.cuda(), 0.2, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None)
+    assert torch.isfinite(upd).all() and int(tp.cholInfo.item()) == int(tw.cholInfo.item())
+    assert float(torch.linalg.norm(tw.S0 @ (upd - upd_w)) / torch.linalg.norm(tw.F0)) < 1e-3

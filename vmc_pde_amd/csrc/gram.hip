@@ -134,6 +134,28 @@ __global__ __launch_bounds__(256, GRAM_BKD == 8 ? 3 : 2) void gram_dma_kernel(co
   tile_store(acc, out + ((int64_t)split * ntiles + tile) * (TILE * TILE));
 }
 
+// BASELINE config 5, fast variant ("f32 blocks"): fp32 Jacobian, products summed in fp32 by v_mfma_f32_16x16x4_f32 over blocks of
+// <= 128 samples, block sums accumulated in fp64.  The fp32 buffer is viewed as an array of sample PAIRS (8 bytes), which makes
+// the DMA staging, the swizzled LDS image and the fragment reads those of the fp64 kernel; N2, chunk2 and ldj2 are in pairs.
+__global__ __launch_bounds__(256, 2) void gram_f32_kernel(const double* __restrict__ JT2, int64_t ldj2, int64_t N2, int ntiles, int nsplit,
+                                                          int64_t chunk2, int total_units, int units_per_xcd, int order,
+                                                          double* __restrict__ out) {
+  extern __shared__ double lds[];
+  int split, tile;
+  if (!gram_unit(ntiles, nsplit, total_units, units_per_xcd, order, split, tile)) return;
+  int ti, tj;
+  tri_decode(tile, ti, tj);
+  const int64_t k0 = (int64_t)split * chunk2;
+  const int64_t k1 = (k0 + chunk2 < N2) ? (k0 + chunk2) : N2;
+  double4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  tile_mainloop_dma<16, true>(acc, JT2, ldj2, ti * TILE, JT2, ldj2, tj * TILE, ti == tj, k0, k1, lds);
+  tile_store_f32map(acc, out + ((int64_t)split * ntiles + tile) * (TILE * TILE));
+}
+
 // packed[tile][e] = sum_split slabs[split][tile][e]   (fixed order -> deterministic)
 __global__ void reduce_splits_kernel(const double* __restrict__ slabs, int nsplit, int64_t per_split, double* __restrict__ packed) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
@@ -303,8 +325,10 @@ constexpr int SLOTS_STAGED = 512, SLOTS_DMA = (GRAM_BKD == 8) ? 768 : 512;
 
 extern "C" int64_t vmcpde_gram_workspace_bytes(int32_t P, int64_t n_samples) {
   if (P <= 0 || n_samples <= 0) return 0;
-  const GramPlan a = make_plan(P, n_samples, SLOTS_STAGED), b = make_plan(P, n_samples, SLOTS_DMA);   // either variant may run
-  const int ns = a.nsplit > b.nsplit ? a.nsplit : b.nsplit;
+  // any variant may run (register-staged, DMA, fp32 blocks over sample pairs)
+  const GramPlan a = make_plan(P, n_samples, SLOTS_STAGED), b = make_plan(P, n_samples, SLOTS_DMA), c = make_plan(P, (n_samples + 1) / 2, SLOTS_STAGED);
+  int ns = a.nsplit > b.nsplit ? a.nsplit : b.nsplit;
+  if (c.nsplit > ns) ns = c.nsplit;
   return (int64_t)ns * a.ntiles * TILE * TILE * (int64_t)sizeof(double);
 }
 
@@ -336,7 +360,10 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
   VMC_REQUIRE(ldj >= n_samples && (ldj % 2) == 0 && ldj < (1 << 22), "ldj must be even, >= n_samples and < 2^22");
   VMC_REQUIRE((reinterpret_cast<uintptr_t>(JT) & 15) == 0, "JT must be 16-byte aligned");
   const bool dma = !jt_f32 && !c && !w;       // the steady-state variant
-  GramPlan g = make_plan(P, n_samples, dma ? SLOTS_DMA : SLOTS_STAGED);
+  const bool f32blocks = jt_f32 == 2 && !c && !w;   // fp32 MFMA block sums (centred / weighted requests fall back to widening)
+  VMC_REQUIRE(!f32blocks || (ldj % 4) == 0, "jt_f32 = 2 needs ldj to be a multiple of 4 (16-byte rows)");
+  // in pairs of samples for the fp32-block variant (an odd N relies on the zero padding of the rows)
+  GramPlan g = f32blocks ? make_plan(P, (n_samples + 1) / 2, SLOTS_STAGED) : make_plan(P, n_samples, dma ? SLOTS_DMA : SLOTS_STAGED);
   const int64_t need = (int64_t)g.nsplit * g.ntiles * TILE * TILE * (int64_t)sizeof(double);
   double* out = packed;
   if (g.nsplit > 1) {
@@ -369,7 +396,15 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
     else if (w) VMC_LAUNCH_GRAM(false, true, T);      \
     else VMC_LAUNCH_GRAM(false, false, T);            \
   } while (0)
-  if (dma) {
+  if (f32blocks) {
+    static bool f32_attr = false;
+    if (!f32_attr) {
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_DMA_LDS_BYTES));
+      f32_attr = true;
+    }
+    hipLaunchKernelGGL(gram_f32_kernel, dim3(grid), dim3(256), TILE_DMA_LDS_BYTES, st, static_cast<const double*>(JT), ldj / 2,
+                       (n_samples + 1) / 2, g.ntiles, g.nsplit, g.chunk, total, per_xcd, order, out);
+  } else if (dma) {
     static const size_t dma_lds = 4 * DmaGeom<GRAM_BKD>::DT * sizeof(double) + lds_pad;
     static bool dma_attr = false;
     if (!dma_attr && dma_lds > 64 * 1024) {

@@ -326,6 +326,46 @@ __device__ __forceinline__ void mma_kstep_swz(double4_t (&acc)[4][4], const doub
   }
 }
 
+// fp32 variant (BASELINE config 5, "f32 blocks"): the LDS image holds fp32 values, two per 8-byte slot, so the same swizzled
+// ds_read_b64 fragment reads deliver a float pair per lane and every slot feeds TWO v_mfma_f32_16x16x4_f32 (32 cycles each:
+// the same 64 matrix-pipe cycles as one fp64 MFMA, for twice the samples).  Which sample lands in which MFMA k index is
+// irrelevant for a contraction as long as A and B agree, and they do: both use slot d = 4*k4 + lane/16 -> samples 2d, 2d+1.
+typedef float float4_t __attribute__((ext_vector_type(4)));
+template <int BKD>
+__device__ __forceinline__ void mma_kstep_swz_f32(float4_t (&acc)[4][4], const double* __restrict__ lds, int offAs, int offBs, int wr, int wc,
+                                                  const int (&koff)[BKD / 4]) {
+  const int lr = threadIdx.x & 15;
+  const double* __restrict__ ap = lds + offAs + (64 * wr + lr) * BKD;
+  const double* __restrict__ bp = lds + offBs + (64 * wc + lr) * BKD;
+#pragma unroll
+  for (int k4 = 0; k4 < BKD / 4; ++k4) {
+    float2_t a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float2_t*>(ap + 16 * i * BKD + koff[k4]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const float2_t*>(bp + 16 * j * BKD + koff[k4]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+      }
+  }
+}
+
+// fp64 running sums += fp32 block sums; the fp64 registers simply shadow the fp32 C/D map (row = 4*(lane/16) + reg)
+__device__ __forceinline__ void flush_f32_blocks(double4_t (&acc)[4][4], float4_t (&acc32)[4][4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] += (double)acc32[i][j][r];
+      acc32[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // One K step of this wave's quadrant.  On a diagonal tile (alias) the quadrant above the diagonal is skipped (a quarter of
 // the tile's MFMAs; the freed matrix-pipe slots go to the co-resident workgroups' waves).  Also forming only the lower
 // 16 x 16 blocks of the two quadrants ON the diagonal needs a second copy of the K step, and with two copies hipcc spills
@@ -338,7 +378,11 @@ __device__ __forceinline__ void mma_kstep_sym(double4_t (&acc)[4][4], const doub
 
 // lds: 4 * DmaGeom<BKD>::DT doubles.  Same contract as tile_mainloop<false,false>; with alias (diagonal tile) only the lower
 // triangle of the tile (row >= col) is accumulated.
-template <int BKD>
+// F32: the operands are fp32 arrays viewed as doubles (lda, k0, k1 in 8-byte units, i.e. sample pairs; padding samples must be
+// zero); products are summed in fp32 by the matrix pipe over blocks of F32_BLOCK_STEPS K steps (<= 128 samples) and the block
+// sums are accumulated in fp64 -- acc then follows the fp32 C/D register map (tile_store_f32map).
+constexpr int F32_BLOCK_STEPS = 4;
+template <int BKD, bool F32 = false>
 __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const double* __restrict__ A, int64_t lda, int rowA0,
                                                   const double* __restrict__ B, int64_t ldb, int rowB0, bool alias, int64_t k0,
                                                   int64_t k1, double* __restrict__ lds) {
@@ -364,6 +408,14 @@ __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const 
 #pragma unroll
     for (int k4 = 0; k4 < BKD / 4; ++k4) koff[k4] = (((2 * k4 + (lk >> 1)) ^ f) << 1) + (lk & 1);
   }
+  float4_t acc32[F32 ? 4 : 1][F32 ? 4 : 1];
+  if constexpr (F32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc32[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  const bool active = !alias || wr >= wc;      // the quadrant above the diagonal of a diagonal tile forms no products
   const int boff = alias ? 0 : DTB;
   const int64_t nfull = (k1 - k0) / BKD;
   const int64_t tail = (k1 - k0) - nfull * BKD;
@@ -391,7 +443,14 @@ __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const 
       __builtin_amdgcn_s_setprio(0);
     }
     VMC_STAMP(0)
-    mma_kstep_sym<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff, alias);
+    if constexpr (F32) {
+      if (active) {
+        mma_kstep_swz_f32<BKD>(acc32, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff);
+        if ((s & (F32_BLOCK_STEPS - 1)) == F32_BLOCK_STEPS - 1) flush_f32_blocks(acc, acc32);
+      }
+    } else {
+      mma_kstep_sym<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff, alias);
+    }
     VMC_STAMP(1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     VMC_STAMP(2)
@@ -422,9 +481,29 @@ __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const 
       }
     }
     __syncthreads();
-    mma_kstep_sym<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff, alias);
+    if constexpr (F32) {
+      if (active) mma_kstep_swz_f32<BKD>(acc32, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff);
+    } else {
+      mma_kstep_sym<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff, alias);
+    }
     __syncthreads();
   }
+  if constexpr (F32) flush_f32_blocks(acc, acc32);
+}
+
+// fp32 C/D map: element (i, j, reg r) of this lane sits at row 64*wr + 16*i + 4*(lane>>4) + r, col 64*wc + 16*j + (lane&15).
+__device__ __forceinline__ void tile_store_f32map(const double4_t (&acc)[4][4], double* __restrict__ out /* [128][128] */) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 64 * wr + 16 * i + 4 * (lane >> 4) + r;
+        const int col = 64 * wc + 16 * j + (lane & 15);
+        out[row * TILE + col] = acc[i][j][r];
+      }
 }
 
 // C/D element (i, j, reg r) of this lane sits at row 64*wr + 16*i + (lane>>4) + 4*r, col 64*wc + 16*j + (lane&15).

@@ -28,6 +28,7 @@ from . import global_defs
 from . import mpi_wrapper as mpi
 
 
+F32_BLOCK_MIN_SHIFT = 1e-4   # smallest diagonalShift the fp32-block Gram is allowed with (see TDVP._gram)
 _BORDER_PIVOT = 1e200    # corner of the bordered matrix: any value above F^T A^-1 F keeps the last pivot positive
 
 
@@ -52,6 +53,7 @@ class TDVP:
                                   # "auto": uncentred once the previous call showed max_p mean_p^2/var_p < 1e3, i.e. the
                                   #   cancellation costs < 3 of fp64's 16 digits; centred otherwise
     fuseMoments: bool = True      # uncentred path: sum O and sum O (E - cE) ride in the syrk as two appended Jacobian rows
+    f32BlockGram: bool = False    # with an fp32 Jacobian: fp32 MFMA sums over blocks of <= 128 samples, fp64 across blocks (2x MFMA rate)
 
     def __post_init__(self):
         self._buf = {}
@@ -90,7 +92,13 @@ class TDVP:
         if hook is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        nat.call("vmcpde_gram", nat.ptr(JT), ldj, 1 if JT.dtype == torch.float32 else 0, P, n, nat.ptr(c), nat.ptr(w), nat.ptr(out),
+        f32 = 0 if JT.dtype != torch.float32 else (2 if (self.f32BlockGram and c is None and w is None and ldj % 4 == 0) else 1)
+        if f32 == 2 and self._solver() == "cholesky" and self.diagonalShift < F32_BLOCK_MIN_SHIFT:
+            # fp32 block sums perturb the scaled Gram by ~2e-8 per entry, i.e. ~2e-8 * 2 sqrt(P) in norm: the sum is no longer
+            # exactly positive semi-definite, and a smaller shift cannot make the (rank-deficient) S + shift*diag(S) definite
+            raise ValueError(f"f32BlockGram needs diagonalShift >= {F32_BLOCK_MIN_SHIFT:g} with the Cholesky solver "
+                             f"(got {self.diagonalShift:g}); use the widening fp32 path (f32BlockGram=False) for smaller shifts")
+        nat.call("vmcpde_gram", nat.ptr(JT), ldj, f32, P, n, nat.ptr(c), nat.ptr(w), nat.ptr(out),
                  nat.ptr(b["gram_ws"]), b["gram_ws"].numel() * 8, nat.stream())
         if hook is not None:
             e1.record()
