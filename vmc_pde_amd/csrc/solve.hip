@@ -151,9 +151,9 @@ __device__ __forceinline__ int factor_inverse_32(double* a, int j0, double* scr,
 // padded with the identity.  LDS: the 128 x 129 block + three 32 x 33 scratch tiles.
 __device__ __forceinline__ void chol_diag_body(double* __restrict__ A, int64_t lda, int k0, int n, double* __restrict__ Linv,
                                                int* __restrict__ info, int phase /* diagnostic: 5 = everything */) {
-  extern __shared__ double a[];          // [NB][DP] followed by T[3][SB][SB+1]
+  extern __shared__ double a[];          // [NB][DP] followed by four wave-private 32 x 17 scratch tiles and the dump line
   double* T = a + NB * DP;
-  double* scr = T + 3 * SB * (SB + 1);   // exchange line of factor_inverse_32
+  double* scr = T + 4 * SB * 17;          // dump line of factor_inverse_32
   const int t = threadIdx.x;
   // 128 x 128 block -> LDS: 32 double2 loads per thread, issued 16 at a time so the HBM/L2 latency is paid twice, not 64x
 #pragma unroll 1
@@ -175,19 +175,70 @@ __device__ __forceinline__ void chol_diag_body(double* __restrict__ A, int64_t l
   if (t < NB) a[t * DP + NB] = 0.0;
   __syncthreads();
 
-#pragma nounroll
-  for (int jb = 0; jb < NB / SB; ++jb) {
-    const int j0 = jb * SB;
+  // Software-pipelined over the four 32-wide sub-steps: once sub-step jb has produced its panel (P3) and updated the next
+  // diagonal sub-block (P4a), wave 0 sweeps that sub-block (factor + inverse, a single-wave job) while waves 1..3 finish the
+  // trailing update of sub-step jb (P4b) and write the now final block column jb of L back to memory.
+  const int lane = t & 63, wave = t >> 6;
+  const int crow = lane >> 4, ccol = lane & 15;    // C/D element q of this lane: (crow + 4q, ccol)
+  auto trailing_pair = [&](int j0, int pr) {        // A[i][c] -= sum_m L[i][j0+m] L[c][j0+m] on one lower 16x16 block pair
+    const int base = j0 + SB;
+    int bi, bc;
+    tri_decode(pr, bi, bc);
+    double4_t acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = a[(base + 16 * bi + crow + 4 * q) * DP + base + 16 * bc + ccol];
+    mfma16(acc, SB, [&](int r, int k) { return -a[(base + 16 * bi + r) * DP + j0 + k]; },
+           [&](int c, int k) { return a[(base + 16 * bc + c) * DP + j0 + k]; });
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[(base + 16 * bi + crow + 4 * q) * DP + base + 16 * bc + ccol] = acc[q];
+  };
+  // Off-diagonal 32x32 blocks of X = L^-1, row by row: X_{ib,jb} = -X_{ib,ib} * sum_{mb=jb}^{ib-1} L_{ib,mb} X_{mb,jb}.
+  // One item = 16 columns (cb) of one block (ib, jb), done by ONE wave from start to end -- T = sum L X goes through a
+  // wave-private 32 x 17 scratch tile, so no workgroup barrier is involved and items can run while wave 0 is inside a sweep.
+  // Storage reminder: X[row][col] (row >= col) <-> a[col][row+1]; entries with row < col of a diagonal X block are L's, so
+  // they are masked to zero when read.
+  double* Tw = T + wave * (SB * 17);
+  auto xrow_item = [&](int ib, int jb, int cb) {
+    double4_t acc[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      acc[rb] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      for (int mb = jb; mb < ib; ++mb) {
+        const bool diag = (mb == jb);
+        mfma16(acc[rb], SB, [&](int r, int k) { return a[(SB * ib + 16 * rb + r) * DP + SB * mb + k]; },
+               [&](int c, int k) { return (diag && k < 16 * cb + c) ? 0.0 : a[(SB * jb + 16 * cb + c) * DP + SB * mb + k + 1]; });
+      }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Tw[(16 * rb + crow + 4 * q) * 17 + ccol] = acc[rb][q];
+    __builtin_amdgcn_wave_barrier();      // DS operations of one wave execute in order
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      // X_{ib,jb} = -X_{ib,ib} T   (X_ii lower triangular: only k <= row contributes)
+      double4_t x = {0.0, 0.0, 0.0, 0.0};
+      mfma16(x, 16 * (rb + 1), [&](int r, int k) { return (k <= 16 * rb + r) ? a[(SB * ib + k) * DP + SB * ib + 16 * rb + r + 1] : 0.0; },
+             [&](int c, int k) { return Tw[k * 17 + c]; });
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[(SB * jb + 16 * cb + ccol) * DP + SB * ib + 16 * rb + crow + 4 * q + 1] = -x[q];
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto sweep = [&](int j0) {
     if (phase >= 1 && t < 64) {
       const int pinned = factor_inverse_32(a, j0, scr, phase >= 2);
       if (t == 0 && pinned) atomicAdd(info, pinned);
     }
-    __syncthreads();
+  };
+  sweep(0);
+  __syncthreads();
+#pragma nounroll
+  for (int jb = 0; jb < NB / SB; ++jb) {
+    const int j0 = jb * SB;
     const int R = NB - j0 - SB;          // rows (and trailing columns) below this sub-block
-    const int lane = t & 63, wave = t >> 6;
-    const int crow = lane >> 4, ccol = lane & 15;    // C/D element q of this lane: (crow + 4q, ccol)
     if (R > 0 && phase >= 3) {
-      // panel below on the matrix pipe: L[i][j0+c] = sum_{m<=c} A[i][j0+m] X[c][m]; 16-row blocks round-robin over the
+      // P3, panel below on the matrix pipe: L[i][j0+c] = sum_{m<=c} A[i][j0+m] X[c][m]; 16-row blocks round-robin over the
       // waves, both 16-column blocks per row block held in registers until every wave has read its operands
       const int nib = R / 16;
       double4_t accp[2][2];
@@ -213,70 +264,42 @@ __device__ __forceinline__ void chol_diag_body(double* __restrict__ A, int64_t l
             for (int q = 0; q < 4; ++q) a[(j0 + SB + 16 * ib16 + crow + 4 * q) * DP + j0 + 16 * cb + ccol] = accp[s2][cb][q];
       }
       __syncthreads();
-      if (phase >= 4) {
-        // trailing update inside the block: A[i][c] -= sum_m L[i][j0+m] L[c][j0+m] on the lower 16x16 block pairs
-        const int base = j0 + SB;
-        const int npair = nib * (nib + 1) / 2;
-        for (int pr = wave; pr < npair; pr += 4) {
-          int bi, bc;
-          tri_decode(pr, bi, bc);
-          double4_t acc;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q] = a[(base + 16 * bi + crow + 4 * q) * DP + base + 16 * bc + ccol];
-          mfma16(acc, SB, [&](int r, int k) { return -a[(base + 16 * bi + r) * DP + j0 + k]; },
-                 [&](int c, int k) { return a[(base + 16 * bc + c) * DP + j0 + k]; });
-#pragma unroll
-          for (int q = 0; q < 4; ++q) a[(base + 16 * bi + crow + 4 * q) * DP + base + 16 * bc + ccol] = acc[q];
+      const int npair = nib * (nib + 1) / 2;
+      // P4a: the three 16x16 pairs of the next diagonal sub-block, one per wave
+      if (phase >= 4 && wave < 3) trailing_pair(j0, wave);
+      __syncthreads();
+      if (wave == 0) {
+        sweep(j0 + SB);
+      } else {
+        // P4b: the rest of the trailing update, then the write-back of block column jb of L (final since P3)
+        if (phase >= 4)
+          for (int pr = 3 + (wave - 1); pr < npair; pr += 3) trailing_pair(j0, pr);
+        for (int idx = t - 64; idx < (NB - j0) * SB; idx += 192) {
+          const int i = j0 + idx / SB, j = j0 + (idx & (SB - 1));
+          if (i < n && j <= i) A[(int64_t)(k0 + i) * lda + k0 + j] = a[i * DP + j];
         }
+        // row jb of the off-diagonal blocks of X: everything it needs (X_jj, rows < jb of X, block row jb of L) is final
+        if (phase >= 5)
+          for (int it = wave - 1; it < 2 * jb; it += 3) xrow_item(jb, it >> 1, it & 1);
       }
+      __syncthreads();
+    } else if (R > 0) {     // (diagnostic phases < 3: keep the sweeps)
+      sweep(j0 + SB);
       __syncthreads();
     }
   }
 
-  // write L back (lower triangle incl. diagonal)
-  // (fixed trip count + unroll: 16 LDS reads in flight per thread instead of one dependent read per iteration)
-#pragma unroll 16
-  for (int q = 0; q < NB * NB / 256; ++q) {
-    const int idx = t + 256 * q, i = idx / NB, j = idx - i * NB;
-    const double v = a[i * DP + j];
-    if (i < n && j <= i) A[(int64_t)(k0 + i) * lda + k0 + j] = v;
+  // write back the last block column of L (the earlier ones went out during the sweeps)
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int i = NB - SB + idx / SB, j = NB - SB + (idx & (SB - 1));
+    if (i < n && j <= i) A[(int64_t)(k0 + i) * lda + k0 + j] = a[i * DP + j];
   }
 
-  // off-diagonal 32x32 blocks of X = L^-1:  X_{ib,jb} = -X_{ib,ib} * sum_{mb=jb}^{ib-1} L_{ib,mb} X_{mb,jb},  by block
-  // distance, on the matrix pipe: every 32x32 block is four 16x16 MFMA blocks, dealt round-robin to the four waves.
-  // Storage reminder: X[row][col] (row >= col) <-> a[col][row+1]; entries with row < col of a diagonal X block are L's, so
-  // they are masked to zero when read.
-  {
-    const int lane = t & 63, wave = t >> 6;
-    const int crow = lane >> 4, ccol = lane & 15;
-#pragma nounroll
-    for (int dlt = 1; dlt < ((phase >= 5) ? NB / SB : 1); ++dlt) {
-      const int nblk = 4 * (NB / SB - dlt);
-      // T_p = sum_mb L_{ib,mb} X_{mb,jb}
-      for (int b = wave; b < nblk; b += 4) {
-        const int p = b >> 2, rb = (b >> 1) & 1, cb = b & 1, jb = p, ib = p + dlt;
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-        for (int mb = jb; mb < ib; ++mb) {
-          const bool diag = (mb == jb);
-          mfma16(acc, SB, [&](int r, int k) { return a[(SB * ib + 16 * rb + r) * DP + SB * mb + k]; },
-                 [&](int c, int k) { return (diag && k < 16 * cb + c) ? 0.0 : a[(SB * jb + 16 * cb + c) * DP + SB * mb + k + 1]; });
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) T[(p * SB + 16 * rb + crow + 4 * q) * (SB + 1) + 16 * cb + ccol] = acc[q];
-      }
-      __syncthreads();
-      // X_{ib,jb} = -X_{ib,ib} T_p   (X_ii lower triangular: only k <= row contributes)
-      for (int b = wave; b < nblk; b += 4) {
-        const int p = b >> 2, rb = (b >> 1) & 1, cb = b & 1, jb = p, ib = p + dlt;
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-        mfma16(acc, 16 * (rb + 1), [&](int r, int k) { return (k <= 16 * rb + r) ? a[(SB * ib + k) * DP + SB * ib + 16 * rb + r + 1] : 0.0; },
-               [&](int c, int k) { return T[(p * SB + k) * (SB + 1) + 16 * cb + c]; });
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a[(SB * jb + 16 * cb + ccol) * DP + SB * ib + 16 * rb + crow + 4 * q + 1] = -acc[q];
-      }
-      __syncthreads();
-    }
+  // last row of off-diagonal blocks of X (rows 1 and 2 were assembled during the sweeps): six items over the four waves
+  if (phase >= 5) {
+    for (int it = wave; it < 2 * (NB / SB - 1); it += 4) xrow_item(NB / SB - 1, it >> 1, it & 1);
   }
+  __syncthreads();
 #pragma unroll 16
   for (int q = 0; q < NB * NB / 256; ++q) {
     const int idx = t + 256 * q, i = idx / NB, c = idx - i * NB;
@@ -573,8 +596,8 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
   hipStream_t st = (hipStream_t)stream;
   double* Linv = static_cast<double*>(workspace);
   const int nb = (P + NB - 1) / NB;
-  const size_t diag_lds = ((size_t)NB * DP + 3 * SB * (SB + 1) + 2 * SB) * sizeof(double);   // block + 3 tiles + 64-slot dump line of factor_inverse_32
-  static_assert(((size_t)NB * DP + 3 * SB * (SB + 1) + 2 * SB) * sizeof(double) >= TILE_DMA_LDS_BYTES, "the fused launch sizes its LDS for the diagonal block");
+  const size_t diag_lds = ((size_t)NB * DP + 4 * SB * 17 + 2 * SB) * sizeof(double);   // block + 4 wave-private tiles + 64-slot dump line
+  static_assert(((size_t)NB * DP + 4 * SB * 17 + 2 * SB) * sizeof(double) >= TILE_DMA_LDS_BYTES, "the fused launch sizes its LDS for the diagonal block");
   const size_t strip_lds = (size_t)(NB + 32) * SP * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
