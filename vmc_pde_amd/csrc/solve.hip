@@ -317,19 +317,24 @@ __device__ __forceinline__ void chol_diag_body(double* __restrict__ A, int64_t l
 // the same work on these small grids (one K-step of prefetch, 13.7 us of MFMA per 128^3 tile on a single CU).
 constexpr int SK = 64;            // K half
 constexpr int SP = SK + 2;        // LDS pitch: 4r + 2k dwords mod 64 distinct over a half-wave of ds_read_b64
+// SR = rows per strip workgroup: 16 while 8 strips per block row still fit one round of the 256 CUs (half the MFMA chain per
+// workgroup: 2.88 -> 2.67 ms for the whole factorisation at P = 4213), 32 beyond that (each workgroup re-reads the 128 KB B
+// operand, so twice the workgroups is a loss once they no longer run concurrently).
+template <int SR>
 __global__ __launch_bounds__(256, 1) void chol_strip_kernel(double* __restrict__ A, int64_t lda, int P, int k0, int mode,
                                                             const double* __restrict__ Linv) {
-  extern __shared__ double lds[];          // Bs[128][SP] then As[32][SP]
+  extern __shared__ double lds[];          // Bs[128][SP] then As[SR][SP]
   double* Bs = lds;
   double* As = lds + NB * SP;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int row0 = k0 + NB + blockIdx.x * 32;            // first row of this strip (a row below the panel)
+  const int row0 = k0 + NB + blockIdx.x * SR;            // first row of this strip (a row below the panel)
   const int c0 = k0 + NB;                                // first row of the B operand in mode 1
   const double* __restrict__ Bsrc = mode ? (A + (int64_t)c0 * lda + k0) : Linv;
   const int64_t ldb = mode ? lda : NB;
   const double* __restrict__ Asrc = A + (int64_t)row0 * lda + k0;
-  // ---- issue every load: per K-half 16 double2 of B (128 rows x 32 double2) and 4 of A (32 rows x 32 double2) per thread
-  double2_t vb[2][16], va[2][4];
+  // ---- issue every load: per K-half 16 double2 of B (128 rows x 32 double2) and SR/8 of A (SR rows x 32 double2) per thread
+  constexpr int NA = SR / 8, NI = SR / 16;
+  double2_t vb[2][16], va[2][NA];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -338,14 +343,14 @@ __global__ __launch_bounds__(256, 1) void chol_strip_kernel(double* __restrict__
       vb[h][q] = *reinterpret_cast<const double2_t*>(Bsrc + (int64_t)r * ldb + h * SK + kp);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NA; ++q) {
       const int idx = q * 256 + t, r = idx >> 5, kp = (idx & 31) * 2;
       va[h][q] = *reinterpret_cast<const double2_t*>(Asrc + (int64_t)r * lda + h * SK + kp);
     }
   }
-  double4_t acc[2][2];
+  double4_t acc[NI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
   const int lr = lane & 15, lk = lane >> 4;
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void chol_strip_kernel(double* __restrict__
       *reinterpret_cast<double2_t*>(Bs + r * SP + kp) = vb[h][q];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NA; ++q) {
       const int idx = q * 256 + t, r = idx >> 5, kp = (idx & 31) * 2;
       *reinterpret_cast<double2_t*>(As + r * SP + kp) = va[h][q];
     }
@@ -367,18 +372,19 @@ __global__ __launch_bounds__(256, 1) void chol_strip_kernel(double* __restrict__
     const double* __restrict__ bp = Bs + (32 * wave + lr) * SP + lk;
 #pragma unroll 4
     for (int k4 = 0; k4 < SK / 4; ++k4) {
-      const double a0 = ap[4 * k4], a1 = ap[16 * SP + 4 * k4];
       const double b0 = bp[4 * k4], b1 = bp[16 * SP + 4 * k4];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const double ai = ap[16 * i * SP + 4 * k4];
+        acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, b0, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, b1, acc[i][1], 0, 0, 0);
+      }
     }
   }
   // ---- epilogue: wave w owns columns 32w..32w+31 of the strip
   double* __restrict__ C = A + (int64_t)row0 * lda + (mode ? c0 : k0);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -602,7 +608,8 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
   static bool attr_set = false;
   if (!attr_set) {
     VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
-    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds));
+    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_strip_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds));
+    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_strip_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds));
     VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_syrk_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
     VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_DMA_LDS_BYTES));
     attr_set = true;
@@ -634,8 +641,13 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
     if (rem <= 0) break;
     const int nrem = (rem + TILE - 1) / TILE;
     // n == NB here (a panel with rows below it is always full); row strips of 32 over the zero-padded row range
-    hipLaunchKernelGGL(chol_strip_kernel, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 0, Linv + (int64_t)k * NB * NB);
-    hipLaunchKernelGGL(chol_strip_kernel, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 1, Linv);
+    if (8 * nrem <= 256) {
+      hipLaunchKernelGGL(chol_strip_kernel<16>, dim3(8 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 0, Linv + (int64_t)k * NB * NB);
+      hipLaunchKernelGGL(chol_strip_kernel<16>, dim3(8 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 1, Linv);
+    } else {
+      hipLaunchKernelGGL(chol_strip_kernel<32>, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 0, Linv + (int64_t)k * NB * NB);
+      hipLaunchKernelGGL(chol_strip_kernel<32>, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 1, Linv);
+    }
     double* Linv_next = Linv + (int64_t)(k + 1) * NB * NB;
     const int k1 = k0 + n;
     const int n1 = (P - k1 < NB) ? (P - k1) : NB;
