@@ -155,19 +155,25 @@ __device__ __forceinline__ void chol_diag_body(double* __restrict__ A, int64_t l
   double* T = a + NB * DP;
   double* scr = T + 4 * SB * 17;          // dump line of factor_inverse_32
   const int t = threadIdx.x;
-  // 128 x 128 block -> LDS: 32 double2 loads per thread, issued 16 at a time so the HBM/L2 latency is paid twice, not 64x
-#pragma unroll 1
-  for (int q0 = 0; q0 < 32; q0 += 16) {
-    double2_t v[16];
+  // 128 x 128 block -> LDS.  Only the ten 32 x 32 blocks on and below the block diagonal are needed (the strict upper part
+  // of the LDS image is storage for X, written before it is read); 20 double2 loads per thread, all in flight at once.
+  {
+    double2_t v[20];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int idx2 = t + 256 * (q0 + q), i = idx2 >> 6, j = (idx2 & 63) * 2;
+    for (int q = 0; q < 20; ++q) {
+      const int blk = q >> 1;                                     // lower block (bi, bj), 512 double2 each, 2 per thread
+      int bi, bj;
+      tri_decode(blk, bi, bj);
+      const int e = t + 256 * (q & 1), i = SB * bi + (e >> 4), j = SB * bj + (e & 15) * 2;
       v[q] = (double2_t){0.0, 0.0};
       if (i < n && j < n) v[q] = *reinterpret_cast<const double2_t*>(A + (int64_t)(k0 + i) * lda + k0 + j);   // pitch even: 16-B aligned
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int idx2 = t + 256 * (q0 + q), i = idx2 >> 6, j = (idx2 & 63) * 2;
+    for (int q = 0; q < 20; ++q) {
+      const int blk = q >> 1;
+      int bi, bj;
+      tri_decode(blk, bi, bj);
+      const int e = t + 256 * (q & 1), i = SB * bi + (e >> 4), j = SB * bj + (e & 15) * 2;
       a[i * DP + j] = (i < n && j < n) ? v[q].x : ((i == j) ? 1.0 : 0.0);
       a[i * DP + j + 1] = (i < n && j + 1 < n) ? v[q].y : ((i == j + 1) ? 1.0 : 0.0);
     }
