@@ -45,7 +45,7 @@ WORKLOADS = {
     "C4": dict(dim=6, hidden=(19, 19), n_samp=32768, offset=[1.0, 0.0, 0.0, 1.0, 0.0, 0.0],
                desc="C4: 6-D Fokker-Planck (three damped oscillators), coupling flow d=6 x 4 blocks x hidden (19,19), 32768 samples per GPU"),
 }
-DIAG_SHIFT = 1e-6
+DIAG_SHIFT = 1e-4                # a shift the headline net integrates stably with (tests/test_gpu_published_trajectory.py); timing does not depend on it
 F32BLOCKS_DIAG_SHIFT = 1e-4     # --jacobian f32blocks only (vmc_pde_amd.tdvp.F32_BLOCK_MIN_SHIFT)
 PEAK_F64_MFMA_TFLOPS = 78.6     # AMD MI355X spec, fp64 matrix (dense); the guide has no measured f64 MFMA figure
 PEAK_F32_MFMA_TFLOPS = 157.3    # fp32 matrix (MI355X_MICROARCH.md: 157.3 spec / 155 measured) -- only for --jacobian f32blocks

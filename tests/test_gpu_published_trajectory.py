@@ -142,3 +142,39 @@ def test_phase_space_three_oscillators_matches_exact_moments_and_published_ensem
     dw = np.abs(np.diagonal(cov[idx], axis1=1, axis2=2) - np.diagonal(ref["covar"], axis1=1, axis2=2))
     assert (dw / np.diagonal(ref["covar"], axis1=1, axis2=2)).max() < 0.15
     assert np.abs(x1[idx] - ref["x1"]).max() < 0.2
+
+
+def test_headline_configuration_evolves_the_kramers_equation_correctly():
+    """The benchmark's configuration, not just one step of it: d = 2 phase space, 4 blocks x hidden (21,21) (P = 4213),
+    65 536 samples, Cholesky solve -- i.e. the uncentred DMA Gram, the appended-row moments, the bordered factorisation --
+    integrated with Heun from t = 0 to 1.37 (150 steps, dt = 1e-4 * 1.3^n up to 1e-2) for the harmonic Kramers problem
+    (lam = 0), whose first and second moments are known in closed form.
+    Regularisation: diagonalShift = 1e-4 (+ the absolute floor svdTol * max diag S).  With 1e-6 the over-parametrised net is
+    too stiff for explicit steps of 1e-2: |theta_dot| grows 20 -> 3e10 within 20 steps (measured), whatever the solver."""
+    import vmc_pde_amd as V
+    dim, offset, N = 2, np.array([1.0, 1.0]), 65536
+    sampler = V.Sampler(key=7, dim=dim, name="Gauss", mcmc_info={"offset": offset, "bound": 0.25})
+    vs = V.VarState(sampler, dim, 1, 4, network_args={"intmediate": (21, 21), "offset": offset, "latentSpaceName": "Gauss", "dim": dim})
+    assert vs.numParameters == 4213
+    tdvp = V.TDVP(diagonalShift=1e-4)                   # -> Cholesky solver
+    eq = V.EvolutionEquation(dim=dim, name="advection_hamiltonian_wDiss")      # T = 10, gamma = m = omega = 1, lam = 0
+    stepper = V.FixedStepper(timeStep=1e-4, mode="Heun", maxStep=1e-2, increase_fac=1.3)
+    t, times, x1, cov, resid, unorm = 0.0, [], [], [], [], []
+    for n in range(150):
+        dp, dt, info = stepper.step(0, tdvp, vs.get_parameters(), evolutionEq=eq, psi=vs, nSamplesTDVP=N, nSamplesObs=N,
+                                    normFunction=lambda v, S: v @ S @ v, timings=None, integrals=None)
+        unorm.append(float(torch.linalg.norm(dp - vs.get_parameters())) / dt)
+        vs.set_parameters(dp)
+        times.append(t)
+        x1.append(info["x1"].cpu().numpy())
+        cov.append(info["covar"].cpu().numpy())
+        resid.append(float(tdvp.solverResidual))
+        t += dt
+    assert tdvp._uncentred_ok and int(tdvp.cholInfo.item()) == 0       # the fast path really ran, no pinned pivots
+    times, x1, cov = np.asarray(times), np.asarray(x1), np.asarray(cov)
+    assert times[-1] > 1.3 and np.all(np.isfinite(cov))
+    assert max(resid) < 1e-8 and max(unorm) < 200.0                     # the update stays O(10): no stiff blow-up
+    m_ex, c_ex = _oscillator_moments(times, T=10.0, mean0=(1.0, 1.0))
+    assert np.abs(x1 - m_ex).max() < 0.1                                # measured 0.046
+    rel = np.abs(cov - c_ex) / np.sqrt(np.einsum("tii,tjj->tij", c_ex, c_ex))
+    assert rel.max() < 0.2, rel.max()                                   # measured 0.11 (Heun at dt = 1e-2 + Monte-Carlo noise)

@@ -92,7 +92,8 @@ def test_tdvp_cholesky_path_matches_regularised_reference():
     upd_p, _ = tp(th.cuda(), 0.0, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None)
     assert tp._solver() == "cholesky" and int(tp.cholInfo.item()) == 0
     S = to.S0 + torch.diag(shift * torch.diag(to.S0))
-    exact = torch.linalg.solve(S, to.F0)
+    # the Cholesky path also carries the absolute floor svdTol * max diag(S) (the Tikhonov form of the spectral cut-off)
+    exact = torch.linalg.solve(S + tp.svdTol * torch.diag(to.S0).max() * torch.eye(S.shape[0], dtype=S.dtype), to.F0)
     assert float(torch.linalg.norm(upd_p.cpu() - exact) / torch.linalg.norm(exact)) < 1e-8
     assert float(tp.solverResidual) < 1e-9
     # against the reference's own (spectral) answer for the shifted matrix, in the S-norm

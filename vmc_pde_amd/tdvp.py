@@ -9,7 +9,7 @@ What runs underneath (all on the GPU, all fp64):
     four N x P temporaries and two full GEMMs (tdvp.py:40-47);
   * multi-GPU: every rank processes its shard of the samples and ONE packed buffer
     [ Gram tiles | sum O | sum E~O | sum E, sum E^2, sum |E| | n ] is all-reduced (RCCL) per step; the solve is replicated;
-  * solve: `solver="cholesky"` -- in-place blocked Cholesky of S + diagonalShift*diag(S) on the MFMA tile engine
+  * solve: `solver="cholesky"` -- in-place blocked Cholesky of S + diagonalShift*diag(S) + svdTol*max(diag S)*I on the MFMA tile engine
     (csrc/solve.hip); `solver="eigh"` -- the reference's spectral pseudo-inverse (tdvp.py:57-94), with eigh from
     LAPACK on the host (diagonalizeOnDevice=False, as tdvp.py:61-64) or rocSOLVER on the device.
   * `SExp`, `rhoVar`, `snr` are evaluated lazily from the retained Jacobian (weighted Gram), since only AdaptiveHeun
@@ -63,6 +63,7 @@ class TDVP:
         self.ev = self.V = self.VtF = None
         self._ratio_host = self._ratio_event = None
         self._uncentred_ok = False
+        self._floor = None
 
     # ---- buffers ------------------------------------------------------------------------------------------------
     def _buffers(self, P, device):
@@ -290,6 +291,13 @@ class TDVP:
                 need = nat.lib().vmcpde_chol_workspace_bytes(Pf)
                 if b["chol_ws"] is None or b["chol_ws"].numel() * 8 < need:
                     b["chol_ws"] = torch.empty(need // 8, dtype=global_defs.tReal, device=device)
+                # absolute floor svdTol * max diag(S): the Tikhonov counterpart of the reference's spectral cut-off at
+                # svdTol * lambda_max (tdvp.py:82-85).  The relative shift alone leaves parameters whose gradient is ~0 (S_ii
+                # ~ 1e-18 at the reference's 1e-5 initialisation) with updates ~ 1/sqrt(S_ii), which no time step survives.
+                self._floor = None
+                if self.svdTol > 0:
+                    self._floor = float(self.svdTol) * torch.diagonal(b["S"])[:P].max()
+                    torch.diagonal(A)[:P].add_(self._floor)
                 if bordered:
                     A[P, :P].copy_(F)
                     A[P, P] = _BORDER_PIVOT
@@ -315,6 +323,8 @@ class TDVP:
         Su = S0u
         if self.diagonalShift > 1e-10:
             Su = S0u + self.diagonalShift * torch.diagonal(self.S0) * update
+        if self._solver() == "cholesky" and self._floor is not None:
+            Su = Su + self._floor * update              # the system the Cholesky path solves
         tdvp_error = 1 + (update @ S0u - 2 * (self.F0 @ update)) / self._Esq_mean                      # tdvp.py:93
         residual = torch.linalg.norm(Su - F) / torch.linalg.norm(F)                                     # tdvp.py:94
         return update, residual, tdvp_error
