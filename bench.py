@@ -46,6 +46,7 @@ WORKLOADS = {
                desc="C4: 6-D Fokker-Planck (three damped oscillators), coupling flow d=6 x 4 blocks x hidden (19,19), 32768 samples per GPU"),
 }
 DIAG_SHIFT = 1e-4                # a shift the headline net integrates stably with (tests/test_gpu_published_trajectory.py); timing does not depend on it
+SVD_TOL = 1e-6                   # absolute floor svdTol * max diag(S): what keeps the over-parametrised headline net integrable
 F32BLOCKS_DIAG_SHIFT = 1e-4     # --jacobian f32blocks only (vmc_pde_amd.tdvp.F32_BLOCK_MIN_SHIFT)
 PEAK_F64_MFMA_TFLOPS = 78.6     # AMD MI355X spec, fp64 matrix (dense); the guide has no measured f64 MFMA figure
 PEAK_F32_MFMA_TFLOPS = 157.3    # fp32 matrix (MI355X_MICROARCH.md: 157.3 spec / 155 measured) -- only for --jacobian f32blocks
@@ -63,7 +64,7 @@ def build_problem(device, workload="C2", seed=1, jacobian_dtype=torch.float64):
     vs.set_parameters(theta)
     eq = V.EvolutionEquation(dim=dim, name=EQ)
     eq.eqParams[EQ]["params"]["lam"] = LAM
-    tdvp = V.TDVP(diagonalShift=DIAG_SHIFT, solver="cholesky", fuseMoments=os.environ.get("VMCPDE_FUSE_MOMENTS", "1") != "0")
+    tdvp = V.TDVP(diagonalShift=DIAG_SHIFT, svdTol=SVD_TOL, solver="cholesky", fuseMoments=os.environ.get("VMCPDE_FUSE_MOMENTS", "1") != "0")
     return vs, eq, tdvp, theta
 
 
@@ -248,7 +249,7 @@ def main():
             "config": {"workload": WORKLOADS[args.workload]["desc"],
                        "n_param": P, "n_samp_per_gpu": args.samples, "n_samp_total": n_total, "solver": "cholesky", "gram_operands": ({"f64": "uncentred+DMA", "f32": "uncentred, fp32 widened in staging", "f32blocks": "uncentred+DMA, fp32 MFMA blocks"}[args.jacobian] if tdvp._uncentred_ok else "centred in staging"),
                        "mean2_over_var_max": ratio,
-                       "diagonal_shift": float(tdvp.diagonalShift), "solver_residual": resid, "parallelism": f"dp{world} (samples sharded, one all-reduce of (S,F) per step)"},
+                       "diagonal_shift": float(tdvp.diagonalShift), "svd_tol": float(tdvp.svdTol), "solver_residual": resid, "parallelism": f"dp{world} (samples sharded, one all-reduce of (S,F) per step)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak_spec, "unit": "TFLOP/s",
                          "frac": achieved / peak_spec, "traffic": traffic,
                          "kernel": ("gram_f32_kernel (fp32 MFMA block sums, fp64 across blocks, + split-K reduce)" if args.jacobian == "f32blocks"

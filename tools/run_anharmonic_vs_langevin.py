@@ -1,0 +1,87 @@
+"""BASELINE C2 physics check: the anharmonic Kramers problem (lam = 0.1) integrated by the TDVP engine (hidden (21,21),
+P = 4213, 65 536 samples) against a brute-force Langevin ensemble (Euler-Maruyama, 10^6 walkers, dt = 5e-4) of the same SDE
+   dx = p/m dt,   dp = (-m w^2 x - 4 lam x^3 - gamma p) dt + sqrt(2 m gamma T) dW      (evolutionEq.py:35-45,107-119)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import vmc_pde_amd as V
+
+dev = torch.device("cuda", 0)
+T_END = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
+LAM = float(os.environ.get("LAM", "0.1"))
+
+
+def langevin(t_marks, x0, dt=5e-4, m=1.0, w=1.0, gam=1.0, T=10.0, seed=3):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x, p = x0[:, 0].clone(), x0[:, 1].clone()          # walkers start from samples of the model's own initial density
+    n = x.numel()
+    out, t, k = [], 0.0, 0
+    sig = float(np.sqrt(2 * m * gam * T * dt))
+    while k < len(t_marks):
+        if t >= t_marks[k] - 1e-12:
+            out.append([float(x.mean()), float(p.mean()), float(x.var()), float(p.var()), float(((x - x.mean()) * (p - p.mean())).mean()),
+                        float(((x - x.mean()) ** 4).mean())])
+            k += 1
+        f = -m * w * w * x - 4 * LAM * x ** 3 - gam * p
+        x = x + p / m * dt
+        p = p + f * dt + sig * torch.randn(n, generator=g, dtype=torch.float64, device=dev)
+        t += dt
+    return np.asarray(out)
+
+
+def make_state(out_scale):
+    dim, offset = 2, np.array([1.0, 1.0])
+    sampler = V.Sampler(key=7, dim=dim, name="Gauss", mcmc_info={"offset": offset, "bound": 0.25})
+    vs = V.VarState(sampler, dim, 1, 4, network_args={"intmediate": (21, 21), "offset": offset, "latentSpaceName": "Gauss", "dim": dim})
+    if out_scale is not None:                           # an active (non-Gaussian) initial flow, as in bench.py
+        vs.set_parameters(vs.net.init(1, out_scale=out_scale))
+    return vs
+
+
+def tdvp_run(vs, t_marks, shift=1e-4, N=65536, max_step=1e-2):
+    dim = 2
+    eq = V.EvolutionEquation(dim=dim, name="advection_hamiltonian_wDiss")
+    eq.eqParams["advection_hamiltonian_wDiss"]["params"]["lam"] = LAM
+    tdvp = V.TDVP(diagonalShift=shift, svdTol=float(os.environ.get("SVD_TOL", "1e-6")))
+    if os.environ.get("ADAPTIVE"):       # the reference's error-controlled stepper (stepper.py:20-91, tol as main.py:109)
+        stepper = V.AdaptiveHeun(timeStep=1e-5, tol=float(os.environ["ADAPTIVE"]), maxStep=max_step)
+    else:
+        stepper = V.FixedStepper(timeStep=1e-4, mode="Heun", maxStep=max_step, increase_fac=1.3)
+    nsteps = 0
+    out, t, k = [], 0.0, 0
+    while k < len(t_marks):
+        if t >= t_marks[k] - 1e-12:
+            xs, _ = vs.sample(262144)
+            xs = xs[0]
+            x, p = xs[:, 0], xs[:, 1]
+            out.append([float(x.mean()), float(p.mean()), float(x.var()), float(p.var()), float(((x - x.mean()) * (p - p.mean())).mean()),
+                        float(((x - x.mean()) ** 4).mean())])
+            k += 1
+        dp, dt, _ = stepper.step(0, tdvp, vs.get_parameters(), evolutionEq=eq, psi=vs, nSamplesTDVP=N, nSamplesObs=N,
+                                 normFunction=lambda v, S: v @ S @ v, timings=None, observables=False)
+        nsteps += 1
+        if nsteps % 50 == 0:
+            print(f"  step {nsteps} t = {t:.4f} dt = {dt:.2e}", flush=True)
+        if not torch.isfinite(dp).all():
+            print(f"  (non-finite parameters at t = {t:.3f})")
+            break
+        vs.set_parameters(dp)
+        t += dt
+    return np.asarray(out)
+
+
+if __name__ == "__main__":
+    marks = np.arange(0.0, T_END + 1e-9, 0.25)
+    shift = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-4
+    max_step = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-2
+    out_scale = float(sys.argv[4]) if len(sys.argv) > 4 else 0.1
+    vs = make_state(out_scale if out_scale > 0 else None)
+    t0 = time.perf_counter()
+    ref = langevin(marks, vs.sample(1 << 20)[0][0])
+    t1 = time.perf_counter()
+    run = tdvp_run(vs, marks, shift=shift, max_step=max_step)
+    t2 = time.perf_counter()
+    print(f"lam {LAM}, diagonalShift {shift:g}, maxStep {max_step:g}, output scale of the initial flow {out_scale:g}")
+    print(f"Langevin {t1 - t0:.1f} s, TDVP {t2 - t1:.1f} s;  columns: <x> <p> var x  var p  cov xp  <dx^4>")
+    for tm, a, b in zip(marks, run, ref):
+        print(f"t={tm:.1f}  tdvp {np.round(a, 3)}\n       sde  {np.round(b, 3)}", flush=True)
