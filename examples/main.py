@@ -39,13 +39,18 @@ def main():
     ap.add_argument("--samples", type=int, default=10000)
     ap.add_argument("--wdir", default=None)
     ap.add_argument("--resume", action="store_true")
+    ap.add_argument("--hidden", type=int, nargs="*", default=None, help="widths of the conditioner MLPs (default: the reference's (dim//2,))")
+    ap.add_argument("--diagonal-shift", type=float, default=0.0,
+                    help="tdvp.py:50-51; > 1e-10 selects the on-device Cholesky (default 0: the reference's spectral pseudo-inverse)")
+    ap.add_argument("--svd-tol", type=float, default=1e-11,
+                    help="spectral cut-off / absolute floor; wide networks (P in the thousands) need ~1e-6 with --diagonal-shift 1e-4")
     args = ap.parse_args()
     m = mode_dict[args.mode]
     dim, offset = m["dim"], m["offset"]
     initKey = 1
 
     smp = sampler_mod.Sampler(dim=dim, numChains=30, name=m["latent_space_name"], mcmc_info={"offset": offset, "bound": m["mcmcbound"]})   # main.py:69
-    vState = var_state.VarState(smp, dim, initKey, 4, network_args={"intmediate": (dim // 2,) * 1, "offset": offset,
+    vState = var_state.VarState(smp, dim, initKey, 4, network_args={"intmediate": tuple(args.hidden) if args.hidden else (dim // 2,) * 1, "offset": offset,
                                                                      "latentSpaceName": m["latent_space_name"], "dim": dim})              # main.py:73
     print(f"Number of Model parameters: {vState.numParameters}")
     x_real = torch.ones(dim, dtype=torch.float64)                                                                                          # main.py:77-96
@@ -58,7 +63,7 @@ def main():
 
     dt, maxStep = 1e-7, 1e-2                                                                                                               # main.py:108-118
     myStepper = stepper.FixedStepper(timeStep=dt, mode='Heun', maxStep=maxStep, increase_fac=1.3)
-    tdvpEq = tdvp.TDVP()
+    tdvpEq = tdvp.TDVP(diagonalShift=args.diagonal_shift, svdTol=args.svd_tol)
     timings = util.Timings()
     evolutionEq = evolutionEq_mod.EvolutionEquation(dim=dim, name=m["evolution_type"])
     nSamplesTDVP = nSamplesObs = args.samples
@@ -91,8 +96,9 @@ def main():
         print(f"\t > Means = {info['x1']}")
         for key in info.keys():
             infos.setdefault(key, []).append(info[key])
-        infos["ev"].append(tdvpEq.ev)
-        infos["snr"].append(tdvpEq.snr)
+        if tdvpEq.ev is not None:      # spectral quantities exist on the eigh path only (not with --diagonal-shift)
+            infos["ev"].append(tdvpEq.ev)
+            infos["snr"].append(tdvpEq.snr)
         infos["solver_res"].append(tdvpEq.solverResidual)
         infos["tdvp_error"].append(tdvpEq.tdvp_error)
         infos["dist_params"].append(vState.params['params']['dist_params'].clone())

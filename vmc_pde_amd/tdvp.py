@@ -248,6 +248,8 @@ class TDVP:
     def snr(self):
         """tdvp.py:71."""
         if self._snr is None:
+            if self.V is None:
+                raise RuntimeError("rhoVar/snr need the eigenbasis: use solver='eigh'")
             self._snr = torch.sqrt(torch.abs(self._lazy["Ntot"] * (self.VtF * self.VtF) / self.rhoVar))
         return self._snr
 
