@@ -1,8 +1,9 @@
-"""ODE integrators for the parameter flow (reference: vmc_fluids/stepper.py).
+"""ODE integrators for the parameter flow theta' = f(theta, t)  (reference: vmc_fluids/stepper.py).
 
-Same classes, constructor arguments and `step(t, f, y, normFunction, **rhsArgs) -> (y_new, dt, info)` protocol.
-The reference relies on the value semantics of immutable jnp arrays (`y += dt*k0` rebinds, stepper.py:136); with
-torch tensors every update below builds a new tensor instead of mutating the caller's.
+The call protocol is the reference's -- `Stepper(...).step(t, f, y, normFunction, **rhsArgs) -> (y_new, dt_used, info)`,
+with `f(y, t, **rhsArgs, intStep=k) -> (k_vector, info)` and, for the adaptive scheme, the attribute `f.SExp` -- but the
+schemes are written here as explicit Runge-Kutta stages on new tensors: the caller's `y` is never modified (the reference
+gets that for free from immutable arrays, stepper.py:136).
 """
 import torch
 
@@ -11,8 +12,36 @@ def _default_norm(v, *_):
     return torch.linalg.norm(v)
 
 
+class _Stages:
+    """Evaluates the right-hand side at numbered stages and keeps the `info` of a chosen stage."""
+
+    def __init__(self, f, rhsArgs):
+        self.f, self.rhsArgs, self.count = f, rhsArgs, 0
+
+    def __call__(self, y, t):
+        k, info = self.f(y, t, **self.rhsArgs, intStep=self.count)
+        self.count += 1
+        return k, info
+
+
+def _heun_increment(rhs, y0, t, h, k_first=None):
+    """Heun (explicit trapezoid) increment over [t, t+h] from y0; reuses a known first slope.  Returns (dy, k_first, infos)."""
+    infos = []
+    if k_first is None:
+        k_first, i0 = rhs(y0, t)
+        infos.append(i0)
+    k_end, i1 = rhs(y0 + h * k_first, t + h)
+    infos.append(i1)
+    return 0.5 * h * (k_first + k_end), k_first, infos
+
+
 class AdaptiveHeun:
-    """stepper.py:4-91: adaptive second-order scheme (Heun full step vs two half steps)."""
+    """Step-doubling error control (stepper.py:4-91): one Heun step of size dt against two of size dt/2; the difference,
+    measured by `normFunction(., f.SExp)`, against `tol` decides acceptance and the next step size
+    (factor 0.9 * (tol/err)^(1/3), clipped to [0.2, 2], step capped at maxStep).  Five right-hand sides per attempt, evaluated
+    in the reference's order so that `intStep` numbers and `f.SExp` (the last evaluation's) agree with it."""
+
+    SAFETY, SHRINK_MIN, GROW_MAX, EXPONENT = 0.9, 0.2, 2.0, 0.33333
 
     def __init__(self, timeStep=1e-3, tol=1e-8, maxStep=1):
         self.dt = timeStep
@@ -20,43 +49,28 @@ class AdaptiveHeun:
         self.maxStep = maxStep
 
     def step(self, t, f, y, normFunction=_default_norm, **rhsArgs):
-        fe = 0.5
+        y_start = y.clone()
         dt = self.dt
-        yInitial = y.clone()
-        while fe < 1.:
-            y = yInitial.clone()
-            k0, info = f(y, t, **rhsArgs, intStep=0)
-            y = y + dt * k0
-            k1, _ = f(y, t + dt, **rhsArgs, intStep=1)
-            dy0 = 0.5 * dt * (k0 + k1)
-            # now with half step size (stepper.py:57-65)
-            y = y - 0.5 * dt * k0
-            k10, _ = f(y, t + 0.5 * dt, **rhsArgs, intStep=2)
-            dy1 = 0.25 * dt * (k0 + k10)
-            y = yInitial + dy1
-            k01, _ = f(y, t + 0.5 * dt, **rhsArgs, intStep=3)
-            y = y + 0.5 * dt * k01
-            k11, _ = f(y, t + dt, **rhsArgs, intStep=4)
-            dy1 = dy1 + 0.25 * dt * (k01 + k11)
-            # compute deviation (stepper.py:69-72)
-            updateDiff = normFunction(dy1 - dy0, f.SExp)
-            fe = float(self.tolerance / updateDiff)
-            if 0.2 > 0.9 * fe ** 0.33333:
-                tmp = 0.2
-            else:
-                tmp = 0.9 * fe ** 0.33333
-            if tmp > 2.:
-                tmp = 2.
-            realDt = dt
-            dt *= tmp
-            if dt > self.maxStep:
-                dt = self.maxStep
+        while True:
+            rhs = _Stages(f, rhsArgs)
+            coarse, k0, infos = _heun_increment(rhs, y_start, t, dt)                      # stages 0, 1
+            info = infos[0]
+            half_a, _, _ = _heun_increment(rhs, y_start, t, 0.5 * dt, k_first=k0)         # stage 2 (stage 0 reused)
+            half_b, _, _ = _heun_increment(rhs, y_start + half_a, t + 0.5 * dt, 0.5 * dt)  # stages 3, 4
+            fine = half_a + half_b
+            err = normFunction(fine - coarse, f.SExp)
+            ratio = float(self.tolerance / err)
+            used = dt
+            dt = min(dt * min(max(self.SAFETY * ratio ** self.EXPONENT, self.SHRINK_MIN), self.GROW_MAX), self.maxStep)
+            if ratio >= 1.0:
+                break
         self.dt = dt
-        return yInitial + dy1, realDt, info
+        return y_start + fine, used, info
 
 
 class FixedStepper:
-    """stepper.py:94-145: Heun / Euler with a geometrically growing step."""
+    """Heun or explicit Euler with a geometrically growing step, dt <- min(dt * increase_fac, maxStep) before every step
+    (stepper.py:94-145)."""
 
     def __init__(self, timeStep=1e-3, maxStep=1e-2, increase_fac=1.3, mode='Heun'):
         self.dt = timeStep
@@ -65,18 +79,13 @@ class FixedStepper:
         self.increase_fac = increase_fac
 
     def step(self, t, f, y, normFunction=_default_norm, **rhsArgs):
-        yInitial = y.clone()
-        self.dt = min(self.dt * self.increase_fac, self.maxStep)      # stepper.py:131
-        if self.mode == 'Heun':
-            y = yInitial.clone()
-            k0, _ = f(y, t, **rhsArgs, intStep=0)
-            y = y + self.dt * k0
-            k1, info = f(y, t + self.dt, **rhsArgs, intStep=1)
-            dy = 0.5 * self.dt * (k0 + k1)
-            return yInitial + dy, self.dt, info
+        if self.mode not in ('Heun', 'Euler'):
+            raise ValueError(self.mode)
+        y_start = y.clone()
+        self.dt = min(self.dt * self.increase_fac, self.maxStep)
+        rhs = _Stages(f, rhsArgs)
         if self.mode == 'Euler':
-            y = yInitial.clone()
-            k0, info = f(y, t, **rhsArgs, intStep=0)
-            dy = self.dt * k0
-            return yInitial + dy, self.dt, info
-        raise ValueError(self.mode)
+            k0, info = rhs(y_start, t)
+            return y_start + self.dt * k0, self.dt, info
+        dy, _, infos = _heun_increment(rhs, y_start, t, self.dt)
+        return y_start + dy, self.dt, infos[-1]

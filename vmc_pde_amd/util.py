@@ -19,28 +19,29 @@ def build_cov_matrix(L_para, L_diag, dim):
 
 
 def store_infos(wdir, infos, name="infos.npz"):
-    """util.py:29-32 (one dataset per key; .npz because h5py is not part of the image)."""
-    out = {}
-    for key, value in infos.items():
-        out[key] = np.asarray([v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v) for v in value])
-    np.savez(wdir + name, **out)
+    """Run record of the driver loop (util.py:29-32): every key of `infos` becomes one array stacked over the steps.
+    Written as .npz -- h5py is not part of the image; `np.load(...)[key]` replaces `h5py.File(...)[key][:]`."""
+    def as_numpy(v):
+        return v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    np.savez(wdir + name, **{key: np.asarray([as_numpy(v) for v in series]) for key, series in infos.items()})
 
 
 class Timings:
-    """util.py:35-52: wall-clock sections; stop_timing synchronises the device like block_until_ready."""
+    """Named wall-clock sections (util.py:35-52): `timing_dict[name]` is the list of durations of that section, one per
+    occurrence.  The caller synchronises the device at the section boundaries (TDVP does, like block_until_ready)."""
 
     def __init__(self):
         self.timing_dict = {}
+        self._open = {}
 
     def start_timing(self, key):
-        self.timing_dict.setdefault(key, []).append(-time.perf_counter())
+        self._open[key] = time.perf_counter()
 
     def stop_timing(self, key):
-        self.timing_dict[key][-1] += time.perf_counter()
+        self.timing_dict.setdefault(key, []).append(time.perf_counter() - self._open.pop(key))
 
     def print_timings(self):
-        total = 0
-        for key, value in self.timing_dict.items():
-            print(f"\t > {key}: {value[-1]}")
-            total += value[-1]
-        print(f"\t > TOTAL: {total}")
+        latest = {key: series[-1] for key, series in self.timing_dict.items() if series}
+        for key, seconds in latest.items():
+            print(f"\t > {key}: {seconds}")
+        print(f"\t > TOTAL: {sum(latest.values())}")
