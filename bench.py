@@ -50,6 +50,12 @@ SVD_TOL = 1e-6                   # absolute floor svdTol * max diag(S): what kee
 F32BLOCKS_DIAG_SHIFT = 1e-4     # --jacobian f32blocks only (vmc_pde_amd.tdvp.F32_BLOCK_MIN_SHIFT)
 PEAK_F64_MFMA_TFLOPS = 78.6     # AMD MI355X spec, fp64 matrix (dense); the guide has no measured f64 MFMA figure
 PEAK_F32_MFMA_TFLOPS = 157.3    # fp32 matrix (MI355X_MICROARCH.md: 157.3 spec / 155 measured) -- only for --jacobian f32blocks
+DTYPE_LABEL = {"f64": "f64", "f32": "f64 accumulate, f32 Jacobian storage (BASELINE config 5)",
+               "f32blocks": "f32 Jacobian, f32 MFMA sums over 128-sample blocks, f64 across blocks (BASELINE config 5, fast variant)"}
+OPERAND_LABEL = {"f64": "uncentred+DMA", "f32": "uncentred, fp32 widened in staging", "f32blocks": "uncentred+DMA, fp32 MFMA blocks"}
+KERNEL_LABEL = {"f64": "gram_dma_kernel (fp64 MFMA syrk, + split-K reduce)",
+                "f32": "gram_kernel<false,false,float> (fp32 operands widened, fp64 MFMA syrk, + split-K reduce)",
+                "f32blocks": "gram_f32_kernel (fp32 MFMA block sums, fp64 across blocks, + split-K reduce)"}
 OUT_SCALE = 0.1                 # output kernels U(-0.1, 0.1) (the reference's 1e-5 makes J nearly degenerate)
 
 
@@ -244,16 +250,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f64": "f64", "f32": "f64 accumulate, f32 Jacobian storage (BASELINE config 5)",
-                      "f32blocks": "f32 Jacobian, f32 MFMA sums over 128-sample blocks, f64 across blocks (BASELINE config 5, fast variant)"}[args.jacobian], "data": "synthetic",
+            "dtype": DTYPE_LABEL[args.jacobian], "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload]["desc"],
-                       "n_param": P, "n_samp_per_gpu": args.samples, "n_samp_total": n_total, "solver": "cholesky", "gram_operands": ({"f64": "uncentred+DMA", "f32": "uncentred, fp32 widened in staging", "f32blocks": "uncentred+DMA, fp32 MFMA blocks"}[args.jacobian] if tdvp._uncentred_ok else "centred in staging"),
+                       "n_param": P, "n_samp_per_gpu": args.samples, "n_samp_total": n_total, "solver": "cholesky",
+                       "gram_operands": OPERAND_LABEL[args.jacobian] if tdvp._uncentred_ok else "centred in staging",
                        "mean2_over_var_max": ratio,
-                       "diagonal_shift": float(tdvp.diagonalShift), "svd_tol": float(tdvp.svdTol), "solver_residual": resid, "parallelism": f"dp{world} (samples sharded, one all-reduce of (S,F) per step)"},
+                       "diagonal_shift": float(tdvp.diagonalShift), "svd_tol": float(tdvp.svdTol), "solver_residual": resid,
+                       "parallelism": f"dp{world} (samples sharded, one all-reduce of (S,F) per step)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak_spec, "unit": "TFLOP/s",
                          "frac": achieved / peak_spec, "traffic": traffic,
-                         "kernel": ("gram_f32_kernel (fp32 MFMA block sums, fp64 across blocks, + split-K reduce)" if args.jacobian == "f32blocks"
-                                    else "gram_kernel (fp64 MFMA syrk, + split-K reduce)"), "ms_per_launch": gram_ms,
+                         "kernel": KERNEL_LABEL[args.jacobian], "ms_per_launch": gram_ms,
                          "algorithmic_flops_per_launch": flops, "measured_mfma_f64_peak": peak_meas,
                          "frac_of_measured_peak": achieved / peak_meas if peak_meas > 0 else None},
             "stages_ms": stage_ms, "heun_step_ms": heun_ms,
