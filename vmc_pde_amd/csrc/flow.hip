@@ -113,6 +113,8 @@ struct Ctx {
   int lane;
   int wave, nw;   // this wave's index among the nw waves that share the workgroup's samples
   int jt_f32;   // Jacobian rows are stored as float (BASELINE config 5) instead of double
+  uint32_t joff;      // byte offset of this lane's sample inside a Jacobian row (n * element size)
+  int64_t jpitch;     // bytes between consecutive Jacobian rows (ldj * element size) -- wave-uniform
   const double* __restrict__ th;
   const FlowProgram* __restrict__ fp;
 };
@@ -121,10 +123,36 @@ struct Ctx {
 #define SYNC() __syncthreads()
 #define W0 (c.wave == 0)
 
-// one Jacobian entry of this lane's sample: row `row` of the parameter-major buffer (fp64, or fp32 for config 5)
-__device__ __forceinline__ void jt_store(const Ctx& c, void* __restrict__ JT, int64_t ldj, int64_t row, int64_t n, double v) {
-  if (c.jt_f32) static_cast<float*>(JT)[row * ldj + n] = (float)v;
-  else static_cast<double*>(JT)[row * ldj + n] = v;
+// Jacobian stores.  A row pointer is wave-uniform (base + row * pitch: SGPR arithmetic) and the lane only adds its 32-bit
+// byte offset, which lets the store use the scalar-base + vector-offset addressing form -- no 64-bit VALU address per element.
+__device__ __forceinline__ void jt_store(const Ctx& c, void* __restrict__ JT, int64_t /*ldj*/, int64_t row, int64_t /*n*/, double v) {
+  char* rowp = static_cast<char*>(JT) + row * c.jpitch;
+  if (c.jt_f32) *reinterpret_cast<float*>(rowp + c.joff) = (float)v;
+  else *reinterpret_cast<double*>(rowp + c.joff) = v;
+}
+// JB consecutive rows starting at `row0` (nj <= JB of them valid), values vals[jj] * scale: one precision branch and one
+// bounds decision per block instead of per element
+__device__ __forceinline__ void jt_store_block(const Ctx& c, void* __restrict__ JT, int64_t row0, int nj, const double (&vals)[JB], double scale) {
+  char* p = static_cast<char*>(JT) + row0 * c.jpitch;
+  if (c.jt_f32) {
+    if (nj == JB) {
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) *reinterpret_cast<float*>(p + jj * c.jpitch + c.joff) = (float)(scale * vals[jj]);
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj)
+        if (jj < nj) *reinterpret_cast<float*>(p + jj * c.jpitch + c.joff) = (float)(scale * vals[jj]);
+    }
+  } else {
+    if (nj == JB) {
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) *reinterpret_cast<double*>(p + jj * c.jpitch + c.joff) = scale * vals[jj];
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj)
+        if (jj < nj) *reinterpret_cast<double*>(p + jj * c.jpitch + c.joff) = scale * vals[jj];
+    }
+  }
 }
 
 // tanh with absolute error ~2e-16 and no lane-divergent branches (ocml's tanh costs about as much as a 21 x 6 block of the
@@ -430,11 +458,8 @@ __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const
       double dl[JB];
 #pragma unroll
       for (int jj = 0; jj < JB; ++jj) dl[jj] = (j0 + jj < n_out) ? LD(cur + j0 + jj) : 0.0;
-      if (JT != nullptr && active && (blk % c.nw) == c.wave) {
-#pragma unroll
-        for (int jj = 0; jj < JB; ++jj)
-          if (j0 + jj < n_out) jt_store(c, JT, ldj, L.off_bias + j0 + jj, n, dl[jj]);
-      }
+      const int nj = (n_out - j0 < JB) ? (n_out - j0) : JB;
+      if (JT != nullptr && active && (blk % c.nw) == c.wave) jt_store_block(c, JT, L.off_bias + j0, nj, dl, 1.0);
       for (int i = c.wave; i < n_in; i += c.nw) {
         const double a = LD(uin + i);
         const double* __restrict__ wr = W + i * n_out + j0;
@@ -445,11 +470,7 @@ __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const
           e = fma(w, dl[jj], e);
         }
         LD(r.EPS + i) += e;
-        if (JT != nullptr && active) {
-#pragma unroll
-          for (int jj = 0; jj < JB; ++jj)
-            if (j0 + jj < n_out) jt_store(c, JT, ldj, L.off_kernel + i * n_out + j0 + jj, n, a * dl[jj]);
-        }
+        if (JT != nullptr && active) jt_store_block(c, JT, L.off_kernel + i * n_out + j0, nj, dl, a);
       }
     }
     if (k > 0) {
@@ -583,6 +604,8 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_eval_kernel(const Flow
   const int64_t n = (int64_t)blockIdx.x * lanes + c.lane;
   const bool active = lane_ok && n < N;
   const int64_t nn = (n < N) ? n : (N - 1);
+  c.joff = (uint32_t)n * (jt_f32 ? 4u : 8u);
+  c.jpitch = ldj * (jt_f32 ? 4 : 8);
 
   // wave 0 owns the per-sample state and the scalar results; all waves walk the same sequence of stages
   double lp_val = 0.0;
