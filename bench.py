@@ -123,7 +123,12 @@ def cpu_baseline(theta_cpu, inds_up, inds_down):
     SExp = Ow.T @ Ow / n_gemm                      # tdvp.py:47
     t_gram = time.perf_counter() - t0
     t0 = time.perf_counter()
-    ev, Vm = np.linalg.eigh(S0.numpy())            # tdvp.py:61-64
+    try:                                           # numpy's OpenBLAS pool is separate from torch's: same thread cap, or the eigh runs 4x slower
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=cores):
+            ev, Vm = np.linalg.eigh(S0.numpy())    # tdvp.py:61-64
+    except ImportError:
+        ev, Vm = np.linalg.eigh(S0.numpy())
     t_eigh = time.perf_counter() - t0
     Vt = torch.from_numpy(Vm)
     t0 = time.perf_counter()
