@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle's many small CPU ops (vmap(grad), eigh of a few hundred rows) are far slower on a pool as wide as the host's
+    # 256 hardware threads than on a handful of cores
+    import torch
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
 
 
 @pytest.fixture(scope="session")
