@@ -14,6 +14,11 @@ def pytest_configure(config):
     # 256 hardware threads than on a handful of cores
     import torch
     torch.set_num_threads(min(8, os.cpu_count() or 1))
+    try:                       # numpy's OpenBLAS pool is separate (the oracle's host eigh)
+        from threadpoolctl import threadpool_limits
+        config._blas_limit = threadpool_limits(limits=min(8, os.cpu_count() or 1))
+    except ImportError:
+        pass
 
 
 @pytest.fixture(scope="session")
