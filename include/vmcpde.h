@@ -142,7 +142,8 @@ int64_t vmcpde_gram_workspace_bytes(int32_t P, int64_t n_samples);
  * jt_f32 = 1: JT holds fp32 values (ldj in elements), widened to fp64 while staging; products and sums are fp64.
  * jt_f32 = 2 ("f32 blocks", only with c = w = NULL, otherwise treated as 1): fp32 products are summed in fp32 by the matrix pipe
  *   over blocks of <= 128 samples and the block sums are accumulated in fp64 -- twice the MFMA rate; ldj must be a multiple of 4 and
- *   the row padding [n_samples, ldj) must be zero.  S agrees with the fp64 result on the same fp32 data to ~1e-8 relative. */
+ *   the row padding [n_samples, ldj) must be zero.  S agrees with the fp64 result on the same fp32 data to ~1e-8 relative, but is
+ *   no longer exactly positive semi-definite: factor it only with a relative diagonal shift >= 1e-4. */
 int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t P, int64_t n_samples, const double* c, const double* w,
                 double* packed, void* workspace, int64_t workspace_bytes, void* stream);
 /* tdvp.py:45-46,50-51: S[i][j] = packed/Ntot - d_i d_j (full symmetric, both triangles written) with
