@@ -277,7 +277,10 @@ class TDVP:
             try:
                 self.ev, self.V = torch.linalg.eigh(S)                        # tdvp.py:59 (rocSOLVER)
                 done = True
-            except RuntimeError:                                              # rocSOLVER did not converge: fall back to LAPACK
+            except RuntimeError as exc:                                       # rocSOLVER did not converge on this (singular) S
+                import warnings
+                warnings.warn(f"rocSOLVER eigh failed ({str(exc)[:80]}); using host LAPACK for this call, as the reference does "
+                              f"with diagonalizeOnDevice=False (tdvp.py:61-64)", RuntimeWarning)
                 done = False
         if not done:
             with _lapack_threads(P):
