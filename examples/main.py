@@ -40,8 +40,10 @@ def main():
     ap.add_argument("--wdir", default=None)
     ap.add_argument("--resume", action="store_true")
     ap.add_argument("--hidden", type=int, nargs="*", default=None, help="widths of the conditioner MLPs (default: the reference's (dim//2,))")
-    ap.add_argument("--diagonal-shift", type=float, default=0.0,
-                    help="tdvp.py:50-51; > 1e-10 selects the on-device Cholesky (default 0: the reference's spectral pseudo-inverse)")
+    ap.add_argument("--diagonal-shift", type=float, default=0.0, help="tdvp.py:50-51: S += shift * diag(S)")
+    ap.add_argument("--solver", default="auto", choices=["auto", "eigh", "cholesky"],
+                    help="auto/eigh: the reference's spectral pseudo-inverse; cholesky: on-device regularised Cholesky (use with --diagonal-shift)")
+    ap.add_argument("--save-every", type=int, default=1, help="write infos.npz every this many steps (and at the end)")
     ap.add_argument("--svd-tol", type=float, default=1e-11,
                     help="spectral cut-off / absolute floor; wide networks (P in the thousands) need ~1e-6 with --diagonal-shift 1e-4")
     args = ap.parse_args()
@@ -63,7 +65,7 @@ def main():
 
     dt, maxStep = 1e-7, 1e-2                                                                                                               # main.py:108-118
     myStepper = stepper.FixedStepper(timeStep=dt, mode='Heun', maxStep=maxStep, increase_fac=1.3)
-    tdvpEq = tdvp.TDVP(diagonalShift=args.diagonal_shift, svdTol=args.svd_tol)
+    tdvpEq = tdvp.TDVP(diagonalShift=args.diagonal_shift, svdTol=args.svd_tol, solver=args.solver)
     timings = util.Timings()
     evolutionEq = evolutionEq_mod.EvolutionEquation(dim=dim, name=m["evolution_type"])
     nSamplesTDVP = nSamplesObs = args.samples
@@ -74,10 +76,14 @@ def main():
     infos = {"times": [], "ev": [], "snr": [], "solver_res": [], "tdvp_error": [], "dist_params": []}                                     # main.py:157
     ckpt = os.path.join(wdir, "checkpoint.pt")
     if args.resume and os.path.exists(ckpt):
-        st = torch.load(ckpt)
+        st = torch.load(ckpt, weights_only=False)
         vState.set_parameters(st["theta"])
         t, myStepper.dt, smp._calls = st["t"], st["dt"], st["sampler_calls"]
-        print(f"resumed at t = {t}")
+        infos = st.get("infos", infos)          # the run record continues where the interrupted run stopped
+        print(f"resumed at t = {t} with {len(infos['times'])} recorded steps")
+
+    def host(v):
+        return v.detach().cpu() if torch.is_tensor(v) else v
     while t < args.t_end + dt:                                                                                                             # main.py:159
         t1 = time.perf_counter()
         dp, dt, info = myStepper.step(0, tdvpEq, vState.get_parameters(), evolutionEq=evolutionEq, psi=vState, nSamplesTDVP=nSamplesTDVP,
@@ -95,17 +101,23 @@ def main():
         print(f"\t > dist params = {vState.params['params']['dist_params']}")
         print(f"\t > Means = {info['x1']}")
         for key in info.keys():
-            infos.setdefault(key, []).append(info[key])
+            infos.setdefault(key, []).append(host(info[key]))
         if tdvpEq.ev is not None:      # spectral quantities exist on the eigh path only (not with --diagonal-shift)
-            infos["ev"].append(tdvpEq.ev)
-            infos["snr"].append(tdvpEq.snr)
-        infos["solver_res"].append(tdvpEq.solverResidual)
-        infos["tdvp_error"].append(tdvpEq.tdvp_error)
-        infos["dist_params"].append(vState.params['params']['dist_params'].clone())
+            infos["ev"].append(host(tdvpEq.ev))
+            infos["snr"].append(host(tdvpEq.snr))
+        infos["solver_res"].append(host(tdvpEq.solverResidual))
+        infos["tdvp_error"].append(host(tdvpEq.tdvp_error))
+        infos["dist_params"].append(host(vState.params['params']['dist_params'].clone()))
         t = t + dt
-        torch.save({"theta": vState.get_parameters().cpu(), "t": t, "dt": myStepper.dt, "sampler_calls": smp._calls}, ckpt)
+        # checkpoint (parameters, clock, sampler stream position AND the run record) -- written next to the target and renamed,
+        # so a kill in the middle of the write leaves the previous checkpoint intact
+        tmp = ckpt + ".tmp"
+        torch.save({"theta": vState.get_parameters().cpu(), "t": t, "dt": myStepper.dt, "sampler_calls": smp._calls, "infos": infos}, tmp)
+        os.replace(tmp, ckpt)
+        if len(infos["times"]) % args.save_every == 0:
+            util.store_infos(wdir, infos)
     util.store_infos(wdir, infos)                                                                                                          # main.py:209
-    print("wrote", wdir + "infos.npz")
+    print("wrote", os.path.join(wdir, "infos.npz"))
 
 
 if __name__ == "__main__":

@@ -473,8 +473,16 @@ class TDVPOracle:
     snrTol: float = 2e0
     svdTol: float = 1e-11
     diagonalShift: float = 0.0
+    frozen: tuple = ()       # NOT in the reference's tdvp.py: flat indices whose Jacobian columns are identically zero.  Emulates the
+                             # latent covariance S = I + A A^T the published diffusion runs were made with (main.py:55-57 "latent
+                             # space covariance matrix: Diffusion: np.eye(..) + A @ A.T"): at the initial A = 0, dS = dA A^T + A dA^T
+                             # = 0, so dlogp/dA = 0, the pseudo-inverse (tdvp.py:82) never moves A, and the run equals the
+                             # checked-out L L^T model (util.py:21-26) with L, L_diag held at 0.
 
     def get_tdvp_equation(self, Eloc, gradients, logProbs, N):
+        if len(self.frozen):
+            gradients = gradients.clone()
+            gradients[..., list(self.frozen)] = 0.0
         self.ElocMean = Eloc.sum() / N                                   # :37  mpi_wrapper.py:166-193
         self.ElocMeanAbs = Eloc.abs().sum() / N                          # :38
         self.ElocVar = ((Eloc - self.ElocMean) ** 2).sum() / N           # :39  mpi_wrapper.py:196-245

@@ -23,7 +23,7 @@ def main():
     with h5py.File(REF + "data_diffusion/dim8_Gauss_NsamplesTDVP10000_NsamplesObs10000/infos.hdf5", "r") as f:
         g = dict(times=f["times"][:], entropy=f["entropy"][:], covar_diag=np.diagonal(f["covar"][:], axis1=1, axis2=2).copy(),
                  tdvp_error=f["tdvp_error"][:], solver_res=f["solver_res"][:], ev_first=f["ev"][0], ev_last=f["ev"][-1],
-                 x1_last=f["x1"][-1])
+                 x1_last=f["x1"][-1], snr_first=f["snr"][0], x1=f["x1"][:], ev_step20=f["ev"][20], snr_step20=f["snr"][20])
     np.savez_compressed(os.path.join(OUT, "published_diffusion_d8_gauss.npz"), **g)
     with h5py.File(REF + "data_diffusion/dim8_StudentT_nu2_NsamplesTDVP10000_NsamplesObs10000/infos.hdf5", "r") as f:
         s = dict(times=f["times"][:], entropy=f["entropy"][:], dist_params=f["dist_params"][:, 0], tdvp_error=f["tdvp_error"][:],

@@ -81,7 +81,19 @@ def test_flow_and_rhs_against_committed_vectors(case):
         assert np.allclose(tp.ev.cpu().numpy()[big], evg[big], rtol=1e-6, atol=0)
         # S is rank deficient: the update is compared in the S-norm
         du = upd.cpu() - torch.as_tensor(GOLD[f"{pre}/update"])
-        assert float(torch.linalg.norm(tp.S0.cpu() @ du)) < 1e-8 * np.linalg.norm(GOLD[f"{pre}/F0"]), name
+        assert float(torch.linalg.norm(tp.S0.cpu() @ du)) < 1e-9 * np.linalg.norm(GOLD[f"{pre}/F0"]), name
+        # ... and, with the TDVP error, restricted to the modes with lambda > 1e-9 lambda_max at SURVEY's 1e-9 / 1e-10
+        Vw = tp.V.cpu()[:, torch.as_tensor(tp.ev.cpu().numpy() > 1e-9 * float(tp.ev[-1]))]
+        S0c, F0c = tp.S0.cpu(), tp.F0.cpu()
+        msq = float(tp.ElocVar) + float(tp.ElocMean) ** 2
+
+        def restricted(u):
+            uw = Vw @ (Vw.T @ u)
+            return uw, float(1 + (uw @ S0c @ uw - 2 * F0c @ uw) / msq)
+
+        (uw_p, err_p), (uw_g, err_g) = restricted(upd.cpu()), restricted(torch.as_tensor(GOLD[f"{pre}/update"]))
+        assert float(torch.linalg.norm(S0c @ (uw_p - uw_g))) < 1e-9 * np.linalg.norm(GOLD[f"{pre}/F0"]), name
+        assert abs(err_p - err_g) < 1e-10, name
         # tdvp_error = 1 - F^T S^+ F / <E^2> feels the eigenvalues that sit on the soft cut-off (round-off level, H2)
         assert abs(float(tp.tdvp_error) - float(GOLD[f"{pre}/tdvp_error"])) < 1e-6, name
 

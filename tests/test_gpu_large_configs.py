@@ -1,0 +1,235 @@
+"""GPU tests at BASELINE config 3 (P = 16 181, hidden (43,43)) and config 4's per-GPU shard (d = 6, hidden (19,19), P = 4155,
+32 768 samples): the code paths only large problems reach -- `chol_strip_kernel<32>` (P >~ 4350), the side-stream trailing
+update of the blocked Cholesky (P >~ 6000), the one-workgroup-per-CU flow geometry of the (43,43) net, the Gram kernel without
+sample splits.  Reference shapes: var_state.py:110-124; tdvp.py:36-94.
+
+Oracle comparisons run at sizes the CPU oracle finishes in seconds; the full-size runs are checked through size-independent
+properties (||L L^T v - A v||, S v = J^T (J v), additivity over sample splits, solver residual, pinned-pivot count)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from vmc_pde_amd import _native as nat
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _pad(v, m):
+    return (v + m - 1) // m * m
+
+
+def _spd_gpu(P, seed, K=1024, ridge=0.05):
+    """A = X X^T / K + ridge * diag(1..2): positive definite, condition ~1e2-1e3, built on the device (2 GiB at P = 16181)."""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    X = torch.randn((P, K), generator=g, dtype=torch.float64, device=DEV)
+    A = X @ X.T / K
+    A += torch.diag(ridge * (1.0 + torch.arange(P, dtype=torch.float64, device=DEV) / P))
+    return A
+
+
+def _factor(A, P):
+    Pp = _pad(P, 128)
+    Ap = torch.zeros((Pp, Pp), dtype=torch.float64, device=DEV)
+    Ap[:P, :P] = A
+    need = nat.lib().vmcpde_chol_workspace_bytes(P)
+    ws = torch.empty(need // 8, dtype=torch.float64, device=DEV)
+    info = torch.zeros(1, dtype=torch.int32, device=DEV)
+    nat.call("vmcpde_cholesky", nat.ptr(Ap), Pp, P, nat.ptr(info), nat.ptr(ws), need, nat.stream())
+    return Ap, Pp, ws, need, info
+
+
+@pytest.mark.parametrize("P", [4400, 6300, 16181])
+def test_cholesky_large_P_against_rocsolver(P):
+    # 4400: chol_strip_kernel<32>; 6300: first panels take the side-stream branch; 16181: BASELINE config 3
+    A = _spd_gpu(P, P)
+    Ap, Pp, ws, need, info = _factor(A, P)
+    assert int(info.item()) == 0
+    L = torch.tril(Ap[:P, :P])
+    Lref = torch.linalg.cholesky(A)
+    assert float((L - Lref).abs().max() / Lref.abs().max()) < 1e-11
+    del Lref
+    g = torch.Generator(device=DEV).manual_seed(1)
+    v = torch.randn(P, generator=g, dtype=torch.float64, device=DEV)
+    Av = A @ v
+    assert float(torch.linalg.norm(L @ (L.T @ v) - Av) / torch.linalg.norm(Av)) < 1e-13
+    # and the triangular solves at this size
+    u = torch.empty(P, dtype=torch.float64, device=DEV)
+    nat.call("vmcpde_chol_solve", nat.ptr(Ap), Pp, P, nat.ptr(Av), nat.ptr(u), nat.ptr(ws), need, nat.stream())
+    assert float(torch.linalg.norm(u - v) / torch.linalg.norm(v)) < 1e-9
+
+
+@pytest.mark.parametrize("P", [300, 1000])
+def test_cholesky_side_stream_branch_on_small_matrices(P, monkeypatch):
+    # VMCPDE_CHOL_FUSED_MAX=1 sends every trailing update with more than one tile through the fork/join branch
+    # (chol_syrk_kernel on the caller's stream, the next diagonal block on the device's side stream)
+    monkeypatch.setenv("VMCPDE_CHOL_FUSED_MAX", "1")
+    rng = np.random.default_rng(P)
+    Q, _ = np.linalg.qr(rng.standard_normal((P, P)))
+    Amat = (Q * np.logspace(0, -4, P)) @ Q.T
+    Ap, Pp, ws, need, info = _factor(torch.as_tensor(Amat).to(DEV), P)
+    assert int(info.item()) == 0
+    L = np.tril(Ap.cpu().numpy()[:P, :P])
+    Lref = np.linalg.cholesky(Amat)
+    assert np.abs(L - Lref).max() < 1e-10 * np.abs(Lref).max()
+    monkeypatch.delenv("VMCPDE_CHOL_FUSED_MAX")
+    Ap2, *_ = _factor(torch.as_tensor(Amat).to(DEV), P)
+    assert torch.equal(Ap2[:P, :P].tril(), Ap[:P, :P].tril())       # both schedules do the same arithmetic
+
+
+def _gram_full(JT, ldj, P, N):
+    npk = nat.lib().vmcpde_gram_packed_doubles(P)
+    packed = torch.empty(npk, dtype=torch.float64, device=DEV)
+    need = nat.lib().vmcpde_gram_workspace_bytes(P, N)
+    ws = torch.empty(max(need // 8, 1), dtype=torch.float64, device=DEV)
+    nat.call("vmcpde_gram", nat.ptr(JT), ldj, 0, P, N, None, None, nat.ptr(packed), nat.ptr(ws), ws.numel() * 8, nat.stream())
+    return packed
+
+
+def test_gram_config3_width_matvec_and_split_additivity():
+    P, N = 16181, 4096
+    Pp = _pad(P, 128)
+    g = torch.Generator(device=DEV).manual_seed(7)
+    JT = torch.zeros((Pp, N), dtype=torch.float64, device=DEV)
+    JT[:P] = torch.randn((P, N), generator=g, dtype=torch.float64, device=DEV) + 0.25
+    packed = _gram_full(JT, N, P, N)
+    S = torch.empty((Pp, Pp), dtype=torch.float64, device=DEV)
+    zero = torch.zeros(P, dtype=torch.float64, device=DEV)
+    nat.call("vmcpde_gram_finalize", nat.ptr(packed), nat.ptr(zero), None, None, None, None, None, P, 1.0, 0.0, nat.ptr(S), Pp, None, 0,
+             None, None, nat.stream())
+    v = torch.randn(P, generator=g, dtype=torch.float64, device=DEV)
+    ref = JT[:P] @ (JT[:P].T @ v)
+    assert float(torch.linalg.norm(S[:P, :P] @ v - ref) / torch.linalg.norm(ref)) < 1e-13
+    assert torch.equal(S[:P, :P], S[:P, :P].T)
+    # sum over two sample ranges = the whole (the contraction is linear in the sample set); ragged split point on purpose
+    n1 = 1500
+    A1 = torch.zeros((Pp, _pad(n1, 16)), dtype=torch.float64, device=DEV)
+    A1[:, :n1] = JT[:, :n1]
+    A2 = JT[:, n1:].contiguous()
+    n2 = N - n1
+    ld2 = _pad(n2, 16)
+    if ld2 != n2:
+        B = torch.zeros((Pp, ld2), dtype=torch.float64, device=DEV)
+        B[:, :n2] = A2
+        A2 = B
+    p1 = _gram_full(A1, A1.shape[1], P, n1)
+    p2 = _gram_full(A2, A2.shape[1], P, n2)
+    tiles = packed.view(-1, 128, 128)
+    both = (p1 + p2).view(-1, 128, 128)
+    nb = Pp // 128
+    diag_ids = torch.tensor([i * (i + 1) // 2 + i for i in range(nb)], device=DEV)
+    mask = torch.ones(tiles.shape[0], dtype=torch.bool, device=DEV)
+    mask[diag_ids] = False
+    scale = float(tiles[mask].abs().max())
+    assert float((tiles[mask] - both[mask]).abs().max()) < 1e-12 * scale          # off-diagonal tiles: every entry is defined
+    low = torch.tril(torch.ones(128, 128, dtype=torch.bool, device=DEV))            # diagonal tiles: lower triangle only
+    assert float(((tiles[diag_ids] - both[diag_ids]) * low).abs().max()) < 1e-12 * scale
+
+
+# ---- flow kernels of the two large nets against the autodiff oracle ---------------------------------------------------------
+LARGE_NETS = [
+    (2, 4, (43, 43), "Gauss", "no_add"),     # BASELINE C3 (P = 16 181): 140 KB of LDS per 64 samples, one workgroup per CU
+    (6, 4, (19, 19), "Gauss", "no_add"),     # BASELINE C4 (P = 4155)
+]
+
+
+@pytest.mark.parametrize("cfg", LARGE_NETS)
+def test_flow_parity_large_nets(cfg):
+    from oracle import vmc_oracle as O
+    from helpers import make_spec, random_theta, make_varstate, rel_err
+    dim, depth, hidden, latent, coupling = cfg
+    n = 40
+    off = np.linspace(-0.5, 0.7, dim)
+    spec = make_spec(dim, depth, hidden, latent=latent, coupling=coupling, offset=off, seed=11)
+    th = random_theta(spec, 11)
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn(1, n, dim, generator=g, dtype=torch.float64) * 0.8 + torch.as_tensor(off)
+    vo = O.VarStateOracle(spec, th)
+    vs = make_varstate(spec, th)
+    assert vs.numParameters == {(43, 43): 16181, (19, 19): 4155}[hidden]
+    x_o, lp_o = vo.flow_sample(z)
+    x_p, lp_p = vs.flow_sample(z)
+    assert rel_err(x_p, x_o) < 1e-12 and rel_err(lp_p, lp_o) < 1e-12
+    lo, go, Jo = vo(x_o, "eval_coordgrads")
+    lp, gp, Jp = vs(x_o, mode="eval_coordgrads")
+    assert rel_err(lp, lo) < 1e-12 and rel_err(gp, go) < 1e-11
+    assert float((Jp.cpu() - Jo).abs().max()) < 1e-11 * float(Jo.abs().max())
+    Ho, Hp = vo.hessian(x_o), vs.hessian(x_o)
+    assert float((Hp.cpu() - Ho).abs().max()) < 1e-10 * float(Ho.abs().max())
+
+
+def test_tdvp_rhs_parity_config4_net():
+    """One TDVP right-hand side of the C4 network (d = 6 Kramers problem, P = 4155) at N = 512 against the oracle."""
+    import vmc_pde_amd as V
+    from oracle import vmc_oracle as O
+    from helpers import make_spec, random_theta, make_varstate, FixedSampler, rel_err
+    dim, N, eq = 6, 512, "advection_hamiltonian_wDiss"
+    spec = make_spec(dim, 4, (19, 19), offset=np.linspace(0.4, -0.3, dim), seed=3)
+    th = random_theta(spec, 3, out_scale=0.03)
+    g = torch.Generator().manual_seed(3)
+    z = O.latent_from_normals(spec, th, torch.randn(N, dim, generator=g, dtype=torch.float64))
+    eo, ep = O.EvolutionEquationOracle(dim, eq), V.EvolutionEquation(dim=dim, name=eq)
+    eo.eqParams[eq]["params"]["lam"] = ep.eqParams[eq]["params"]["lam"] = 0.1
+    # shifted system (tdvp.py:50-51): the spectral answer of the oracle and the on-device Cholesky solve the same matrix
+    shift = 1e-4
+    to = O.TDVPOracle(diagonalShift=shift)
+    upd_o, _ = to.rhs(th, 0.1, O.VarStateOracle(spec, th), eo, z)
+    vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()))
+    tp = V.TDVP(diagonalShift=shift, solver="cholesky")
+    upd_p, _ = tp(th.cuda(), 0.1, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None)
+    assert rel_err(tp.S0, to.S0) < 1e-11 and rel_err(tp.F0, to.F0) < 1e-10
+    assert int(tp.cholInfo.item()) == 0 and float(tp.solverResidual) < 1e-9
+    S = to.S0 + torch.diag(shift * torch.diag(to.S0))
+    exact = torch.linalg.solve(S + tp.svdTol * torch.diag(to.S0).max() * torch.eye(S.shape[0], dtype=S.dtype), to.F0)
+    assert float(torch.linalg.norm(upd_p.cpu() - exact) / torch.linalg.norm(exact)) < 1e-8
+
+
+def _full_size_call(dim, hidden, N, eq, lam):
+    import vmc_pde_amd as V
+    ups = [[int(v) for v in np.random.default_rng(b).permutation(dim)[: dim // 2]] for b in range(4)]
+    dns = [[i for i in range(dim) if i not in u] for u in ups]
+    off = np.zeros(dim)
+    sampler = V.Sampler(key=1, dim=dim, name="Gauss", mcmc_info={"offset": off, "bound": 0.25})
+    vs = V.VarState(sampler, dim, 1, 4, network_args=dict(intmediate=hidden, offset=off, latentSpaceName="Gauss", dim=dim),
+                    inds_up=ups, inds_down=dns)
+    th = vs.net.init(1, out_scale=0.1)
+    vs.set_parameters(th)
+    ep = V.EvolutionEquation(dim=dim, name=eq)
+    ep.eqParams[eq]["params"]["lam"] = lam
+    tp = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky")
+    out = []
+    for _ in range(2):          # second call: lagged centring + uncentred DMA Gram + fused moments (the steady state)
+        upd, _ = tp(th, 0.0, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+        torch.cuda.synchronize()
+        out.append((upd.clone(), float(tp.solverResidual), int(tp.cholInfo.item()), float(tp.tdvp_error)))
+    return vs, tp, out
+
+
+def test_full_size_config3_tdvp_call():
+    """BASELINE config 3 at full size: P = 16 181, 65 536 samples (J = 8.5 GB, S = 2.1 GB) -- sample, flow, Gram, Cholesky."""
+    vs, tp, out = _full_size_call(2, (43, 43), 65536, "advection_hamiltonian_wDiss", 0.1)
+    assert vs.numParameters == 16181
+    for upd, resid, info, err in out:
+        assert torch.isfinite(upd).all() and info == 0 and resid < 1e-8 and 0.0 <= err < 1.0
+    assert tp._uncentred_ok       # the second call ran the steady-state path
+    # same samples are redrawn with a new stream id, so the two updates agree to Monte-Carlo accuracy only
+    assert float(torch.linalg.norm(out[0][0] - out[1][0]) / torch.linalg.norm(out[0][0])) < 0.5
+    # S v = J^T (J v) / N - mean (mean . v) on the retained Jacobian of the last call
+    z = tp._lazy
+    P, n = z["P"], z["n"]
+    g = torch.Generator(device=DEV).manual_seed(3)
+    v = torch.randn(P, generator=g, dtype=torch.float64, device=DEV)
+    J = z["JT"][:P, :n]
+    ref = J @ (J.T @ v) / n - z["mean"] * (z["mean"] @ v)
+    assert float(torch.linalg.norm(tp.S0 @ v - ref) / torch.linalg.norm(ref)) < 1e-10
+
+
+def test_full_size_config4_shard_tdvp_call():
+    """BASELINE config 4, one GPU's shard: d = 6, hidden (19,19), P = 4155, 32 768 samples."""
+    vs, tp, out = _full_size_call(6, (19, 19), 32768, "advection_hamiltonian_wDiss", 0.0)
+    assert vs.numParameters == 4155
+    for upd, resid, info, err in out:
+        assert torch.isfinite(upd).all() and info == 0 and resid < 1e-8 and 0.0 <= err < 1.0
+    assert tp._uncentred_ok

@@ -41,7 +41,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     V, vs, eq = _problem()
     res = {}
-    for name, kw in (("chol", dict(diagonalShift=1e-5)), ("eigh", dict(solver="eigh"))):
+    for name, kw in (("chol", dict(diagonalShift=1e-5, solver="cholesky")), ("eigh", dict(solver="eigh"))):
         res[name] = _two_calls(V, vs, eq, kw)
     q.put((rank, {k: [v.numpy() if torch.is_tensor(v) else v for v in vals] for k, vals in res.items()}))   # by value
     dist.barrier()
@@ -50,7 +50,7 @@ def _worker(rank, world, port, q):
 
 def test_two_ranks_match_single_rank():
     V, vs, eq = _problem()
-    single = {name: _two_calls(V, vs, eq, kw) for name, kw in (("chol", dict(diagonalShift=1e-5)), ("eigh", dict(solver="eigh")))}
+    single = {name: _two_calls(V, vs, eq, kw) for name, kw in (("chol", dict(diagonalShift=1e-5, solver="cholesky")), ("eigh", dict(solver="eigh")))}
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

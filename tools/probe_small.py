@@ -7,7 +7,7 @@ dim, offset, N = 6, np.array([1.0, 0.0, 1.0, 0.0, 1.0, 0.0]), 10000
 sampler = V.Sampler(key=1, dim=dim, name="Gauss", mcmc_info={"offset": offset, "bound": 0.25})
 vs = V.VarState(sampler, dim, 1, 4, network_args={"intmediate": (3,), "offset": offset, "latentSpaceName": "Gauss", "dim": dim, "different_add": True})
 eq = V.EvolutionEquation(dim=dim, name="advection_hamiltonian_wDiss")
-for name, tdvp in (("cholesky", V.TDVP(diagonalShift=1e-4, svdTol=1e-8)), ("eigh host", V.TDVP()), ("eigh device", V.TDVP(diagonalizeOnDevice=True))):
+for name, tdvp in (("cholesky", V.TDVP(diagonalShift=1e-4, svdTol=1e-8, solver="cholesky")), ("eigh host", V.TDVP()), ("eigh device", V.TDVP(diagonalizeOnDevice=True))):
     th = vs.get_parameters()
     kw = dict(evolutionEq=eq, psi=vs, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
     for _ in range(5): tdvp(th, 0.0, **kw)

@@ -42,7 +42,7 @@ def tdvp_run(vs, t_marks, shift=1e-4, N=65536, max_step=1e-2):
     dim = 2
     eq = V.EvolutionEquation(dim=dim, name="advection_hamiltonian_wDiss")
     eq.eqParams["advection_hamiltonian_wDiss"]["params"]["lam"] = LAM
-    tdvp = V.TDVP(diagonalShift=shift, svdTol=float(os.environ.get("SVD_TOL", "1e-6")))
+    tdvp = V.TDVP(diagonalShift=shift, svdTol=float(os.environ.get("SVD_TOL", "1e-6")), solver="cholesky")
     if os.environ.get("ADAPTIVE"):       # the reference's error-controlled stepper (stepper.py:20-91, tol as main.py:109)
         stepper = V.AdaptiveHeun(timeStep=1e-5, tol=float(os.environ["ADAPTIVE"]), maxStep=max_step)
     else:

@@ -81,6 +81,26 @@ struct LatentCache {
   double dlognorm_dtau;  // d lognorm / d dist_params[0] (Student-t only)
 };
 
+// Per-GPU state of the library (side stream + fork/join events of the Cholesky lookahead, "function attributes already
+// raised" flags).  HIP function attributes, streams and events belong to one device, so they are keyed by hipGetDevice()
+// and created under a lock: a process may drive several GPUs and call from several threads (one stream per thread).
+struct DeviceCtx {
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool attr_chol = false, attr_gram = false, attr_gram_f32 = false, attr_gram_dma = false, attr_solve = false;
+  int flow_eval_lds = 0, flow_sample_lds = 0;   // largest dynamic-LDS size the flow kernels were raised to
+};
+// returns nullptr (and sets the error string) if the current device cannot be queried
+DeviceCtx* device_ctx();
+struct DeviceCtxLock {   // serialises first-use initialisation on one device
+  DeviceCtxLock();
+  ~DeviceCtxLock();
+};
+
+// integer tuning knob from the environment, read on every call (a getenv is ~100 ns; a cached static would freeze the
+// value of whichever call came first in the process)
+int env_int(const char* name, int fallback);
+
 }  // namespace vmcpde
 
 struct vmcpde_model {

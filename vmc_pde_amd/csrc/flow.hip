@@ -831,7 +831,7 @@ int pick_lanes(int total_units, int wgt_doubles, int waves, int* lds_bytes) {
     if (wg > max_wg) wg = max_wg;
     if (l * wg > best) { best = l * wg; lanes = l; }
   }
-  if (const char* e = getenv("VMCPDE_FLOW_LANES")) lanes = atoi(e);   // tuning knob
+  lanes = env_int("VMCPDE_FLOW_LANES", lanes);   // tuning knob
   *lds_bytes = (int)((int64_t)total_units * lanes * 8 + fixed);
   return lanes;
 }
@@ -850,6 +850,9 @@ extern "C" int vmcpde_flow_eval_config(const vmcpde_model* m, int n_dirs, int* l
 }
 
 int vmcpde_prepare_latent_internal(vmcpde_model* m, const double* theta, hipStream_t st) {
+  int dev = -1;
+  VMC_CHECK_HIP(hipGetDevice(&dev));     // the flow program and the latent cache live on the GPU the handle was created on
+  VMC_REQUIRE(dev == m->device, "model handle belongs to GPU %d but the current device is %d (one handle per GPU)", m->device, dev);
   hipLaunchKernelGGL(latent_prepare_kernel, dim3(1), dim3(64), 0, st, m->dev, theta, m->cache);
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
@@ -871,8 +874,15 @@ extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const doub
   int bytes = 0;
   const int lanes = pick_lanes(r.total, r.wgt, pick_waves(m->host), &bytes);
   VMC_REQUIRE(bytes <= 160 * 1024, "network too wide for the LDS-resident flow kernel (%d B per sample lane)", r.total * 8);
-  if (bytes > 64 * 1024)
-    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)flow_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (bytes > 64 * 1024) {
+    DeviceCtx* ctx = device_ctx();
+    if (!ctx) return -2;
+    DeviceCtxLock lock;
+    if (bytes > ctx->flow_eval_lds) {
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)flow_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      ctx->flow_eval_lds = bytes;
+    }
+  }
   const int64_t grid = (n_samples + lanes - 1) / lanes;
   hipLaunchKernelGGL(flow_eval_kernel, dim3((unsigned)grid), dim3(64 * pick_waves(m->host)), bytes, st, m->dev, m->cache, theta, x, n_samples,
                      dirs, (hv ? n_dirs : 0), logp, g, hv, JT, ldj, (int)jt_f32, lanes, r);
@@ -890,8 +900,15 @@ extern "C" int vmcpde_flow_sample(vmcpde_model* m, const double* theta, const do
   int bytes = 0;
   const int lanes = pick_lanes(r.total, r.wgt, pick_waves(m->host), &bytes);
   VMC_REQUIRE(bytes <= 160 * 1024, "network too wide for the LDS-resident flow kernel");
-  if (bytes > 64 * 1024)
-    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)flow_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (bytes > 64 * 1024) {
+    DeviceCtx* ctx = device_ctx();
+    if (!ctx) return -2;
+    DeviceCtxLock lock;
+    if (bytes > ctx->flow_sample_lds) {
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)flow_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      ctx->flow_sample_lds = bytes;
+    }
+  }
   const int64_t grid = (n_samples + lanes - 1) / lanes;
   hipLaunchKernelGGL(flow_sample_kernel, dim3((unsigned)grid), dim3(64 * pick_waves(m->host)), bytes, st, m->dev, m->cache, theta, z, n_samples,
                      inv, x, logp, lanes, r);

@@ -62,7 +62,7 @@ GramPlan make_plan(int P, int64_t N, int slots /* resident workgroups: 256 CUs x
     }
     ns = pick;
   }
-  if (getenv("VMCPDE_GRAM_NSPLIT")) ns = atoi(getenv("VMCPDE_GRAM_NSPLIT"));   // tuning knob
+  ns = env_int("VMCPDE_GRAM_NSPLIT", (int)ns);   // tuning knob
   int64_t steps_per = (ksteps + ns - 1) / ns;
   g.chunk = steps_per * BK;
   g.nsplit = (int)((N + g.chunk - 1) / g.chunk);
@@ -371,20 +371,22 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
     out = static_cast<double*>(workspace);
   }
   hipStream_t st = (hipStream_t)stream;
-  static const int order = getenv("VMCPDE_GRAM_ORDER") ? atoi(getenv("VMCPDE_GRAM_ORDER")) : 1;   // tuning knob
+  const int order = env_int("VMCPDE_GRAM_ORDER", 1);   // tuning knob
   const int total = g.ntiles * g.nsplit;
   const int per_xcd = (order == 1) ? (g.ntiles + 7) / 8 : (total + 7) / 8;
   const int grid = (order == 1) ? per_xcd * 8 * g.nsplit : per_xcd * 8;
   // tuning knob: extra dynamic LDS forces one workgroup per CU (to measure what the co-resident partner is worth)
-  static const size_t lds_pad = getenv("VMCPDE_GRAM_LDSPAD") ? (size_t)atoi(getenv("VMCPDE_GRAM_LDSPAD")) : 0;
+  const size_t lds_pad = (size_t)env_int("VMCPDE_GRAM_LDSPAD", 0);
   const size_t lds_bytes = TILE_LDS_BYTES + lds_pad;
-  static bool attr_set = false;
-  if (!attr_set) {
+  DeviceCtx* ctx = device_ctx();
+  if (!ctx) return -2;
+  DeviceCtxLock lock;      // first-use attribute changes; held over the (asynchronous) launches below, which is harmless
+  if (!ctx->attr_gram || lds_pad) {
 #define VMC_ATTR(CEN, SCA, T) VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<CEN, SCA, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes))
     VMC_ATTR(false, false, double); VMC_ATTR(true, false, double); VMC_ATTR(false, true, double); VMC_ATTR(true, true, double);
     VMC_ATTR(false, false, float); VMC_ATTR(true, false, float); VMC_ATTR(false, true, float); VMC_ATTR(true, true, float);
 #undef VMC_ATTR
-    attr_set = true;
+    ctx->attr_gram = true;
   }
 #define VMC_LAUNCH_GRAM(CEN, SCA, T)                                                                                              \
   hipLaunchKernelGGL((gram_kernel<CEN, SCA, T>), dim3(grid), dim3(256), lds_bytes, st, static_cast<const T*>(JT), ldj, P, n_samples, c, w, \
@@ -397,19 +399,17 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
     else VMC_LAUNCH_GRAM(false, false, T);            \
   } while (0)
   if (f32blocks) {
-    static bool f32_attr = false;
-    if (!f32_attr) {
+    if (!ctx->attr_gram_f32) {
       VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_DMA_LDS_BYTES));
-      f32_attr = true;
+      ctx->attr_gram_f32 = true;
     }
     hipLaunchKernelGGL(gram_f32_kernel, dim3(grid), dim3(256), TILE_DMA_LDS_BYTES, st, static_cast<const double*>(JT), ldj / 2,
                        (n_samples + 1) / 2, g.ntiles, g.nsplit, g.chunk, total, per_xcd, order, out);
   } else if (dma) {
-    static const size_t dma_lds = 4 * DmaGeom<GRAM_BKD>::DT * sizeof(double) + lds_pad;
-    static bool dma_attr = false;
-    if (!dma_attr && dma_lds > 64 * 1024) {
+    const size_t dma_lds = 4 * DmaGeom<GRAM_BKD>::DT * sizeof(double) + lds_pad;
+    if ((!ctx->attr_gram_dma || lds_pad) && dma_lds > 64 * 1024) {
       VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds));
-      dma_attr = true;
+      ctx->attr_gram_dma = true;
     }
     hipLaunchKernelGGL(gram_dma_kernel, dim3(grid), dim3(256), dma_lds, st, static_cast<const double*>(JT), ldj, n_samples, g.ntiles,
                        g.nsplit, g.chunk, total, per_xcd, order, out);

@@ -3,7 +3,9 @@
 // net.py:74-82 (SingleBlock.setup), net.py:196-207 (INNwProb.setup).
 #include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -18,6 +20,29 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+DeviceCtx g_ctx[MAX_DEVICES];
+std::mutex g_ctx_mutex;
+}  // namespace
+
+DeviceCtx* device_ctx() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+    set_error("device_ctx: cannot query the current HIP device");
+    return nullptr;
+  }
+  return &g_ctx[dev];
+}
+
+DeviceCtxLock::DeviceCtxLock() { g_ctx_mutex.lock(); }
+DeviceCtxLock::~DeviceCtxLock() { g_ctx_mutex.unlock(); }
+
+int env_int(const char* name, int fallback) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : fallback;
 }
 
 }  // namespace vmcpde

@@ -611,31 +611,39 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
   const size_t diag_lds = ((size_t)NB * DP + 4 * SB * 17 + 2 * SB) * sizeof(double);   // block + 4 wave-private tiles + 64-slot dump line
   static_assert(((size_t)NB * DP + 4 * SB * 17 + 2 * SB) * sizeof(double) >= TILE_DMA_LDS_BYTES, "the fused launch sizes its LDS for the diagonal block");
   const size_t strip_lds = (size_t)(NB + 32) * SP * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
-    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_strip_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds));
-    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_strip_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds));
-    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_syrk_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
-    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_DMA_LDS_BYTES));
-    attr_set = true;
+  DeviceCtx* ctx = device_ctx();
+  if (!ctx) return -2;
+  {
+    DeviceCtxLock lock;
+    if (!ctx->attr_chol) {
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_strip_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds));
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_strip_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds));
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_syrk_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_DMA_LDS_BYTES));
+      ctx->attr_chol = true;
+    }
+    if (ctx->side == nullptr) {
+      VMC_CHECK_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+      VMC_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      VMC_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
   }
   VMC_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), st));
   // Lookahead: the diagonal block of panel k+1 only depends on the first block column of panel k's trailing update.
   //  * up to FUSED_MAX_TILES tiles in the rest of that update: workgroup 0 of the same launch factors it
   //    (chol_syrk_diag_kernel) -- the update is short, the single-workgroup factorisation is the critical path;
   //  * more: the update is the critical path; it runs at two workgroups per CU on the caller's stream while the block is
-  //    factored on an internal side stream (fork/join with events anchored on the caller's stream, so that from outside
+  //    factored on this device's side stream (fork/join with events anchored on the caller's stream, so that from outside
   //    all work is ordered in `stream` as usual).
-  static const int diag_phase = getenv("VMCPDE_DIAG_PHASE") ? atoi(getenv("VMCPDE_DIAG_PHASE")) : 5;   // timing diagnostics only
-  static const int fused_max = getenv("VMCPDE_CHOL_FUSED_MAX") ? atoi(getenv("VMCPDE_CHOL_FUSED_MAX")) : FUSED_MAX_TILES;
-  static hipStream_t side = nullptr;
-  static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  if (side == nullptr) {
-    VMC_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    VMC_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-    VMC_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-  }
+#ifdef VMC_DIAG_PHASE_KNOB
+  const int diag_phase = env_int("VMCPDE_DIAG_PHASE", 5);   // timing diagnostics only (debug builds): < 5 gives wrong factors
+#else
+  const int diag_phase = 5;
+#endif
+  const int fused_max = env_int("VMCPDE_CHOL_FUSED_MAX", FUSED_MAX_TILES);
+  hipStream_t side = ctx->side;
+  hipEvent_t ev_fork = ctx->ev_fork, ev_join = ctx->ev_join;
   {
     const int n0 = (P < NB) ? P : NB;
     hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), diag_lds, st, A, lda, 0, n0, Linv, info, diag_phase);

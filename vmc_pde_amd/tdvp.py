@@ -54,7 +54,10 @@ class TDVP:
     svdTol: float = 1e-11
     diagonalShift: float = 0
     diagonalizeOnDevice: bool = False
-    solver: str = "auto"          # "eigh" (reference pseudo-inverse), "cholesky", or "auto" (cholesky iff diagonalShift > 1e-10)
+    solver: str = "auto"          # "eigh": the reference's spectral pseudo-inverse (tdvp.py:57-94) -- what "auto" selects, so that the
+                                  #   reference's constructor arguments solve the reference's system and publish ev / V / snr;
+                                  # "cholesky": explicit opt-in to the on-device regularised Cholesky (no eigenbasis, hence no SNR)
+    residualBound: float = 1e-6   # Cholesky path: a solver residual above this (or a NaN) is treated as a failed factorisation
     centering: str = "auto"       # "exact": global means before the Gram (an extra pass over J, + one tiny all-reduce when sharded)
                                   # "lagged": previous call's global mean as shift -> one pass, a single all-reduce per step
                                   # "auto": exact on the first call, lagged afterwards (algebraically identical, see finalize)
@@ -65,8 +68,20 @@ class TDVP:
                                   #   cancellation costs < 3 of fp64's 16 digits; centred otherwise
     fuseMoments: bool = True      # uncentred path: sum O and sum O (E - cE) ride in the syrk as two appended Jacobian rows
     f32BlockGram: bool = False    # with an fp32 Jacobian: fp32 MFMA sums over blocks of <= 128 samples, fp64 across blocks (2x MFMA rate)
+    frozenParameters: object = None   # flat parameter indices held fixed: their rows / columns of S and entries of F are zeroed, so
+                                  # both solvers return a zero update for them (the pseudo-inverse drops the zero modes, tdvp.py:82;
+                                  # the Cholesky pins or floors them).  Not a reference argument: the published diffusion runs used
+                                  # a latent covariance I + A A^T (main.py:55-57) whose gradient vanishes at the initial A = 0, which
+                                  # is this model with L, L_diag frozen.
 
     def __post_init__(self):
+        if self.solver not in ("auto", "eigh", "cholesky"):
+            raise ValueError(f"unknown solver {self.solver!r}")
+        if self.solver == "cholesky" and self.useSNR:
+            # tdvp.py:87-89: the SNR soft cut-off lives in the eigenbasis of S; a Cholesky factor has none
+            raise ValueError("useSNR=True needs the spectral solver (solver='eigh' or 'auto'); the Cholesky path has no eigenbasis")
+        self._guard_host = self._guard_event = None
+        self.cholInfo = None
         self._buf = {}
         self._c_prev = None
         self._lazy = None
@@ -158,6 +173,9 @@ class TDVP:
             else:
                 b["c"].copy_(self._c_prev)
                 b["cE"].copy_(self._cE_prev)
+            # health record of the previous solve (pinned pivots, residual): like the ratio check below its copy precedes this
+            # call's sampling and flow kernels in the stream, so waiting for it here does not idle the GPU
+            self._check_guard("previous step")
             shift_mode = self.gramShift
             if shift_mode == "auto":
                 if self._ratio_event is not None:
@@ -194,9 +212,19 @@ class TDVP:
             nat.call("vmcpde_gram_finalize", nat.ptr(b["packed"]), nat.ptr(b["rowsum"]), nat.ptr(b["rowdot"]), nat.ptr(b["sums"]),
                      nat.ptr(b["c"]), nat.ptr(c_gram), nat.ptr(b["cE"]), P, Ntot, float(self.diagonalShift), nat.ptr(b["S"]), b["Ppad"],
                      nat.ptr(b["A"]) if use_chol else None, b["Ppad"], nat.ptr(b["F"]), nat.ptr(b["mean"]), nat.stream())
+            if self.frozenParameters is not None:
+                idx = self._frozen_index(device)
+                b["S"][idx, :] = 0.0
+                b["S"][:, idx] = 0.0
+                b["F"][idx] = 0.0
+                if use_chol:
+                    b["A"][idx, :] = 0.0
+                    b["A"][:, idx] = 0.0
             if self.gramShift == "auto":     # asynchronous safety check for the next call: no host sync here
                 diag = torch.diagonal(b["S"])[:P]
                 m2 = b["mean"] ** 2
+                if self.frozenParameters is not None:
+                    m2[self._frozen_index(device)] = 0.0      # their variance was zeroed above; they take no part in the solve
                 ratio = torch.where(diag > 0, m2 / diag, torch.where(m2 > 0, torch.full_like(m2, float("inf")), torch.zeros_like(m2))).max()
                 if self._ratio_host is None:
                     self._ratio_host = torch.empty(1, dtype=global_defs.tReal).pin_memory()
@@ -211,15 +239,29 @@ class TDVP:
         self._c_prev, self._cE_prev = b["mean"].clone(), self.ElocMean.reshape(1).clone()
         self.F0 = b["F"][:P]
         self.S0 = b["S"][:P, :P]
-        self._lazy = dict(JT=JT, ldj=ldj, P=P, n=n, Ntot=Ntot, e=e, logp=logProbs.reshape(-1).contiguous(), b=b,
-                          mean=b["mean"], Emean=self.ElocMean)
+        # SExp / rhoVar / snr are evaluated lazily from the retained Jacobian, which is psi's per-N workspace (2 GB at C2: not
+        # copied).  The N-sized vectors are cloned; for the Jacobian the workspace generation is recorded and checked on use.
+        self._lazy = dict(JT=JT, ldj=ldj, P=P, n=n, Ntot=Ntot, e=e.clone(), logp=logProbs.reshape(-1).clone(), b=b,
+                          mean=b["mean"].clone(), Emean=self.ElocMean.clone(),
+                          owner=psi if jt is not None else None,
+                          gen=psi.workspace_generation(n) if jt is not None else None)
         self._SExp = self._rhoVar = self._snr = self._S = None
         return self.F0
+
+    def _frozen_index(self, device):
+        idx = getattr(self, "_frozen_idx", None)
+        if idx is None or idx.device != device:
+            idx = self._frozen_idx = torch.as_tensor(np.asarray(self.frozenParameters, dtype=np.int64), device=device)
+        return idx
 
     def _weighted_gram(self, w):
         """(1/N) sum_n w_n^2 O~_n O~_n^T over all ranks from the retained Jacobian (w = logp: tdvp.py:33,47; w = E~: the
         second moment behind rhoVar, tdvp.py:68-70)."""
         z = self._lazy
+        if z["owner"] is not None and z["owner"].workspace_generation(z["n"]) != z["gen"]:
+            raise RuntimeError("SExp / rhoVar / snr are computed lazily from the Jacobian of the last TDVP call, but the VarState "
+                               "has evaluated another batch of the same size since (its workspace was overwritten): read these "
+                               "attributes before calling psi(...), psi.hessian or psi.evaluate again")
         b, P = z["b"], z["P"]
         tmp = torch.zeros(b["npk"], dtype=global_defs.tReal, device=w.device)
         out = torch.zeros((b["Ppad"], b["Ppad"]), dtype=global_defs.tReal, device=w.device)
@@ -229,6 +271,10 @@ class TDVP:
             mpi.allreduce_sum_(tmp)
             nat.call("vmcpde_gram_finalize", nat.ptr(tmp), nat.ptr(zero), None, None, None, None, None, P, z["Ntot"], 0.0, nat.ptr(out),
                      b["Ppad"], None, 0, None, None, nat.stream())
+        if self.frozenParameters is not None:
+            idx = self._frozen_index(w.device)
+            out[idx, :] = 0.0
+            out[:, idx] = 0.0
         return out[:P, :P]
 
     @property
@@ -265,9 +311,39 @@ class TDVP:
         return self._snr
 
     def _solver(self):
-        if self.solver == "auto":
-            return "cholesky" if self.diagonalShift > 1e-10 else "eigh"
-        return self.solver
+        return "eigh" if self.solver == "auto" else self.solver
+
+    # ---- Cholesky health: pinned pivots and the solver residual ------------------------------------------------------
+    def _record_guard(self, info, residual):
+        """Queue (pinned-pivot count, residual) of this solve for the host without synchronising: checked by `_check_guard`
+        at the next host-side guard (the NaN check of `__call__`, or the start of the next solve when observables are off)."""
+        if self._guard_host is None:
+            self._guard_host = torch.empty(2, dtype=global_defs.tReal).pin_memory()
+            self._guard_dev = torch.empty(2, dtype=global_defs.tReal, device=residual.device)
+            self._guard_event = torch.cuda.Event()
+        self._guard_dev[0] = info[0]
+        self._guard_dev[1] = residual
+        self._guard_host.copy_(self._guard_dev, non_blocking=True)
+        self._guard_event.record()
+        self._guard_pending = True
+
+    def _check_guard(self, when):
+        """factor_inverse_32 (csrc/solve.hip) replaces every non-positive / NaN pivot by a unit row and only counts it, so an
+        indefinite or NaN-contaminated S gives a finite but wrong update: fail loudly instead of integrating on."""
+        if not getattr(self, "_guard_pending", False):
+            return
+        self._guard_event.synchronize()
+        self._guard_pending = False
+        pinned, resid = int(self._guard_host[0]), float(self._guard_host[1])
+        if not (resid <= self.residualBound):      # also catches NaN
+            raise FloatingPointError(f"on-device Cholesky failed ({when}): solver residual {resid:.3e} > {self.residualBound:g} with "
+                                     f"{pinned} pinned pivot(s); S + shift is not positive definite -- raise diagonalShift / svdTol "
+                                     f"or use solver='eigh'")
+        if pinned and not getattr(self, "_warned_pinned", False):
+            import warnings
+            warnings.warn(f"Cholesky pinned {pinned} parameter(s) with a non-positive pivot (dead or padded parameters; their update "
+                          f"is 0); residual {resid:.2e} is within bound", RuntimeWarning)
+            self._warned_pinned = True
 
     # ---- tdvp.py:57-71 -------------------------------------------------------------------------------------------
     def transform_to_eigenbasis(self, S, F, EOdata=None):
@@ -344,6 +420,8 @@ class TDVP:
             Su = Su + self._floor * update              # the system the Cholesky path solves
         tdvp_error = 1 + (update @ S0u - 2 * (self.F0 @ update)) / self._Esq_mean                      # tdvp.py:93
         residual = torch.linalg.norm(Su - F) / torch.linalg.norm(F)                                     # tdvp.py:94
+        if self._solver() == "cholesky":
+            self._record_guard(b["info"], residual)
         return update, residual, tdvp_error
 
     # ---- tdvp.py:96-164 ------------------------------------------------------------------------------------------
@@ -384,6 +462,7 @@ class TDVP:
         if not rhsArgs.get("observables", True):
             return update, {}
 
+        self._check_guard("this step")          # (the host synchronises for the NaN check below anyway)
         if bool(torch.isnan(update).any()):                                   # tdvp.py:136-141
             print(self.S0)
             print(self.F0)

@@ -1,4 +1,5 @@
 """Helpers (reference: vmc_fluids/util.py)."""
+import os
 import time
 
 import numpy as np
@@ -23,7 +24,10 @@ def store_infos(wdir, infos, name="infos.npz"):
     Written as .npz -- h5py is not part of the image; `np.load(...)[key]` replaces `h5py.File(...)[key][:]`."""
     def as_numpy(v):
         return v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
-    np.savez(wdir + name, **{key: np.asarray([as_numpy(v) for v in series]) for key, series in infos.items()})
+    target = os.path.join(wdir, name)
+    tmp = target + ".tmp.npz"          # np.savez appends .npz to names without it
+    np.savez(tmp, **{key: np.asarray([as_numpy(v) for v in series]) for key, series in infos.items()})
+    os.replace(tmp, target)
 
 
 class Timings:

@@ -50,10 +50,17 @@ class VarState:
                       JT=torch.zeros((_round_up(P, nat.GRAM_TILE), ldj), dtype=self.jacobian_dtype, device=self.device),
                       logp=torch.empty(n, dtype=global_defs.tReal, device=self.device),
                       g=torch.empty((n, self.dim), dtype=global_defs.tReal, device=self.device))
+            ws["gen"] = 0
             if len(self._ws) >= 2:   # at most two sample counts alive (TDVP + observables)
                 self._ws.pop(next(iter(self._ws)))
             self._ws[n] = ws
         return ws
+
+    def workspace_generation(self, n):
+        """(identity, write count) of the per-N workspace: changes whenever `evaluate` overwrites logp / g / the Jacobian of that
+        sample count, or the buffer is dropped.  TDVP's lazy SExp / rhoVar / snr check it before re-reading the Jacobian."""
+        ws = self._ws.get(n)
+        return None if ws is None else (id(ws), ws["gen"])
 
     def _dirs(self, dirs):
         """Device copy of a (D, d) direction set (cached by content)."""
@@ -71,6 +78,7 @@ class VarState:
         x = torch.as_tensor(coords, dtype=global_defs.tReal, device=self.device).reshape(-1, self.dim).contiguous()
         n = x.shape[0]
         ws = self._workspace(n)
+        ws["gen"] += 1
         D = 0
         hv = dirs_t = None
         if dirs is not None and len(dirs):
