@@ -157,6 +157,19 @@ int vmcpde_gram_finalize(const double* packed, const double* rowsum, const doubl
                          double diagonal_shift, double* S, int64_t lds, double* A_shifted, int64_t lda, double* F, double* mean,
                          void* stream);
 
+/* ---- mpi_wrapper.py:129-163 (global_sum) ---------------------------------------------------------------------- */
+/* The single collective of a TDVP step: packed[0..count) <- sum over the ranks of `comm`, in place, fp64, on `stream`
+ * (ncclAllReduce of RCCL over xGMI; replaces the reference's pmap psum + host-buffer MPI.Allreduce, ten calls per step).
+ * `packed` is the buffer vmcpde_gram filled followed by the row sums, E~O sums, Eloc sums and the sample count
+ * (everything vmcpde_gram_finalize consumes), so one call per step reduces all of them.
+ * comm: an ncclComm_t of the RCCL loaded in this process -- either the caller's own, or one made with the three helpers
+ * below (rank 0 obtains a 128-byte id, distributes it by any means -- mpi4py bcast in the reference's setting --, and every
+ * rank calls vmcpde_comm_init_rank with its GPU current).  RCCL is resolved at run time; single-GPU use never touches it. */
+int vmcpde_allreduce(double* packed, int64_t count, void* comm, void* stream);
+int vmcpde_comm_unique_id(void* id128 /* [host] 128 bytes out */);
+int vmcpde_comm_init_rank(void** comm, int32_t n_ranks, const void* id128, int32_t rank);
+int vmcpde_comm_destroy(void* comm);
+
 /* diagnostic (no reference counterpart): `blocks` workgroups x 4 waves x `iters` x 8 back-to-back v_mfma_f64_16x16x4_f64
  * (2048 flop each) with operands in registers; out: [dev] blocks*256.  Times the fp64 matrix-pipe peak for the roofline. */
 int vmcpde_bench_mfma_f64(int32_t iters, int32_t blocks, double* out, void* stream);

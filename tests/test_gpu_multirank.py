@@ -81,3 +81,70 @@ def test_two_ranks_match_single_rank():
                 assert float(torch.linalg.norm(S0 @ (r[0] - u0)) / torch.linalg.norm(F0)) < 1e-8
         # the replicated solve is bit-identical on both ranks (same all-reduced inputs, deterministic kernels)
         assert torch.equal(got[0][name][0], got[1][name][0]) and torch.equal(got[0][name][3], got[1][name][3])
+
+
+def test_abi_allreduce_on_a_single_rank_communicator():
+    """The C-ABI collective end to end on the one GPU there is: unique id -> ncclCommInitRank (1 rank) -> vmcpde_allreduce in
+    place on the current stream -> destroy.  A one-rank sum is the identity, which is exactly what makes it checkable here."""
+    import ctypes as C
+    from vmc_pde_amd import _native as nat
+    torch.cuda.set_device(0)
+    ident = (C.c_char * 128)()
+    nat.call("vmcpde_comm_unique_id", C.cast(ident, C.c_void_p))
+    assert any(b != 0 for b in ident.raw)
+    comm = C.c_void_p()
+    nat.call("vmcpde_comm_init_rank", C.byref(comm), 1, C.cast(ident, C.c_void_p), 0)
+    assert comm.value
+    g = torch.Generator(device="cuda").manual_seed(3)
+    buf = torch.randn(9_191_000, generator=g, dtype=torch.float64, device="cuda")    # the size of the C2 payload (73.5 MB)
+    keep = buf.clone()
+    for _ in range(3):
+        nat.call("vmcpde_allreduce", nat.ptr(buf), buf.numel(), comm, nat.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(buf, keep)
+    with pytest.raises(nat.VmcpdeError, match="null argument"):
+        nat.call("vmcpde_allreduce", nat.ptr(buf), buf.numel(), None, nat.stream())
+    nat.call("vmcpde_comm_destroy", comm)
+
+
+def _worker_nccl(rank, world, port, collective, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      VMCPDE_COLLECTIVE=collective, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    V, vs, eq = _problem()
+    res = _two_calls(V, vs, eq, dict(diagonalShift=1e-5, solver="cholesky"))
+    q.put((rank, [v.numpy() if torch.is_tensor(v) else v for v in res]))
+    dist.barrier()
+    from vmc_pde_amd import mpi_wrapper as mpi
+    mpi.destroy_abi_communicator()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+@pytest.mark.parametrize("collective", ["torch", "abi"])
+def test_two_ranks_over_rccl_match_single_rank(collective):
+    """One rank per GPU, backend nccl (= RCCL over xGMI): the packed buffer is reduced on the device, either by
+    torch.distributed or by the library's own vmcpde_allreduce.  Runs on the first box that has two GPUs."""
+    V, vs, eq = _problem()
+    u0, S0, F0, u1, S1, F1, Em, Ev = _two_calls(V, vs, eq, dict(diagonalShift=1e-5, solver="cholesky"))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_nccl, args=(r, 2, port, collective, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        r = [torch.from_numpy(v) if isinstance(v, np.ndarray) else v for v in got[rank]]
+        assert float((r[1] - S0).abs().max() / S0.abs().max()) < 1e-12 and float((r[4] - S1).abs().max() / S1.abs().max()) < 1e-11
+        assert float((r[2] - F0).abs().max() / F0.abs().max()) < 1e-11 and float((r[5] - F1).abs().max() / F1.abs().max()) < 1e-10
+        assert float(torch.linalg.norm(r[0] - u0) / torch.linalg.norm(u0)) < 1e-7
+        assert float(torch.linalg.norm(r[3] - u1) / torch.linalg.norm(u1)) < 1e-7
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][3], got[1][3])       # replicated solve: bit-identical

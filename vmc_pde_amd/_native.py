@@ -69,6 +69,10 @@ _PROTOS = {
     "vmcpde_gram_workspace_bytes": (_i64, [_i32, _i64]),
     "vmcpde_gram": (_int, [_vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "vmcpde_gram_finalize": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f64, _f64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "vmcpde_allreduce": (_int, [_vp, _i64, _vp, _vp]),
+    "vmcpde_comm_unique_id": (_int, [_vp]),
+    "vmcpde_comm_init_rank": (_int, [C.POINTER(_vp), _i32, _vp, _i32]),
+    "vmcpde_comm_destroy": (_int, [_vp]),
     "vmcpde_bench_mfma_f64": (_int, [_i32, _i32, _vp, _vp]),
     "vmcpde_chol_workspace_bytes": (_i64, [_i32]),
     "vmcpde_cholesky": (_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp]),

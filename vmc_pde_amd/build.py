@@ -15,7 +15,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIBDIR = PKG / "_lib"
 LIB = LIBDIR / "libvmcpde.so"
-SOURCES = ["model.hip", "flow.hip", "sampler.hip", "gram.hip", "solve.hip"]
+SOURCES = ["model.hip", "flow.hip", "sampler.hip", "gram.hip", "solve.hip", "comm.hip"]
 HEADERS = [CSRC / "common.hpp", CSRC / "mfma_tile.hpp", PKG.parent / "include" / "vmcpde.h"]
 ARCH = "gfx950"
 
@@ -49,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             subprocess.run(cmd, check=True)
         objs.append(o)
     if force or _stale(LIB, objs):
-        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)]
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs), "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -6,6 +6,8 @@ processes (one per GPU, backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests
 partial sums of a step into ONE buffer that is all-reduced once (tdvp.py in this package).  The functions below keep
 the reference names for the generic cases.
 """
+import os as _os
+
 import torch
 import torch.distributed as dist
 
@@ -32,45 +34,80 @@ def __getattr__(name):      # `mpi.rank` / `mpi.commSize` as module attributes (
     raise AttributeError(name)
 
 
+def _shard_sizes(total, parts):
+    """Sizes of `parts` contiguous shards of `total` items: the first `total % parts` shards hold one item more."""
+    base, extra = divmod(int(total), int(parts))
+    return [base + (r < extra) for r in range(parts)]
+
+
 def distribute_sampling(numSamples, localDevices=None, numChainsPerDevice=1):
-    """mpi_wrapper.py:68-110: samples per rank (or per chain when localDevices is given); sets globNumSamples."""
+    """mpi_wrapper.py:68-110.  Exact samplers (localDevices None): this rank's shard of `numSamples`.  MCMC: every rank runs
+    `localDevices * numChainsPerDevice` chains, so the return value is the number of sweeps that covers its shard, and the global
+    sample count is rounded up to whole sweeps on every rank.  Sets `globNumSamples` either way."""
     global globNumSamples
-    commSize, rank = get_comm_size(), get_rank()
-    samplesPerProcess = numSamples // commSize
-    if rank < numSamples % commSize:
-        samplesPerProcess += 1
+    shards = _shard_sizes(numSamples, get_comm_size())
     if localDevices is None:
         globNumSamples = numSamples
-        return samplesPerProcess
-    numChainsPerProcess = localDevices * numChainsPerDevice
-
-    def spc(spp):
-        return (spp + numChainsPerProcess - 1) // numChainsPerProcess
-
-    a = numSamples % commSize
-    globNumSamples = (a * spc(1 + numSamples // commSize) + (commSize - a) * spc(numSamples // commSize)) * numChainsPerProcess
-    return spc(samplesPerProcess)
+        return shards[get_rank()]
+    chains = localDevices * numChainsPerDevice
+    sweeps = [-(-n // chains) for n in shards]
+    globNumSamples = chains * sum(sweeps)
+    return sweeps[get_rank()]
 
 
 def first_sample_id(numSamples=None):
-    """mpi_wrapper.py:113-126: global index of this rank's first sample."""
-    n = globNumSamples if numSamples is None else numSamples
-    commSize, rank = get_comm_size(), get_rank()
-    mySamples = n // commSize
-    firstSampleId = rank * mySamples
-    firstSampleId += rank if rank < n % commSize else n % commSize
-    return firstSampleId
+    """mpi_wrapper.py:113-126: global index of this rank's first sample = the sizes of the shards before it."""
+    total = globNumSamples if numSamples is None else numSamples
+    return sum(_shard_sizes(total, get_comm_size())[:get_rank()])
+
+
+_abi_comm = None       # ncclComm_t made through the C ABI (vmcpde_comm_init_rank), one per process
+
+
+def abi_communicator():
+    """RCCL communicator owned by libvmcpde: rank 0 draws the 128-byte id (vmcpde_comm_unique_id), the torch.distributed
+    rendezvous that is up anyway carries it to the other ranks, and every rank binds its current GPU
+    (vmcpde_comm_init_rank).  A reference-side binder would do the same with an mpi4py bcast."""
+    global _abi_comm
+    if _abi_comm is None:
+        import ctypes as C
+        from . import _native as nat
+        ident = (C.c_char * 128)()
+        if get_rank() == 0:
+            nat.call("vmcpde_comm_unique_id", C.cast(ident, C.c_void_p))
+        box = [bytes(ident.raw)]
+        dist.broadcast_object_list(box, src=0)
+        ident = (C.c_char * 128).from_buffer_copy(box[0])
+        comm = C.c_void_p()
+        nat.call("vmcpde_comm_init_rank", C.byref(comm), get_comm_size(), C.cast(ident, C.c_void_p), get_rank())
+        _abi_comm = comm
+    return _abi_comm
+
+
+def destroy_abi_communicator():
+    global _abi_comm
+    if _abi_comm is not None:
+        from . import _native as nat
+        nat.call("vmcpde_comm_destroy", _abi_comm)
+        _abi_comm = None
 
 
 def allreduce_sum_(buf: torch.Tensor) -> torch.Tensor:
-    """In-place sum over ranks of one packed device buffer (the single collective of a TDVP step)."""
+    """In-place sum over ranks of one packed device buffer (the single collective of a TDVP step).
+    backend "nccl" = RCCL over xGMI, either through torch.distributed (default) or -- VMCPDE_COLLECTIVE=abi -- through the
+    library's own entry point `vmcpde_allreduce` on a communicator made by `abi_communicator` (the path a non-torch host
+    would bind).  backend "gloo": CPU rehearsal of the multi-rank logic, staged through the host."""
     if _on() and dist.get_world_size() > 1:
-        if buf.is_cuda and dist.get_backend() == "gloo":     # CPU-backend rehearsal of the multi-rank path: stage via host
+        if buf.is_cuda and dist.get_backend() == "gloo":
             tmp = buf.cpu()
             dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
             buf.copy_(tmp)
+        elif buf.is_cuda and buf.dtype == torch.float64 and buf.is_contiguous() and _os.environ.get("VMCPDE_COLLECTIVE", "torch") == "abi":
+            from . import _native as nat
+            with torch.cuda.device(buf.device):
+                nat.call("vmcpde_allreduce", nat.ptr(buf), buf.numel(), abi_communicator(), nat.stream())
         else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)       # backend "nccl" = RCCL over xGMI
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf
 
 
