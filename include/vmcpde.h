@@ -59,6 +59,7 @@ typedef struct {
   const int32_t* inds_up;   /* [host] depth * n_up          (var_state.py:116, order preserved) */
   const int32_t* inds_down; /* [host] depth * (dim - n_up)  (var_state.py:117) */
   const double* offset;     /* [host] dim, network_args["offset"] (net.py:192,212) */
+  int32_t global_change;    /* net.py:72,80-82: per block a scalar global_scale and a d-vector global_offset (ABI 2) */
 } vmcpde_model_desc;
 
 /* constants of one EvolutionEquation (evolutionEq.py:61-77); unused fields are ignored by `kind` */
@@ -79,7 +80,8 @@ int vmcpde_destroy(vmcpde_model* m);
 int vmcpde_num_parameters(const vmcpde_model* m);                 /* var_state.py:27 */
 /* offset of a leaf in the flat vector (var_state.py:94-108). block<0 selects the latent leaves:
  * trafo 0='L',1='L_diag',2='dist_params',3='mu'. Otherwise trafo 0='s1',1='s2',2='t1',3='t2';
- * leaf 0='bias',1='kernel' of Dense_<layer>. Returns -1 if absent. */
+ * leaf 0='bias',1='kernel' of Dense_<layer>; trafo 4='global_offset', 5='global_scale' of the block (layer, leaf ignored).
+ * Returns -1 if absent. */
 int vmcpde_param_offset(const vmcpde_model* m, int block, int trafo, int layer, int leaf);
 /* bytes of LDS one wave needs / samples per wave chosen for flow_eval with n_dirs directions (diagnostic) */
 int vmcpde_flow_eval_config(const vmcpde_model* m, int n_dirs, int* lanes, int* lds_bytes);

@@ -61,6 +61,7 @@ class NetSpec:
     jac_eq_1: bool = False
     different_add: bool = False
     no_add: bool = True
+    global_change: bool = False   # net.py:72: per-block affine map y -> global_scale * y + global_offset
 
     @property
     def depth(self) -> int:
@@ -94,6 +95,9 @@ def param_layout(spec: NetSpec) -> List[Tuple[str, Tuple[int, ...]]]:
     block_names = sorted(f"blocks_{b}" for b in range(spec.depth))  # string sort: blocks_10 < blocks_2
     for bn in block_names:
         b = int(bn.split("_")[1])
+        if spec.global_change:                      # net.py:80-82; 'global_offset' < 'global_scale' < 's1' in the sorted dict
+            out.append((f"myINN/{bn}/global_offset", (d,)))
+            out.append((f"myINN/{bn}/global_scale", (1,)))
         for tn in sorted(trafo_names(spec)):
             n_in, n_out = trafo_io(spec, b, tn)
             widths = [n_in] + list(spec.intmediate) + [n_out]
@@ -150,6 +154,8 @@ def init_parameters(spec: NetSpec, seed: int, out_scale: float = 1e-5, hidden_sc
             k = int(name.split("/")[-2].split("_")[1])
             scale = out_scale if k == n_dense - 1 else hidden_scale
             p[name] = 2 * scale * (torch.rand(shape, generator=g, dtype=tReal) - 0.5)
+        elif name.endswith("/global_scale"):
+            p[name] = torch.ones(shape, dtype=tReal)                       # net.py:81 initializers.ones
         else:
             p[name] = torch.zeros(shape, dtype=tReal)
     return flatten(spec, p)
@@ -183,7 +189,10 @@ def single_trafo(p: Dict[str, torch.Tensor], prefix: str, n_hidden: int, x: torc
 
 
 def single_block(spec: NetSpec, p, b: int, x: torch.Tensor, inv: bool):
-    """net.py:84-153 (global_change is never enabled by INN, net.py:166, and is not restated)."""
+    """net.py:84-153, including the global_change option (net.py:72,80-82,115-116,150-151) exactly as written: the forward
+    direction returns scale * result + offset, and the inverse direction returns (result - offset) / scale AFTER the inverse
+    coupling steps -- which is not the inverse map of the forward direction unless scale = 1, offset = 0 (the affine step would
+    have to be undone BEFORE them).  INN never enables the option (net.py:166), so the reference never met this."""
     up, dn = spec.inds_up[b], spec.inds_down[b]
     nh = len(spec.intmediate)
     pre = f"myINN/blocks_{b}"
@@ -216,6 +225,9 @@ def single_block(spec: NetSpec, p, b: int, x: torch.Tensor, inv: bool):
         res = torch.zeros_like(x)
         res = res.index_put((torch.tensor(up),), v1)
         res = res.index_put((torch.tensor(dn),), v2)
+        if spec.global_change:                                           # net.py:115-116
+            gs, go = p[f"{pre}/global_scale"], p[f"{pre}/global_offset"]
+            return gs * res + go, (s2_u2.sum() + s1_v1.sum()) + torch.log(gs[0]) * (len(up) + len(dn))
         return res, s2_u2.sum() + s1_v1.sum()
     else:
         v1, v2 = x[up], x[dn]
@@ -242,6 +254,9 @@ def single_block(spec: NetSpec, p, b: int, x: torch.Tensor, inv: bool):
         res = torch.zeros_like(x)
         res = res.index_put((torch.tensor(up),), u1)
         res = res.index_put((torch.tensor(dn),), u2)
+        if spec.global_change:                                           # net.py:150-151
+            gs, go = p[f"{pre}/global_scale"], p[f"{pre}/global_offset"]
+            return (res - go) / gs, -(s1_v1.sum() + s2_u2.sum()) - torch.log(gs[0]) * (len(up) + len(dn))
         return res, -(s1_v1.sum() + s2_u2.sum())
 
 

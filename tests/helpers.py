@@ -8,8 +8,10 @@ from oracle import vmc_oracle as O
 def make_spec(dim, depth, hidden, latent="Gauss", coupling="no_add", seed=1, offset=None):
     ups, dns = O.random_partitions(dim, depth, seed)
     off = np.zeros(dim) if offset is None else np.asarray(offset, dtype=np.float64)
+    global_change = coupling.endswith("+global")          # e.g. "no_add+global": net.py:72
+    coupling = coupling.split("+")[0]
     flags = dict(jac_eq_1=coupling == "jac_eq_1", different_add=coupling == "different_add",
-                 no_add=coupling in ("no_add",))
+                 no_add=coupling in ("no_add",), global_change=global_change)
     return O.NetSpec(dim=dim, inds_up=ups, inds_down=dns, intmediate=tuple(hidden), offset=off.tolist(),
                      latentSpaceName=latent, **flags)
 
@@ -29,15 +31,17 @@ def random_theta(spec, seed, out_scale=0.05, latent_scale=0.3):
     off = 0
     for name, shape in O.param_layout(spec):
         n = int(np.prod(shape))
-        if name.endswith("/bias"):
+        if name.endswith("/bias") or name.endswith("/global_offset"):
             th[off:off + n] = 0.2 * (torch.rand(n, generator=g, dtype=torch.float64) - 0.5)
+        elif name.endswith("/global_scale"):
+            th[off:off + n] = 1.0 + 0.4 * (torch.rand(n, generator=g, dtype=torch.float64) - 0.5)
         off += n
     return th
 
 
 def make_varstate(spec, theta, sampler=None, jacobian_dtype=None):
     import vmc_pde_amd as V
-    coupling = dict(jac_eq_1=spec.jac_eq_1, different_add=spec.different_add, no_add=spec.no_add)
+    coupling = dict(jac_eq_1=spec.jac_eq_1, different_add=spec.different_add, no_add=spec.no_add, global_change=spec.global_change)
     if sampler is None:
         sampler = V.Sampler(key=1, dim=spec.dim, name=spec.latentSpaceName, mcmc_info={"offset": np.asarray(spec.offset), "bound": 0.25})
     vs = V.VarState(sampler, spec.dim, 1, spec.depth,

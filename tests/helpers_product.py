@@ -22,7 +22,10 @@ class FixedSampler:
 
 def build_varstate(dim, depth, hidden, latent, coupling, offset, inds_up, inds_down, theta, sampler=None):
     import vmc_pde_amd as V
-    flags = dict(jac_eq_1=coupling == "jac_eq_1", different_add=coupling == "different_add", no_add=coupling == "no_add")
+    global_change = coupling.endswith("+global")          # e.g. "no_add+global": net.py:72
+    coupling = coupling.split("+")[0]
+    flags = dict(jac_eq_1=coupling == "jac_eq_1", different_add=coupling == "different_add", no_add=coupling == "no_add",
+                 global_change=global_change)
     if sampler is None:
         sampler = V.Sampler(key=1, dim=dim, name=latent, mcmc_info={"offset": np.asarray(offset), "bound": 0.25})
     vs = V.VarState(sampler, dim, 1, depth,

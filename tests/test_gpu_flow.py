@@ -21,6 +21,8 @@ CONFIGS = [
     (4, 2, (3,), "Student_t", "jac_eq_1"),
     (2, 4, (21, 21), "Gauss", "no_add"),        # BASELINE C2 net (P = 4213)
     (2, 2, (9, 9, 9), "Gauss", "different_add"),
+    (3, 3, (4,), "Gauss", "no_add+global"),              # global_change (net.py:72,80-82,115-116,150-151), odd d
+    (6, 11, (3,), "Student_t", "different_add+global"),  # ... with t-networks; 11 blocks: 'blocks_10' sorts before 'blocks_2'
 ]
 
 

@@ -21,6 +21,7 @@ CASES = [
     ("d6_b4_h3_gauss_diffadd", 6, 4, (3,), "Gauss", "different_add", ["advection_hamiltonian_wDiss", "diffusion_anisotropic"]),
     ("d8_b1_h3_student_noadd", 8, 1, (3,), "Student_t", "no_add", ["diffusion"]),
     ("d8_b4_h44_student_noadd", 8, 4, (4, 4), "Student_t", "no_add", ["diffusion", "diffusion_drift"]),
+    ("d3_b2_h3_gauss_noadd_global", 3, 2, (3,), "Gauss", "no_add+global", ["diffusion"]),      # global_change, net.py:72
 ]
 
 

@@ -31,6 +31,7 @@ CASES = [
     (2, 3, (4, 4), "Gauss", "no_add", "advection_hamiltonian_wDiss", 700),        # C2-like, ragged N
     (6, 4, (3,), "Gauss", "different_add", "advection_hamiltonian_wDiss", 512),   # C4-like (published P = 411)
     (8, 3, (6,), "Student_t", "no_add", "diffusion", 600),                        # published Student-t net
+    (3, 2, (3,), "Gauss", "no_add+global", "diffusion_drift", 300),               # global_change (net.py:72), odd d
 ]
 
 

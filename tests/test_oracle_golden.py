@@ -33,7 +33,12 @@ def test_oracle_reproduces_committed_vectors(k):
     for name, val in (("x", x), ("logp_sample", logp_s), ("logp", logp), ("grad_x", g), ("hessian", H), ("J", J)):
         assert _close(val.numpy(), GOLD[f"{tag}/{name}"], 1e-13), name
     # log p of the inverse flow equals log p of the forward evaluation at the same points (net.py:214-217 vs :209-213)
-    assert _close(logp_s.numpy(), logp.numpy(), 1e-12)
+    if not spec.global_change:
+        assert _close(logp_s.numpy(), logp.numpy(), 1e-12)
+    else:
+        # net.py:150-151 applies the affine step of global_change on the wrong side of the inverse coupling steps, so the
+        # reference's "inverse" is not the inverse map and the two log-densities differ (restated as written, see the oracle)
+        assert not _close(logp_s.numpy(), logp.numpy(), 1e-3)
     name = eqs[0]
     eo = M.make_eq(dim, name)
     to = O.TDVPOracle()

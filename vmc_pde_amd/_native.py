@@ -38,7 +38,7 @@ class ModelDesc(C.Structure):
     _fields_ = [("dim", C.c_int32), ("depth", C.c_int32), ("n_hidden", C.c_int32),
                 ("hidden", C.c_int32 * MAX_HIDDEN_LAYERS), ("coupling", C.c_int32), ("latent", C.c_int32),
                 ("n_up", C.c_int32), ("inds_up", C.POINTER(C.c_int32)), ("inds_down", C.POINTER(C.c_int32)),
-                ("offset", C.POINTER(C.c_double))]
+                ("offset", C.POINTER(C.c_double)), ("global_change", C.c_int32)]
 
 
 class EqConsts(C.Structure):

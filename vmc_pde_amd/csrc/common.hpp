@@ -65,6 +65,8 @@ struct FlowProgram {
   int32_t max_width;     // widest MLP layer (incl. inputs/outputs)
   int32_t max_sum_act;   // max over trafos of (n_in + sum_hidden)
   double alpha;          // SingleTrafo.alpha = 10 (net.py:50)
+  int32_t global_change; // net.py:72: block b ends with y -> th[off_gscale[b]] * y + th[off_goffset[b] + i]
+  int32_t off_goffset[VMCPDE_MAX_DEPTH], off_gscale[VMCPDE_MAX_DEPTH];
   double offset[MAX_DIM];
   HalfStep hs[MAX_HALFSTEPS];
 };

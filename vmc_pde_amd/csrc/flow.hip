@@ -324,6 +324,50 @@ __device__ __forceinline__ void halfstep_forward(const Ctx& c, const HalfStep& h
   }
 }
 
+// The global_change step that closes block b in the forward direction (net.py:115-116): y = scale * r + offset on all d
+// coordinates, log-jacobian += d * log(scale).  Wave 0 (the owner of X and lj) only.
+template <int NC>
+__device__ __forceinline__ void global_forward(const Ctx& c, int b, const Regions& r, double* lj) {
+  if (!W0) return;
+  const int d = c.fp->dim;
+  const double gs = c.th[c.fp->off_gscale[b]];
+  for (int i = 0; i < d; ++i) {
+    LD(r.X + i) = gs * LD(r.X + i) + c.th[c.fp->off_goffset[b] + i];
+#pragma unroll
+    for (int cc = 1; cc < NC; ++cc) LD(r.X + cc * d + i) = gs * LD(r.X + cc * d + i);
+  }
+  lj[0] += (double)d * log(gs);
+}
+
+// ... and what the reference's inverse direction does with it (net.py:150-151): AFTER the inverse coupling steps,
+// x = (r - offset) / scale and log-jacobian -= d * log(scale).  As written, not the inverse of global_forward (see the oracle).
+__device__ __forceinline__ void global_inverse_as_written(const Ctx& c, int b, const Regions& r, double& lj) {
+  if (!W0) return;
+  const int d = c.fp->dim;
+  const double gs = c.th[c.fp->off_gscale[b]];
+  for (int i = 0; i < d; ++i) LD(r.X + i) = (LD(r.X + i) - c.th[c.fp->off_goffset[b] + i]) / gs;
+  lj -= (double)d * log(gs);
+}
+
+// Reverse sweep through global_forward: on entry X = y, G = dlogp/dy; on exit X = r, G = dlogp/dr, and the d + 1 Jacobian
+// rows of the block are written: dlogp/d offset_i = G_i, dlogp/d scale = sum_i G_i r_i + d / scale.
+__device__ __forceinline__ void global_backward(const Ctx& c, int b, const Regions& r, void* __restrict__ JT, int64_t ldj, int64_t n,
+                                                bool active) {
+  if (!W0) return;
+  const int d = c.fp->dim;
+  const double gs = c.th[c.fp->off_gscale[b]];
+  double dscale = (double)d / gs;
+  for (int i = 0; i < d; ++i) {
+    const double gi = LD(r.G + i);
+    const double ri = (LD(r.X + i) - c.th[c.fp->off_goffset[b] + i]) / gs;
+    if (JT != nullptr && active) jt_store(c, JT, ldj, c.fp->off_goffset[b] + i, n, gi);
+    dscale = fma(gi, ri, dscale);
+    LD(r.X + i) = ri;
+    LD(r.G + i) = gs * gi;
+  }
+  if (JT != nullptr && active) jt_store(c, JT, ldj, c.fp->off_gscale[b], n, dscale);
+}
+
 // One coupling half-step in the inverse direction (latent -> real), values only, net.py:121-148.
 __device__ __forceinline__ void halfstep_inverse(const Ctx& c, const HalfStep& h, const Regions& r, double& lj) {
   const int cs = r.cs;
@@ -618,7 +662,10 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_eval_kernel(const Flow
           LD(r.X + 2 * d + i) = 0.0;
         }
       double lj[3] = {0, 0, 0}, lp[3];
-      for (int s = 0; s < fp->n_half; ++s) halfstep_forward<3>(c, fp->hs[s], r, lj);
+      for (int s = 0; s < fp->n_half; ++s) {
+        halfstep_forward<3>(c, fp->hs[s], r, lj);
+        if ((s & 1) && fp->global_change) global_forward<3>(c, s >> 1, r, lj);
+      }
       if (W0) {
         latent_forward<3>(c, lc, r, r.X, lp);
         lp_val = lp[0] + lj[0];
@@ -629,7 +676,10 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_eval_kernel(const Flow
     if (W0)
       for (int i = 0; i < d; ++i) LD(r.X + i) = x[nn * d + i];
     double lj[1] = {0}, lp[1];
-    for (int s = 0; s < fp->n_half; ++s) halfstep_forward<1>(c, fp->hs[s], r, lj);
+    for (int s = 0; s < fp->n_half; ++s) {
+      halfstep_forward<1>(c, fp->hs[s], r, lj);
+      if ((s & 1) && fp->global_change) global_forward<1>(c, s >> 1, r, lj);
+    }
     if (W0) {
       latent_forward<1>(c, lc, r, r.X, lp);
       lp_val = lp[0] + lj[0];
@@ -640,7 +690,10 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_eval_kernel(const Flow
 
   // reverse sweep: X currently holds z
   if (W0) latent_backward(c, lc, r, JT, ldj, n, active);
-  for (int s = fp->n_half - 1; s >= 0; --s) halfstep_backward(c, fp->hs[s], r, JT, ldj, n, active);
+  for (int s = fp->n_half - 1; s >= 0; --s) {
+    if ((s & 1) && fp->global_change) global_backward(c, s >> 1, r, JT, ldj, n, active);
+    halfstep_backward(c, fp->hs[s], r, JT, ldj, n, active);
+  }
   if (g != nullptr && active && W0)
     for (int i = 0; i < d; ++i) g[n * d + i] = LD(r.G + i);
 }
@@ -674,10 +727,16 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_sample_kernel(const Fl
   }
   double lj = 0.0;
   if (inv) {
-    for (int s = fp->n_half - 1; s >= 0; --s) halfstep_inverse(c, fp->hs[s], r, lj);
+    for (int s = fp->n_half - 1; s >= 0; --s) {
+      halfstep_inverse(c, fp->hs[s], r, lj);
+      if (!(s & 1) && fp->global_change) global_inverse_as_written(c, s >> 1, r, lj);
+    }
   } else {
     double ljv[1] = {0};
-    for (int s = 0; s < fp->n_half; ++s) halfstep_forward<1>(c, fp->hs[s], r, ljv);
+    for (int s = 0; s < fp->n_half; ++s) {
+      halfstep_forward<1>(c, fp->hs[s], r, ljv);
+      if ((s & 1) && fp->global_change) global_forward<1>(c, s >> 1, r, ljv);
+    }
     lj = ljv[0];
   }
   if (active) {

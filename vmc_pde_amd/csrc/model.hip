@@ -50,7 +50,7 @@ int env_int(const char* name, int fallback) {
 using namespace vmcpde;
 
 extern "C" const char* vmcpde_last_error(void) { return vmcpde::g_err; }
-extern "C" int vmcpde_abi_version(void) { return 1; }
+extern "C" int vmcpde_abi_version(void) { return 2; }
 
 namespace {
 
@@ -134,8 +134,15 @@ extern "C" int vmcpde_create(const vmcpde_model_desc* desc, vmcpde_model** out) 
   std::vector<std::pair<std::string, int>> blocks;
   for (int b = 0; b < d.depth; ++b) blocks.push_back({"blocks_" + std::to_string(b), b});
   std::sort(blocks.begin(), blocks.end());  // string order: blocks_10 < blocks_2
+  fp.global_change = d.global_change ? 1 : 0;
   for (auto& bn : blocks) {
     const int b = bn.second;
+    if (fp.global_change) {          // 'global_offset' < 'global_scale' < 's1' (net.py:80-82)
+      fp.off_goffset[b] = pos;
+      pos += d.dim;
+      fp.off_gscale[b] = pos;
+      pos += 1;
+    }
     const int n_tr = has_t ? 4 : 2;  // sorted names: s1 < s2 < t1 < t2
     for (int tr = 0; tr < n_tr; ++tr) {
       // s1/t1: |up| -> |down| ; s2/t2: |down| -> |up|   (net.py:75-79)
@@ -222,6 +229,8 @@ extern "C" int vmcpde_param_offset(const vmcpde_model* m, int block, int trafo, 
       default: return -1;
     }
   }
+  if (block < fp.n_half / 2 && (trafo == 4 || trafo == 5))
+    return fp.global_change ? (trafo == 4 ? fp.off_goffset[block] : fp.off_gscale[block]) : -1;
   if (block >= fp.n_half / 2 || trafo < 0 || trafo > 3 || layer < 0 || layer >= MAX_LAYERS || leaf < 0 || leaf > 1) return -1;
   return static_cast<const LayoutTable*>(m->layout)->off[block][trafo][layer][leaf];
 }

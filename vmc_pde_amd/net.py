@@ -25,7 +25,7 @@ class INNwProb:
     (which the reference can only change by editing net.py, main.py:43-58) are ordinary keyword arguments here."""
 
     def __init__(self, inds_up, inds_down, intmediate=(3,), offset=None, latentSpaceName="Gauss", dim=2,
-                 jac_eq_1=False, different_add=False, no_add=True, device=None):
+                 jac_eq_1=False, different_add=False, no_add=True, global_change=False, device=None):
         self.inds_up = [[int(v) for v in u] for u in inds_up]
         self.inds_down = [[int(v) for v in u] for u in inds_down]
         self.intmediate = tuple(int(v) for v in intmediate)
@@ -43,6 +43,7 @@ class INNwProb:
             self.coupling = "no_add"          # net.py:95-96
         else:
             self.coupling = "plain"           # net.py:97-98
+        self.global_change = bool(global_change)   # net.py:72,80-82: per-block y -> global_scale * y + global_offset
         self.device = global_defs.my_device() if device is None else torch.device(device)
 
         n_up = len(self.inds_up[0])
@@ -56,6 +57,7 @@ class INNwProb:
         for k, w in enumerate(self.intmediate):
             desc.hidden[k] = w
         desc.coupling, desc.latent, desc.n_up = nat.COUPLING[self.coupling], nat.LATENT[latentSpaceName], n_up
+        desc.global_change = 1 if self.global_change else 0
         desc.inds_up = C.cast(self._keep["up"], C.POINTER(C.c_int32))
         desc.inds_down = C.cast(self._keep["dn"], C.POINTER(C.c_int32))
         desc.offset = C.cast(self._keep["off"], C.POINTER(C.c_double))
@@ -91,6 +93,9 @@ class INNwProb:
         n_up = len(self.inds_up[0])
         for bn in sorted(f"blocks_{b}" for b in range(self.depth)):
             b = int(bn.split("_")[1])
+            if self.global_change:
+                out.append((("myINN", bn, "global_offset"), L.vmcpde_param_offset(self.handle, b, 4, 0, 0), (d,)))
+                out.append((("myINN", bn, "global_scale"), L.vmcpde_param_offset(self.handle, b, 5, 0, 0), (1,)))
             for tn in names:
                 n_in, n_out = (n_up, d - n_up) if tn in ("s1", "t1") else (d - n_up, n_up)
                 widths = [n_in] + list(self.intmediate) + [n_out]
@@ -139,6 +144,8 @@ class INNwProb:
                 scale = out_scale if k == n_dense - 1 else hidden_scale
                 n = int(np.prod(shape))
                 theta[off:off + n] = 2 * scale * (torch.rand(n, generator=g, dtype=global_defs.tReal) - 0.5)
+            elif path[-1] == "global_scale":
+                theta[off] = 1.0                       # net.py:81 initializers.ones
         return theta.to(self.device)
 
     # ---- net.py:209-217 ---------------------------------------------------------------------------------------
