@@ -150,14 +150,40 @@ int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t P, int64_t 
                 double* packed, void* workspace, int64_t workspace_bytes, void* stream);
 /* tdvp.py:45-46,50-51: S[i][j] = packed/Ntot - d_i d_j (full symmetric, both triangles written) with
  * d = rowsum/Ntot + c - c_gram = (global mean) - (the shift vmcpde_gram was given; c_gram NULL = 0, i.e. uncentred Gram),
- * A_shifted = S + diag(diagonal_shift * diag S) (optional second copy for the in-place Cholesky, may be NULL),
+ * A_shifted = S + diag(diagonal_shift * diag S) + floor_dev[0] * I (optional second copy for the in-place Cholesky, may be NULL;
+ * floor_dev: [dev] 1 or NULL = 0 -- the absolute floor svdTol * max diag(S) that vmcpde_tdvp_moments leaves in scal[6]),
  * F = rowdot/Ntot - delta*deltaE, mean = c + delta, with delta = rowsum/Ntot, deltaE = sums[0]/Ntot - cE  (c = the shift
- * vmcpde_row_moments was given, NULL = 0).  S: [dev] P*lds, A_shifted: [dev] P*lda.  All inputs may already be all-reduced
- * over ranks (Ntot = global count). */
+ * vmcpde_row_moments was given, NULL = 0; F and mean may be NULL = skipped).  S: [dev] P*lds, A_shifted: [dev] P*lda.  All
+ * inputs may already be all-reduced over ranks (Ntot = global count). */
 int vmcpde_gram_finalize(const double* packed, const double* rowsum, const double* rowdot, const double* sums,
                          const double* c, const double* c_gram, const double* cE_dev, int32_t P, double n_total,
-                         double diagonal_shift, double* S, int64_t lds, double* A_shifted, int64_t lda, double* F, double* mean,
-                         void* stream);
+                         double diagonal_shift, const double* floor_dev, double* S, int64_t lds, double* A_shifted, int64_t lda,
+                         double* F, double* mean, void* stream);
+
+/* ---- the O(N) and O(P) glue of tdvp.py:36-52, 93-94, three launches per right-hand side ---------------------------------- */
+/* tdvp.py:37-39,150: sums3 = { sum E, sum E^2, sum |E| } over the local samples, count[0] = n_samples, max_out[0] = max E
+ * (count, max_out may be NULL).  If row_e / row_one are given (both or neither), also row_e[n] = E_n - cE_dev[0] and
+ * row_one[n] = 1 for n < n_samples: the two rows the fused-moments path appends to the Jacobian, so that the syrk's last tile
+ * row carries sum_n O (E - cE) and sum_n O.  workspace: [dev] >= vmcpde_tdvp_prepare_workspace_bytes(), zeroed ONCE by the
+ * caller (the kernel returns it zeroed); sums are formed in a fixed order (run-to-run reproducible). */
+int64_t vmcpde_tdvp_prepare_workspace_bytes(void);
+int vmcpde_tdvp_prepare(const double* eloc, int64_t n_samples, const double* cE_dev, double* row_e, double* row_one, double* sums3,
+                        double* count, double* max_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* After the all-reduce, everything that is O(P) (tdvp.py:37-41,45 and the diagonal of :46):
+ *   bordered != 0: rowsum / rowdot are WRITTEN from the last tile row of a Gram over P + 2 rows (rows P, P+1 = E - cE, 1);
+ *   bordered == 0: they are read (vmcpde_row_moments, possibly all-reduced).
+ *   F, mean as vmcpde_gram_finalize; diagS[p] = diag(S)_p;
+ *   scal[0..6] = ElocMean, ElocMeanAbs, ElocVar, <E^2>, max_p mean_p^2 / diagS_p, max_p diagS_p, svdTol * max_p diagS_p
+ *   (maxima over the parameters with mask[p] != 0; mask NULL = all);  scal: [dev] 8.
+ *   border_row non-NULL: border_row[0..P) = F, border_row[P] = border_pivot -- row P of the bordered Cholesky matrix. */
+int vmcpde_tdvp_moments(const double* packed, int32_t P, int32_t bordered, double* rowsum, double* rowdot, const double* sums3,
+                        double n_total, const double* c, const double* c_gram, const double* cE_dev, const double* mask, double* F,
+                        double* mean, double* diagS, double* scal, double svdTol, double* border_row, double border_pivot,
+                        void* stream);
+/* tdvp.py:93-94 from u and S0 u: out[0] = |S u - F| / |F| with S u = S0 u + (diagonal_shift * diagS + floor_dev[0]) u
+ * (floor_dev NULL = 0), out[1] = 1 + (u.S0u - 2 F.u) / scal[3], out[2] = info[0] (pinned pivots, NULL = 0).  out: [dev] 4. */
+int vmcpde_tdvp_diagnostics(const double* u, const double* S0u, const double* F, const double* diagS, int32_t P, double diagonal_shift,
+                            const double* floor_dev, const double* scal, const int32_t* info, double* out, void* stream);
 
 /* ---- mpi_wrapper.py:129-163 (global_sum) ---------------------------------------------------------------------- */
 /* The single collective of a TDVP step: packed[0..count) <- sum over the ranks of `comm`, in place, fp64, on `stream`

@@ -169,7 +169,7 @@ def test_row_moments_eloc_stats_and_finalize():
     F = torch.empty(P, dtype=torch.float64, device=DEV)
     mean = torch.empty(P, dtype=torch.float64, device=DEV)
     nat.call("vmcpde_gram_finalize", nat.ptr(packed), nat.ptr(rowsum), nat.ptr(rowdot), nat.ptr(sums), nat.ptr(c), nat.ptr(c), nat.ptr(cE), P, float(N),
-             1e-3, nat.ptr(S), Pp, nat.ptr(A), Pp, nat.ptr(F), nat.ptr(mean), nat.stream())
+             1e-3, None, nat.ptr(S), Pp, nat.ptr(A), Pp, nat.ptr(F), nat.ptr(mean), nat.stream())
     Oc = J - J.mean(0)
     S_ref = Oc.T @ Oc / N
     F_ref = (Oc * (E - E.mean())[:, None]).mean(0)
@@ -185,6 +185,6 @@ def test_row_moments_eloc_stats_and_finalize():
     packed0 = _gram(JT, ldj, P, N)
     S2 = torch.zeros((Pp, Pp), dtype=torch.float64, device=DEV)
     nat.call("vmcpde_gram_finalize", nat.ptr(packed0), nat.ptr(rowsum), nat.ptr(rowdot), nat.ptr(sums), nat.ptr(c), None, nat.ptr(cE), P, float(N),
-             0.0, nat.ptr(S2), Pp, None, 0, None, None, nat.stream())
+             0.0, None, nat.ptr(S2), Pp, None, 0, None, None, nat.stream())
     S2g = S2.cpu().numpy()[:P, :P]
     assert np.linalg.norm(S2g - S_ref) / np.linalg.norm(S_ref) < 1e-11

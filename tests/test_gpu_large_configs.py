@@ -97,7 +97,7 @@ def test_gram_config3_width_matvec_and_split_additivity():
     packed = _gram_full(JT, N, P, N)
     S = torch.empty((Pp, Pp), dtype=torch.float64, device=DEV)
     zero = torch.zeros(P, dtype=torch.float64, device=DEV)
-    nat.call("vmcpde_gram_finalize", nat.ptr(packed), nat.ptr(zero), None, None, None, None, None, P, 1.0, 0.0, nat.ptr(S), Pp, None, 0,
+    nat.call("vmcpde_gram_finalize", nat.ptr(packed), nat.ptr(zero), None, None, None, None, None, P, 1.0, 0.0, None, nat.ptr(S), Pp, None, 0,
              None, None, nat.stream())
     v = torch.randn(P, generator=g, dtype=torch.float64, device=DEV)
     ref = JT[:P] @ (JT[:P].T @ v)

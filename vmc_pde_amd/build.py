@@ -15,7 +15,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIBDIR = PKG / "_lib"
 LIB = LIBDIR / "libvmcpde.so"
-SOURCES = ["model.hip", "flow.hip", "sampler.hip", "gram.hip", "solve.hip", "comm.hip"]
+SOURCES = ["model.hip", "flow.hip", "sampler.hip", "gram.hip", "moments.hip", "solve.hip", "comm.hip"]
 HEADERS = [CSRC / "common.hpp", CSRC / "mfma_tile.hpp", PKG.parent / "include" / "vmcpde.h"]
 ARCH = "gfx950"
 

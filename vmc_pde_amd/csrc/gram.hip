@@ -229,9 +229,10 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const TIn* __restrict_
 // grid: (4, 4, ntiles) 32x32 sub-tiles; the mirrored block goes through an LDS transpose so both writes are coalesced.
 __global__ __launch_bounds__(256) void finalize_S_kernel(const double* __restrict__ packed, const double* __restrict__ rowsum,
                                                         const double* __restrict__ c, const double* __restrict__ cg, int P,
-                                                        double inv_n, double shift, double* __restrict__ S,
-                                                        int64_t lds_, double* __restrict__ A2, int64_t lda2) {
+                                                        double inv_n, double shift, const double* __restrict__ floor_dev,
+                                                        double* __restrict__ S, int64_t lds_, double* __restrict__ A2, int64_t lda2) {
   __shared__ double tr[32][33];
+  const double floor_abs = floor_dev ? floor_dev[0] : 0.0;
   int ti, tj;
   tri_decode(blockIdx.z, ti, tj);
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void finalize_S_kernel(const double* __restric
       const double raw = (ti == tj && cidx > r) ? tile[cidx * TILE + r] : tile[r * TILE + cidx];
       v = raw * inv_n - di * dj;
       S[(int64_t)gi * lds_ + gj] = v;
-      if (A2) A2[(int64_t)gi * lda2 + gj] = (gi == gj) ? v + shift * v : v;
+      if (A2) A2[(int64_t)gi * lda2 + gj] = (gi == gj) ? v + shift * v + floor_abs : v;
     }
     tr[ty + 8 * q][tx] = v;
   }
@@ -430,7 +431,8 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
 
 extern "C" int vmcpde_gram_finalize(const double* packed, const double* rowsum, const double* rowdot, const double* sums,
                                     const double* c, const double* c_gram, const double* cE_dev, int32_t P, double n_total, double diagonal_shift,
-                                    double* S, int64_t lds, double* A_shifted, int64_t lda, double* F, double* mean, void* stream) {
+                                    const double* floor_dev, double* S, int64_t lds, double* A_shifted, int64_t lda, double* F, double* mean,
+                                    void* stream) {
   VMC_REQUIRE(packed && rowsum && S, "vmcpde_gram_finalize: null argument");
   VMC_REQUIRE(P >= 1 && lds >= P && n_total > 0, "bad shape");
   VMC_REQUIRE(!A_shifted || lda >= P, "bad lda");
@@ -439,7 +441,7 @@ extern "C" int vmcpde_gram_finalize(const double* packed, const double* rowsum, 
   const int nb = (P + TILE - 1) / TILE;
   const double inv_n = 1.0 / n_total;
   hipLaunchKernelGGL(finalize_S_kernel, dim3(4, 4, (unsigned)tri_count(nb)), dim3(256), 0, st, packed, rowsum, c, c_gram, P, inv_n,
-                     diagonal_shift, S, lds, A_shifted, lda);
+                     diagonal_shift, floor_dev, S, lds, A_shifted, lda);
   VMC_CHECK_HIP(hipGetLastError());
   if (F || mean) {
     hipLaunchKernelGGL(finalize_F_kernel, dim3((P + 255) / 256), dim3(256), 0, st, rowsum, rowdot, sums, c, cE_dev, P, inv_n, F, mean);

@@ -104,9 +104,8 @@ class TDVP:
                      stats=torch.zeros(4, dtype=global_defs.tReal, device=device),
                      S=torch.zeros((Ppad, Ppad), dtype=global_defs.tReal, device=device),
                      F=torch.zeros(P, dtype=global_defs.tReal, device=device),
-                     mean=torch.zeros(P, dtype=global_defs.tReal, device=device),
-                     c=torch.zeros(P, dtype=global_defs.tReal, device=device),
-                     cE=torch.zeros(1, dtype=global_defs.tReal, device=device),
+                     diagS=torch.zeros(P, dtype=global_defs.tReal, device=device),
+                     prep_ws=torch.zeros(nat.lib().vmcpde_tdvp_prepare_workspace_bytes() // 8, dtype=global_defs.tReal, device=device),
                      gram_ws=None, A=None, chol_ws=None, info=torch.zeros(1, dtype=torch.int32, device=device))
             self._buf = {(P, str(device)): b}
         return b
@@ -149,104 +148,114 @@ class TDVP:
             JT, ldj = jt
         Ntot = float(mpi.globNumSamples) if mpi.globNumSamples else float(n * mpi.get_comm_size())
         world = mpi.get_comm_size()
+        f32 = 1 if JT.dtype == torch.float32 else 0
+        use_chol = self._solver() == "cholesky"
+        # per-call results (fresh small tensors, so that attributes read after a later call keep their values)
+        scal = torch.empty(8, dtype=global_defs.tReal, device=device)
+        mean = torch.empty(P, dtype=global_defs.tReal, device=device)
         with torch.cuda.device(device):
-            nat.call("vmcpde_eloc_stats", nat.ptr(e), n, nat.ptr(b["stats"]), nat.stream())
-            b["sums"].copy_(b["stats"][:3])
-            b["count"].fill_(float(n))
-            mode = self.centering
-            if mode == "auto":
-                mode = "exact" if (self._c_prev is None or self._c_prev.numel() != P) else "lagged"
-            if mode == "exact":
-                # pass 1: raw sums -> global means (tdvp.py:37,41); tiny all-reduce when sharded
-                b["c"].zero_()
-                b["cE"].zero_()
-                nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, 1 if JT.dtype == torch.float32 else 0, P, n, nat.ptr(e), None, None, nat.ptr(b["rowsum"]),
-                         nat.ptr(b["rowdot"]), nat.stream())
-                if world > 1:
-                    small = torch.cat([b["rowsum"], b["sums"][:1], b["count"]])
-                    mpi.allreduce_sum_(small)
-                    b["c"].copy_(small[:P] / small[P + 1])
-                    b["cE"].copy_(small[P:P + 1] / small[P + 1])
-                else:
-                    b["c"].copy_(b["rowsum"] / n)
-                    b["cE"].copy_(b["sums"][:1] / n)
-            else:
-                b["c"].copy_(self._c_prev)
-                b["cE"].copy_(self._cE_prev)
-            # health record of the previous solve (pinned pivots, residual): like the ratio check below its copy precedes this
-            # call's sampling and flow kernels in the stream, so waiting for it here does not idle the GPU
+            # health record of the previous solve (pinned pivots, residual) and the previous call's mean^2/var check: their
+            # copies precede this call's sampling and flow kernels in the stream, so waiting for them here does not idle the GPU,
+            # and it makes the choices below identical on every rank (the packed sums must agree)
             self._check_guard("previous step")
             shift_mode = self.gramShift
             if shift_mode == "auto":
                 if self._ratio_event is not None:
-                    # the previous call's mean^2/var check; its copy precedes this call's flow kernels in the stream, so this
-                    # wait never idles the GPU, and it makes the choice identical on every rank (the packed sums must agree)
                     self._ratio_event.synchronize()
                     self._uncentred_ok = bool(self._ratio_host[0] < 1e3)
                 shift_mode = "uncentred" if self._uncentred_ok else "centred"
-            c_gram = b["c"] if shift_mode == "centred" else None
-            # pass 2 (tdvp.py:40-45 in shifted form): sum (O - c), sum (O - c)(E - cE); and the syrk (tdvp.py:46).
-            # Uncentred fp64 path with two spare padded rows: E - cE and 1 are appended to the Jacobian as rows P and P+1, so
-            # the syrk's last tile row carries sum_n O (E - cE) and sum_n O and the separate pass over J is not needed
-            # (uncentred mode already requires mean^2/var < 1e3, which also bounds the cancellation in sum O - N c).
-            bordered = (self.fuseMoments and c_gram is None and JT.dtype == global_defs.tReal and JT.shape[0] >= P + 2
+            # Uncentred fp64 Gram with two spare padded rows: E - cE and 1 are appended to the Jacobian as rows P and P+1, so the
+            # syrk's last tile row carries sum_n O (E - cE) and sum_n O and no separate pass over J is needed (uncentred mode
+            # already requires mean^2/var < 1e3, which also bounds the cancellation in sum O - N c)
+            bordered = (self.fuseMoments and shift_mode == "uncentred" and JT.dtype == global_defs.tReal and JT.shape[0] >= P + 2
                         and P + 2 <= b["Ppad"])
-            if bordered:
-                torch.sub(e, b["cE"], out=JT[P, :n])
-                JT[P + 1, :n].fill_(1.0)
-            else:
-                nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, 1 if JT.dtype == torch.float32 else 0, P, n, nat.ptr(e), nat.ptr(b["c"]),
-                         nat.ptr(b["cE"]), nat.ptr(b["rowsum"]), nat.ptr(b["rowdot"]), nat.stream())
+            rows = (nat.ptr(JT[P]), nat.ptr(JT[P + 1])) if bordered else (None, None)
+            mode = self.centering
+            if mode == "auto":
+                mode = "exact" if (self._c_prev is None or self._c_prev.numel() != P) else "lagged"
+
+            def prepare(cE, with_rows):
+                nat.call("vmcpde_tdvp_prepare", nat.ptr(e), n, nat.ptr(cE), *(rows if with_rows else (None, None)), nat.ptr(b["sums"]),
+                         nat.ptr(b["count"]), nat.ptr(b["stats"][3:]), nat.ptr(b["prep_ws"]), b["prep_ws"].numel() * 8, nat.stream())
+
+            if mode == "exact":
+                # pass 1: raw sums -> global means (tdvp.py:37,41); tiny all-reduce when sharded
+                prepare(None, False)
+                nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, f32, P, n, nat.ptr(e), None, None, nat.ptr(b["rowsum"]),
+                         nat.ptr(b["rowdot"]), nat.stream())
+                if world > 1:
+                    small = torch.cat([b["rowsum"], b["sums"][:1], b["count"]])
+                    mpi.allreduce_sum_(small)
+                    c, cE = small[:P] / small[P + 1], small[P:P + 1] / small[P + 1]
+                else:
+                    c, cE = b["rowsum"] / n, b["sums"][:1] / n
+                if bordered:
+                    prepare(cE, True)
+            else:       # the previous call's global means are the shift of the one-pass moments (no copies: the buffers are per call)
+                c, cE = self._c_prev, self._cE_prev
+                prepare(cE, bordered)
+            c_gram = c if shift_mode == "centred" else None
+            # pass 2 (tdvp.py:40-45 in shifted form): sum (O - c), sum (O - c)(E - cE); and the syrk (tdvp.py:46)
+            if not bordered:
+                nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, f32, P, n, nat.ptr(e), nat.ptr(c), nat.ptr(cE), nat.ptr(b["rowsum"]),
+                         nat.ptr(b["rowdot"]), nat.stream())
             self._gram(b, JT, ldj, P + 2 if bordered else P, n, c_gram, None, b["packed"])
             mpi.allreduce_sum_(b["pack"])            # the one collective of the step (no-op on a single rank)
-            if bordered:
-                nb = b["Ppad"] // nat.GRAM_TILE
-                last = b["packed"].view(-1, nat.GRAM_TILE, nat.GRAM_TILE)[-nb:]          # tiles (nb-1, 0..nb-1)
-                r = P - (nb - 1) * nat.GRAM_TILE
-                # shifted sums the finalize step expects: sum (O - c) and sum (O - c)(E - cE), over all ranks
-                torch.sub(last[:, r + 1, :].reshape(-1)[:P], b["c"] * Ntot, out=b["rowsum"])
-                torch.sub(last[:, r, :].reshape(-1)[:P], b["c"] * (b["sums"][0] - Ntot * b["cE"][0]), out=b["rowdot"])
-            use_chol = self._solver() == "cholesky"
             if use_chol and b["A"] is None:
                 b["A"] = torch.zeros((b["Ppad"], b["Ppad"]), dtype=global_defs.tReal, device=device)
-            nat.call("vmcpde_gram_finalize", nat.ptr(b["packed"]), nat.ptr(b["rowsum"]), nat.ptr(b["rowdot"]), nat.ptr(b["sums"]),
-                     nat.ptr(b["c"]), nat.ptr(c_gram), nat.ptr(b["cE"]), P, Ntot, float(self.diagonalShift), nat.ptr(b["S"]), b["Ppad"],
-                     nat.ptr(b["A"]) if use_chol else None, b["Ppad"], nat.ptr(b["F"]), nat.ptr(b["mean"]), nat.stream())
+            # the bordered Cholesky (row P of A = F, corner = a huge pivot) gets its border row from the same kernel
+            chol_border = use_chol and P < b["Ppad"]
+            mask = self._frozen_mask(P, device) if self.frozenParameters is not None else None
+            nat.call("vmcpde_tdvp_moments", nat.ptr(b["packed"]), P, 1 if bordered else 0, nat.ptr(b["rowsum"]), nat.ptr(b["rowdot"]),
+                     nat.ptr(b["sums"]), Ntot, nat.ptr(c), nat.ptr(c_gram), nat.ptr(cE), nat.ptr(mask), nat.ptr(b["F"]), nat.ptr(mean),
+                     nat.ptr(b["diagS"]), nat.ptr(scal), float(self.svdTol) if use_chol else 0.0,
+                     nat.ptr(b["A"][P]) if chol_border else None, _BORDER_PIVOT, nat.stream())
+            # absolute floor svdTol * max diag(S) (scal[6]): the Tikhonov counterpart of the reference's spectral cut-off at
+            # svdTol * lambda_max (tdvp.py:82-85).  The relative shift alone leaves parameters whose gradient is ~0 (S_ii ~ 1e-18 at
+            # the reference's 1e-5 initialisation) with updates ~ 1/sqrt(S_ii), which no time step survives.
+            nat.call("vmcpde_gram_finalize", nat.ptr(b["packed"]), nat.ptr(b["rowsum"]), None, None, nat.ptr(c), nat.ptr(c_gram), None, P, Ntot,
+                     float(self.diagonalShift), nat.ptr(scal[6:]) if use_chol else None, nat.ptr(b["S"]), b["Ppad"],
+                     nat.ptr(b["A"]) if use_chol else None, b["Ppad"], None, None, nat.stream())
             if self.frozenParameters is not None:
                 idx = self._frozen_index(device)
                 b["S"][idx, :] = 0.0
                 b["S"][:, idx] = 0.0
                 b["F"][idx] = 0.0
+                b["diagS"][idx] = 0.0
                 if use_chol:
-                    b["A"][idx, :] = 0.0
-                    b["A"][:, idx] = 0.0
+                    b["A"][idx, :P] = 0.0
+                    b["A"][:P, idx] = 0.0
+                    b["A"][idx, idx] = scal[6]         # the floor alone: a positive pivot, update exactly 0 (F is 0 there)
+                    if chol_border:
+                        b["A"][P, idx] = 0.0
             if self.gramShift == "auto":     # asynchronous safety check for the next call: no host sync here
-                diag = torch.diagonal(b["S"])[:P]
-                m2 = b["mean"] ** 2
-                if self.frozenParameters is not None:
-                    m2[self._frozen_index(device)] = 0.0      # their variance was zeroed above; they take no part in the solve
-                ratio = torch.where(diag > 0, m2 / diag, torch.where(m2 > 0, torch.full_like(m2, float("inf")), torch.zeros_like(m2))).max()
                 if self._ratio_host is None:
                     self._ratio_host = torch.empty(1, dtype=global_defs.tReal).pin_memory()
                     self._ratio_event = torch.cuda.Event()
-                self._ratio_host.copy_(ratio.reshape(1), non_blocking=True)
+                self._ratio_host.copy_(scal[4:5], non_blocking=True)
                 self._ratio_event.record()
-        sums = b["sums"]
-        self.ElocMean = sums[0] / Ntot                                        # tdvp.py:37
-        self.ElocMeanAbs = sums[2] / Ntot                                     # tdvp.py:38
-        self.ElocVar = sums[1] / Ntot - self.ElocMean ** 2                    # tdvp.py:39
-        self._Esq_mean = sums[1] / Ntot
-        self._c_prev, self._cE_prev = b["mean"].clone(), self.ElocMean.reshape(1).clone()
+        self.ElocMean, self.ElocMeanAbs, self.ElocVar = scal[0], scal[1], scal[2]     # tdvp.py:37-39
+        self._scal = scal
+        self._floor = scal[6] if (use_chol and self.svdTol > 0) else None
+        self._c_prev, self._cE_prev = mean, scal[0:1]
         self.F0 = b["F"][:P]
         self.S0 = b["S"][:P, :P]
-        # SExp / rhoVar / snr are evaluated lazily from the retained Jacobian, which is psi's per-N workspace (2 GB at C2: not
-        # copied).  The N-sized vectors are cloned; for the Jacobian the workspace generation is recorded and checked on use.
-        self._lazy = dict(JT=JT, ldj=ldj, P=P, n=n, Ntot=Ntot, e=e.clone(), logp=logProbs.reshape(-1).clone(), b=b,
-                          mean=b["mean"].clone(), Emean=self.ElocMean.clone(),
+        # SExp / rhoVar / snr are evaluated lazily from the retained Jacobian and log-probabilities, which live in psi's per-N
+        # workspace (2 GB at C2: not copied): its generation is recorded here and checked on use.
+        self._lazy = dict(JT=JT, ldj=ldj, P=P, n=n, Ntot=Ntot, e=e, logp=logProbs.reshape(-1), b=b, mean=mean, Emean=scal[0],
+                          chol_border=chol_border,
                           owner=psi if jt is not None else None,
                           gen=psi.workspace_generation(n) if jt is not None else None)
         self._SExp = self._rhoVar = self._snr = self._S = None
         return self.F0
+
+    def _frozen_mask(self, P, device):
+        m = getattr(self, "_frozen_mask_t", None)
+        if m is None or m.device != device or m.numel() != P:
+            m = torch.ones(P, dtype=global_defs.tReal, device=device)
+            m[self._frozen_index(device)] = 0.0
+            self._frozen_mask_t = m
+        return m
 
     def _frozen_index(self, device):
         idx = getattr(self, "_frozen_idx", None)
@@ -269,7 +278,7 @@ class TDVP:
         with torch.cuda.device(w.device):
             self._gram(b, z["JT"], z["ldj"], P, z["n"], z["mean"], w.contiguous(), tmp)
             mpi.allreduce_sum_(tmp)
-            nat.call("vmcpde_gram_finalize", nat.ptr(tmp), nat.ptr(zero), None, None, None, None, None, P, z["Ntot"], 0.0, nat.ptr(out),
+            nat.call("vmcpde_gram_finalize", nat.ptr(tmp), nat.ptr(zero), None, None, None, None, None, P, z["Ntot"], 0.0, None, nat.ptr(out),
                      b["Ppad"], None, 0, None, None, nat.stream())
         if self.frozenParameters is not None:
             idx = self._frozen_index(w.device)
@@ -314,16 +323,13 @@ class TDVP:
         return "eigh" if self.solver == "auto" else self.solver
 
     # ---- Cholesky health: pinned pivots and the solver residual ------------------------------------------------------
-    def _record_guard(self, info, residual):
-        """Queue (pinned-pivot count, residual) of this solve for the host without synchronising: checked by `_check_guard`
-        at the next host-side guard (the NaN check of `__call__`, or the start of the next solve when observables are off)."""
+    def _record_guard(self, out):
+        """Queue (residual, pinned-pivot count) of this solve for the host without synchronising: checked by `_check_guard` at
+        the next host-side guard (the NaN check of `__call__`, or the start of the next right-hand side when observables are off)."""
         if self._guard_host is None:
-            self._guard_host = torch.empty(2, dtype=global_defs.tReal).pin_memory()
-            self._guard_dev = torch.empty(2, dtype=global_defs.tReal, device=residual.device)
+            self._guard_host = torch.empty(4, dtype=global_defs.tReal).pin_memory()
             self._guard_event = torch.cuda.Event()
-        self._guard_dev[0] = info[0]
-        self._guard_dev[1] = residual
-        self._guard_host.copy_(self._guard_dev, non_blocking=True)
+        self._guard_host.copy_(out, non_blocking=True)
         self._guard_event.record()
         self._guard_pending = True
 
@@ -334,7 +340,7 @@ class TDVP:
             return
         self._guard_event.synchronize()
         self._guard_pending = False
-        pinned, resid = int(self._guard_host[0]), float(self._guard_host[1])
+        resid, pinned = float(self._guard_host[0]), int(self._guard_host[2])
         if not (resid <= self.residualBound):      # also catches NaN
             raise FloatingPointError(f"on-device Cholesky failed ({when}): solver residual {resid:.3e} > {self.residualBound:g} with "
                                      f"{pinned} pinned pivot(s); S + shift is not positive definite -- raise diagonalShift / svdTol "
@@ -384,16 +390,7 @@ class TDVP:
                 need = nat.lib().vmcpde_chol_workspace_bytes(Pf)
                 if b["chol_ws"] is None or b["chol_ws"].numel() * 8 < need:
                     b["chol_ws"] = torch.empty(need // 8, dtype=global_defs.tReal, device=device)
-                # absolute floor svdTol * max diag(S): the Tikhonov counterpart of the reference's spectral cut-off at
-                # svdTol * lambda_max (tdvp.py:82-85).  The relative shift alone leaves parameters whose gradient is ~0 (S_ii
-                # ~ 1e-18 at the reference's 1e-5 initialisation) with updates ~ 1/sqrt(S_ii), which no time step survives.
-                self._floor = None
-                if self.svdTol > 0:
-                    self._floor = float(self.svdTol) * torch.diagonal(b["S"])[:P].max()
-                    torch.diagonal(A)[:P].add_(self._floor)
-                if bordered:
-                    A[P, :P].copy_(F)
-                    A[P, P] = _BORDER_PIVOT
+                # (A = S + shift diag(S) + floor I, and the border row [F, beta] when `bordered`, were written by get_tdvp_equation)
                 nat.call("vmcpde_cholesky", nat.ptr(A), Ppad, Pf, nat.ptr(b["info"]), nat.ptr(b["chol_ws"]), need, nat.stream())
                 if bordered:     # the forward substitution rode along with the factorisation (32 dependent launches less)
                     nat.call("vmcpde_chol_backsolve", nat.ptr(A), Ppad, P, nat.ptr(A[P]), nat.ptr(update), nat.ptr(b["chol_ws"]), need,
@@ -410,19 +407,18 @@ class TDVP:
                 nat.call("vmcpde_pinv_coeffs", nat.ptr(self.ev), nat.ptr(self.VtF), nat.ptr(snr), P, float(self.svdTol),
                          float(self.snrTol), nat.ptr(coef), nat.stream())                              # tdvp.py:82-85
                 nat.call("vmcpde_gemv", nat.ptr(self.V), P, P, P, 0, nat.ptr(coef), nat.ptr(update), nat.stream())   # tdvp.py:91
-            # residual and TDVP error (tdvp.py:93-94): S0 u once, the shifted S adds diagonalShift*diag(S0)*u
+            # residual and TDVP error (tdvp.py:93-94) from one S0 u: the shifted S adds (diagonalShift diag(S0) + floor) u
             S0u = torch.empty(P, dtype=global_defs.tReal, device=device)
+            out = torch.empty(4, dtype=global_defs.tReal, device=device)
+            chol = self._solver() == "cholesky"
             nat.call("vmcpde_gemv", nat.ptr(b["S"]), b["Ppad"], P, P, 0, nat.ptr(update), nat.ptr(S0u), nat.stream())
-        Su = S0u
-        if self.diagonalShift > 1e-10:
-            Su = S0u + self.diagonalShift * torch.diagonal(self.S0) * update
-        if self._solver() == "cholesky" and self._floor is not None:
-            Su = Su + self._floor * update              # the system the Cholesky path solves
-        tdvp_error = 1 + (update @ S0u - 2 * (self.F0 @ update)) / self._Esq_mean                      # tdvp.py:93
-        residual = torch.linalg.norm(Su - F) / torch.linalg.norm(F)                                     # tdvp.py:94
-        if self._solver() == "cholesky":
-            self._record_guard(b["info"], residual)
-        return update, residual, tdvp_error
+            nat.call("vmcpde_tdvp_diagnostics", nat.ptr(update), nat.ptr(S0u), nat.ptr(b["F"]), nat.ptr(b["diagS"]), P,
+                     float(self.diagonalShift) if self.diagonalShift > 1e-10 else 0.0,
+                     nat.ptr(self._floor) if (chol and self._floor is not None) else None, nat.ptr(self._scal),
+                     nat.ptr(b["info"]) if chol else None, nat.ptr(out), nat.stream())
+            if chol:
+                self._record_guard(out)
+        return update, out[0], out[1]
 
     # ---- tdvp.py:96-164 ------------------------------------------------------------------------------------------
     def __call__(self, netParameters, t, psi, evolutionEq, **rhsArgs):
