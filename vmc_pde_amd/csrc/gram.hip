@@ -39,26 +39,35 @@ struct GramPlan {
   int64_t chunk;   // samples per split (multiple of BK)
 };
 
+constexpr int DEFAULT_ORDER = 1;
+int gram_order() { return env_int("VMCPDE_GRAM_ORDER", DEFAULT_ORDER); }
+
 GramPlan make_plan(int P, int64_t N, int slots /* resident workgroups: 256 CUs x 2 (register-staged) or x 3 (DMA) */) {
   GramPlan g;
   g.nb = (P + TILE - 1) / TILE;
   g.ntiles = (int)tri_count(g.nb);
-  // aim at >= 8 rounds of the resident workgroup slots but keep each unit >= 64 K-steps so
-  // prologue/epilogue stay negligible; among the next few split factors take the one whose last round is fullest
+  // aim at >= 8 rounds of the resident workgroup slots but keep each unit >= 64 K-steps so prologue/epilogue stay negligible;
+  // among the neighbouring split factors take the one whose LAST round is fullest.  Rounds are counted the way the work is dealt
+  // out (gram_unit): with order 1 every XCD owns ceil(ntiles/8) tiles of each split and has slots/8 resident workgroups, so the
+  // count that matters is per XCD -- at C2 (561 tiles) 10 splits are 710 units on 64 slots = 11.09 rounds, i.e. a twelfth, nearly
+  // empty round, while 9 splits are 9.98 rounds (measured 17.25 ms against 17.88 ms).
   const int64_t ksteps = (N + BK - 1) / BK;
   int64_t want = (8 * (int64_t)slots + g.ntiles - 1) / g.ntiles;
   int64_t maxsplit = ksteps / 64;
   if (maxsplit < 1) maxsplit = 1;
+  if (maxsplit > 64) maxsplit = 64;
   int64_t ns = want < maxsplit ? want : maxsplit;
   if (ns < 1) ns = 1;
-  if (ns > 64) ns = 64;
   if (ns > 1) {
+    const bool per_xcd = gram_order() == 1;
+    const int64_t units1 = per_xcd ? (g.ntiles + 7) / 8 : g.ntiles;      // units per split in one scheduling domain
+    const int64_t dom_slots = per_xcd ? slots / 8 : slots;
     double best = 1e30;
     int64_t pick = ns;
-    for (int64_t c = ns; c <= ns + 4 && c <= maxsplit && c <= 64; ++c) {
-      const double rounds = (double)(g.ntiles * c) / (double)slots;
-      const double waste = (double)(int64_t)(rounds + 0.999999) / rounds;   // ceil(rounds) / rounds
-      if (waste < best - 1e-9) { best = waste; pick = c; }
+    for (int64_t c = (ns > 3 ? ns - 2 : 1); c <= ns + 10 && c <= maxsplit; ++c) {
+      const int64_t rounds = (units1 * c + dom_slots - 1) / dom_slots;
+      const double cost = (double)rounds / (double)c;                      // time ~ rounds x (samples per unit ~ 1/c)
+      if (cost < best - 1e-9) { best = cost; pick = c; }
     }
     ns = pick;
   }
@@ -372,7 +381,7 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
     out = static_cast<double*>(workspace);
   }
   hipStream_t st = (hipStream_t)stream;
-  const int order = env_int("VMCPDE_GRAM_ORDER", 1);   // tuning knob
+  const int order = gram_order();   // tuning knob
   const int total = g.ntiles * g.nsplit;
   const int per_xcd = (order == 1) ? (g.ntiles + 7) / 8 : (total + 7) / 8;
   const int grid = (order == 1) ? per_xcd * 8 * g.nsplit : per_xcd * 8;
