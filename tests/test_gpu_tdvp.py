@@ -120,12 +120,19 @@ def test_tdvp_snr_regularised_solve_parity(case):
     assert float(torch.linalg.norm(to.S0 @ (upd_o - upd_plain)) / nF) > 1e-3
     assert float(torch.linalg.norm(to.S0 @ (upd_p.cpu() - upd_o)) / nF) < 1e-9
     assert abs(float(tp.tdvp_error) - float(to.tdvp_error)) < 1e-7
-    # snr_k on the significant modes (eigenvectors of near-degenerate pairs rotate between two eigh's: 7e-7 measured)
-    well = to.ev > 1e-9 * to.ev[-1]
+    # snr_k and rhoVar_k mode by mode.  They are functions of the eigenVECTOR v_k, which two correctly rounded eigh's determine only
+    # to |dS| / gap_k: compare where the eigenvalue is separated from its neighbours by more than 1e-6 lambda_max (perturbation
+    # ~1e-12 lambda_max / gap -> relative differences up to ~1e-5 in v_k, asserted 1e-4), and loosely on every significant mode
+    ev = to.ev
+    gap = torch.minimum(torch.diff(ev, prepend=ev[:1] - ev[-1]), torch.diff(ev, append=ev[-1:] + ev[-1]))
+    well = ev > 1e-9 * ev[-1]
+    isolated = well & (gap > 1e-6 * ev[-1])
+    assert int(isolated.sum()) >= 5
     snr_p, snr_o = tp.snr.cpu(), to.snr
-    assert float(((snr_p[well] - snr_o[well]).abs() / snr_o[well]).max()) < 1e-5
     rho_p, rho_o = tp.rhoVar.cpu(), to.rhoVar
-    assert float(((rho_p[well] - rho_o[well]).abs() / rho_o[well].abs()).max()) < 1e-5
+    assert float(((snr_p[isolated] - snr_o[isolated]).abs() / snr_o[isolated]).max()) < 1e-4
+    assert float(((rho_p[isolated] - rho_o[isolated]).abs() / rho_o[isolated].abs()).max()) < 1e-4
+    assert float(((snr_p[well] - snr_o[well]).abs() / (snr_o[well] + 1e-3 * snr_o[well].max())).max()) < 1e-2
     # a Cholesky factor has no eigenbasis: the combination is refused instead of silently dropping the SNR cut-off
     with pytest.raises(ValueError, match="useSNR"):
         V.TDVP(useSNR=True, solver="cholesky", diagonalShift=1e-4)

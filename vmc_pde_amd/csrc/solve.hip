@@ -146,6 +146,116 @@ __device__ __forceinline__ int factor_inverse_32(double* a, int j0, double* scr,
   return pinned;
 }
 
+// The same job on the matrix pipe, without lane broadcasts.  The 32 x 32 block lives in registers in the f64 MFMA C/D layout
+// (element (r, c) of a 16 x 16 block: lane c + 16 (r & 3), register r >> 2) as the three upper blocks C00, C01, C11 of the
+// symmetric matrix, next to W = [W00 0; W10 W11] which starts as the identity.  One elimination step j divides row j by
+// sqrt(pivot) -- that row IS U[j][:] = L[:][j]^T, and in this layout it sits in ONE register of the 16 lanes of group j & 3,
+// which is exactly where an A operand (rows, k = j & 3) and a B operand (k = j & 3, columns) of v_mfma_f64_16x16x4 are read
+// from.  So the rank-1 trailing update C -= m m^T is one MFMA per block with both operands taken from that register (other
+// lane groups masked to zero), and the same row operations applied to W turn the identity into L^-1 (W -= m w_j^T).
+// Per step: one v_readlane pair for the pivot, the rsq / Newton chain, a few selects, then 5 MFMAs (pivot in C00) or 3
+// (pivot in C11) -- 128 MFMAs per block against ~1100 v_readlane + 1000 FMA-lane-instructions in the broadcast version.
+// NEGATIVE RESULT, kept for the record (-DVMC_CHOL_SWEEP_MFMA): 7.3 us per block against 6.7 us for factor_inverse_32.  fp64
+// MFMA and fp64 VALU share one datapath on this chip (tools/microbench/dual_issue.hip), so the 128 rank-1 MFMAs (64 cycles
+// each, three quarters of their K = 4 unused) cost 8200 cycles by themselves and the pivot chains do not hide behind them.
+// Batching four pivots per MFMA would need the four rows of a micro-panel (same register, four lane groups) eliminated
+// against each other first, i.e. cross-lane-group moves per pivot -- not pursued.
+// Interface as factor_inverse_32: L to the lower triangle of `a`, X = L^-1 transposed into the strict upper part
+// (X[r][c] <-> a[c][r+1]); returns the number of pinned pivots.
+__device__ __forceinline__ void pivot_step_scalars(double p, double& d, double& inv_d, double& wscale, int& pinned) {
+  const bool bad = !(p > 0.0) || !isfinite(p);     // wave-uniform: dead / padded parameter (H7) -> unit row
+  pinned += bad ? 1 : 0;
+  sqrt_rsqrt(p, d, inv_d);
+  d = bad ? 1.0 : d;
+  inv_d = bad ? 0.0 : inv_d;                       // pinned: no multipliers below ...
+  wscale = bad ? 1.0 : inv_d;                      // ... and a unit diagonal for the inverse
+}
+
+__device__ __forceinline__ int factor_inverse_32_mfma(double* a, int j0) {
+  int lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));                   // (see factor_inverse_32: keeps lane-only values out of the caller's loop)
+  const int g = lane >> 4, cc = lane & 15;
+  double4_t C00, C01, C11, W00, W10, W11;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = g + 4 * q;
+    // everything is read from the LOWER triangle (the caller's matrix need not be stored symmetrically -- the border row of
+    // the bordered factorisation exists only there --, and only the lower blocks are kept up to date by the trailing updates)
+    const int lo = (cc <= r) ? r : cc, hi = (cc <= r) ? cc : r;
+    C00[q] = a[(j0 + lo) * DP + j0 + hi];
+    C11[q] = a[(j0 + 16 + lo) * DP + j0 + 16 + hi];
+    C01[q] = a[(j0 + 16 + cc) * DP + j0 + r];       // A[r][16 + cc] = A[16 + cc][r]
+    W00[q] = (r == cc) ? 1.0 : 0.0;
+    W11[q] = W00[q];
+    W10[q] = 0.0;
+  }
+  int pinned = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {                   // pivots of the first 16 x 16 block
+    const int gj = j & 3, qj = j >> 2;
+    const double p = readlane_f64(C00[qj], 16 * gj + j);
+    double d, inv_d, wscale;
+    pivot_step_scalars(p, d, inv_d, wscale, pinned);
+    const bool in = (g == gj);
+    const double row0 = (cc == j) ? d : C00[qj] * inv_d;     // U[j][cc], cc >= j (entries left of the diagonal are never stored)
+    const double row1 = C01[qj] * inv_d;                      // U[j][16 + cc]
+    const double w0 = W00[qj] * wscale;                       // scaled row j of W
+    C00[qj] = in ? row0 : C00[qj];
+    C01[qj] = in ? row1 : C01[qj];
+    W00[qj] = in ? w0 : W00[qj];
+    const double m0 = (in && cc > j) ? row0 : 0.0;            // multipliers of the rows below the pivot, first / second block
+    const double m1 = in ? row1 : 0.0;
+    const double bw = in ? w0 : 0.0;
+    const double nm0 = -m0, nm1 = -m1;
+    C00 = __builtin_amdgcn_mfma_f64_16x16x4f64(nm0, m0, C00, 0, 0, 0);      // (the next pivot comes out of this one: issue it first)
+    C01 = __builtin_amdgcn_mfma_f64_16x16x4f64(nm0, m1, C01, 0, 0, 0);
+    C11 = __builtin_amdgcn_mfma_f64_16x16x4f64(nm1, m1, C11, 0, 0, 0);
+    W00 = __builtin_amdgcn_mfma_f64_16x16x4f64(nm0, bw, W00, 0, 0, 0);
+    W10 = __builtin_amdgcn_mfma_f64_16x16x4f64(nm1, bw, W10, 0, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {                   // pivots of the second block
+    const int gj = j & 3, qj = j >> 2;
+    const double p = readlane_f64(C11[qj], 16 * gj + j);
+    double d, inv_d, wscale;
+    pivot_step_scalars(p, d, inv_d, wscale, pinned);
+    const bool in = (g == gj);
+    const double row1 = (cc == j) ? d : C11[qj] * inv_d;
+    const double w0 = W10[qj] * wscale, w1 = W11[qj] * wscale;
+    C11[qj] = in ? row1 : C11[qj];
+    W10[qj] = in ? w0 : W10[qj];
+    W11[qj] = in ? w1 : W11[qj];
+    const double m1 = (in && cc > j) ? row1 : 0.0;
+    const double bw0 = in ? w0 : 0.0, bw1 = in ? w1 : 0.0;
+    const double nm1 = -m1;
+    C11 = __builtin_amdgcn_mfma_f64_16x16x4f64(nm1, m1, C11, 0, 0, 0);
+    W10 = __builtin_amdgcn_mfma_f64_16x16x4f64(nm1, bw0, W10, 0, 0, 0);
+    W11 = __builtin_amdgcn_mfma_f64_16x16x4f64(nm1, bw1, W11, 0, 0, 0);
+  }
+  // U (upper triangular, rows r) -> L[c][r] in the lower triangle; W = L^-1 (lower triangular) -> transposed, one column to the right
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = g + 4 * q;
+    if (cc >= r) {
+      a[(j0 + cc) * DP + j0 + r] = C00[q];
+      a[(j0 + 16 + cc) * DP + j0 + 16 + r] = C11[q];
+    }
+    a[(j0 + 16 + cc) * DP + j0 + r] = C01[q];
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = g + 4 * q;
+    if (cc <= r) {
+      a[(j0 + cc) * DP + j0 + r + 1] = W00[q];
+      a[(j0 + 16 + cc) * DP + j0 + 16 + r + 1] = W11[q];
+    }
+    a[(j0 + cc) * DP + j0 + 16 + r + 1] = W10[q];
+  }
+  __builtin_amdgcn_wave_barrier();
+  return pinned;
+}
+
 // Factor the diagonal block A[k0:k0+n, k0:k0+n] = L L^T in LDS (four 32-wide sub-steps), write L back (lower triangle)
 // and X = L^-1 (dense lower triangular, zero elsewhere) to Linv.  One workgroup of 256 threads; rows/cols >= n are
 // padded with the identity.  LDS: the 128 x 129 block + three 32 x 33 scratch tiles.
@@ -233,7 +343,12 @@ __device__ __forceinline__ void chol_diag_body(double* __restrict__ A, int64_t l
   };
   auto sweep = [&](int j0) {
     if (phase >= 1 && t < 64) {
+#ifdef VMC_CHOL_SWEEP_MFMA     // measured slower (7.3 us against 6.7 us per block), see factor_inverse_32_mfma
+      (void)scr;
+      const int pinned = factor_inverse_32_mfma(a, j0);
+#else
       const int pinned = factor_inverse_32(a, j0, scr, phase >= 2);
+#endif
       if (t == 0 && pinned) atomicAdd(info, pinned);
     }
   };
