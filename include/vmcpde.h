@@ -113,10 +113,14 @@ int vmcpde_flow_sample(vmcpde_model* m, const double* theta, const double* z, in
  * hv[n][k] = v_k^T (Hessian_x logp) v_k for n_dirs caller-given directions dirs[k][d], and the parameter Jacobian.
  * Any of logp,g,hv,JT may be NULL (skipped).  JT: [dev] P * ldj, parameter-major, fp64 or (jt_f32 != 0) fp32 -- BASELINE
  * config 5 "fp32 Jacobian with fp64 S/F accumulate": only the stored Jacobian is rounded, S and F are accumulated in fp64.
- * dirs: [dev] n_dirs*d. */
+ * dirs: [dev] n_dirs*d.
+ * workspace: [dev] >= vmcpde_flow_eval_workspace_bytes(m, n_samples) or NULL.  With a workspace the forward pass keeps every
+ * network's hidden activations and outputs there (C2: 344 doubles per sample = 180 MB) and the reverse sweep reads them back;
+ * without, it re-evaluates each network (identical results, half of all tanh evaluations more). */
+int64_t vmcpde_flow_eval_workspace_bytes(const vmcpde_model* m, int64_t n_samples);
 int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const double* x, int64_t n_samples,
                      const double* dirs, int32_t n_dirs, double* logp, double* g, double* hv,
-                     void* JT, int64_t ldj, int32_t jt_f32, void* stream);
+                     void* JT, int64_t ldj, int32_t jt_f32, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- evolutionEq.py ------------------------------------------------------------------------------------ */
 /* evolutionEq.py:84-119 epilogue: Eloc_n from x, g and the directional second derivatives (J14 + eager einsums).

@@ -81,6 +81,22 @@ def test_flow_sample_and_eval_parity(cfg):
     assert float((Hp.cpu() - Ho).abs().max()) < 1e-10 * float(Ho.abs().max())
 
 
+@pytest.mark.parametrize("cfg", [CONFIGS[3], CONFIGS[8], CONFIGS[11]])
+def test_activation_workspace_variant_gives_identical_results(cfg):
+    """vmcpde_flow_eval with a workspace (the forward pass keeps the activations, the reverse sweep reads them back) against the
+    default (re-evaluation): same arithmetic on the same values, so logp, grad_x and the Jacobian must agree bit for bit."""
+    spec, th, z = _setup(cfg, 150)
+    out = {}
+    for keep in (False, True):
+        vs = make_varstate(spec, th)
+        vs.keep_activations = keep
+        x, _ = vs.flow_sample(z)
+        r = vs.evaluate(x, dirs=np.eye(spec.dim)[:2])
+        out[keep] = (r["logp"].clone(), r["g"].clone(), r["J"].clone(), r["hv"].clone())
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a, b)
+
+
 def test_empty_and_single_sample():
     spec, th, z = _setup(CONFIGS[2], 1)
     vs = make_varstate(spec, th)
@@ -89,7 +105,7 @@ def test_empty_and_single_sample():
     from vmc_pde_amd import _native as nat
     x0 = torch.empty((0, 3), dtype=torch.float64, device=vs.device)
     th_d = vs.get_parameters()
-    nat.call("vmcpde_flow_eval", vs.net.handle, nat.ptr(th_d), nat.ptr(x0), 0, None, 0, None, None, None, None, 0, 0, nat.stream())   # empty batch: no-op
+    nat.call("vmcpde_flow_eval", vs.net.handle, nat.ptr(th_d), nat.ptr(x0), 0, None, 0, None, None, None, None, 0, 0, None, 0, nat.stream())   # empty batch: no-op
 
 
 @pytest.mark.parametrize("latent", ["Gauss", "Student_t"])

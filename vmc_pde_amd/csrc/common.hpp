@@ -54,6 +54,7 @@ struct HalfStep {
   int32_t idx_a[MAX_HALF];  // coordinates fed to the conditioner
   int32_t idx_c[MAX_HALF];  // coordinates that get transformed
   int32_t has_t;
+  int32_t act_off_s, act_off_t;   // first unit of this half-step's s / t network in the activation workspace of flow_eval
   Trafo s, t;
 };
 
@@ -64,6 +65,7 @@ struct FlowProgram {
   int32_t off_L, off_Ldiag, off_dist, off_mu;
   int32_t max_width;     // widest MLP layer (incl. inputs/outputs)
   int32_t max_sum_act;   // max over trafos of (n_in + sum_hidden)
+  int32_t act_units;     // activation workspace: sum over all MLPs of (hidden widths + outputs) doubles per sample
   double alpha;          // SingleTrafo.alpha = 10 (net.py:50)
   int32_t global_change; // net.py:72: block b ends with y -> th[off_gscale[b]] * y + th[off_goffset[b] + i]
   int32_t off_goffset[VMCPDE_MAX_DEPTH], off_gscale[VMCPDE_MAX_DEPTH];

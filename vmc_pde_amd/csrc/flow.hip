@@ -117,6 +117,12 @@ struct Ctx {
   int64_t jpitch;     // bytes between consecutive Jacobian rows (ldj * element size) -- wave-uniform
   const double* __restrict__ th;
   const FlowProgram* __restrict__ fp;
+  // activation workspace (HBM, [unit][sample]): the forward pass leaves every MLP's hidden activations and outputs there so
+  // that the reverse sweep reads them back instead of re-evaluating the networks (half of all tanh evaluations otherwise)
+  double* __restrict__ actw;   // nullptr: recompute
+  int64_t ldw;                 // samples per workspace row
+  int64_t samp_st, samp_ld;    // this lane's column for stores (its sample) / loads (clamped into range for idle lanes)
+  bool act_store;              // this lane writes (a live sample) in a pass that is asked to store
 };
 
 #define LD(u) (c.lds[(u) * c.lanes + c.lane])
@@ -126,6 +132,9 @@ struct Ctx {
 // Jacobian stores.  A row pointer is wave-uniform (base + row * pitch: SGPR arithmetic) and the lane only adds its 32-bit
 // byte offset, which lets the store use the scalar-base + vector-offset addressing form -- no 64-bit VALU address per element.
 __device__ __forceinline__ void jt_store(const Ctx& c, void* __restrict__ JT, int64_t /*ldj*/, int64_t row, int64_t /*n*/, double v) {
+#ifdef VMC_FLOW_DIAG_NO_STORE      // timing diagnostics only: what the Jacobian stores cost
+  if (v != 1.2345e300) return;
+#endif
   char* rowp = static_cast<char*>(JT) + row * c.jpitch;
   if (c.jt_f32) *reinterpret_cast<float*>(rowp + c.joff) = (float)v;
   else *reinterpret_cast<double*>(rowp + c.joff) = v;
@@ -133,6 +142,9 @@ __device__ __forceinline__ void jt_store(const Ctx& c, void* __restrict__ JT, in
 // JB consecutive rows starting at `row0` (nj <= JB of them valid), values vals[jj] * scale: one precision branch and one
 // bounds decision per block instead of per element
 __device__ __forceinline__ void jt_store_block(const Ctx& c, void* __restrict__ JT, int64_t row0, int nj, const double (&vals)[JB], double scale) {
+#ifdef VMC_FLOW_DIAG_NO_STORE
+  if (scale * vals[0] != 1.2345e300) return;
+#endif
   char* p = static_cast<char*>(JT) + row0 * c.jpitch;
   if (c.jt_f32) {
     if (nj == JB) {
@@ -160,6 +172,9 @@ __device__ __forceinline__ void jt_store_block(const Ctx& c, void* __restrict__ 
 // (|r| <= ln2/2: remainder 4e-18), tanh|x| = (1 - t)/(1 + t) with v_rcp_f64 refined by two Newton steps and a residual
 // correction.  Activations are consumed linearly downstream, so absolute (not relative) accuracy near 0 is what matters.
 __device__ __forceinline__ double fast_tanh(double x) {
+#ifdef VMC_FLOW_DIAG_NO_TANH       // timing diagnostics only (wrong results): what the activation function costs
+  return x * 0.25;
+#endif
   const double ax = fmin(fabs(x), 20.0);                   // tanh(20) = 1 - 3e-18
   const double y = -2.0 * ax;
   const double n = rint(y * 1.4426950408889634074);
@@ -202,7 +217,7 @@ __device__ __forceinline__ void stage_weights(const Ctx& c, const DenseLayer& L)
 // y = tanh-layer(x): z_j = b_j + sum_i W[i][j] a_i (net.py:55-61), with NC Taylor components.
 // Cooperative: the input must be visible to all waves on entry; the caller synchronises before the output is read.
 template <int NC>
-__device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, int uin, int uout, int cs, double scale) {
+__device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, int uin, int uout, int cs, double scale, int wofs = -1) {
   const int n_in = L.n_in, n_out = L.n_out;
   const double* __restrict__ W = c.wl;                  // staged by the caller (stage_weights + barrier)
   const double* __restrict__ Bv = c.wl + n_in * n_out;
@@ -236,6 +251,7 @@ __device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, i
         const double h = fast_tanh(acc[0][jj]);
 #endif
         LD(uout + j0 + jj) = scale * h;
+        if (wofs >= 0 && c.act_store) c.actw[(int64_t)(wofs + j0 + jj) * c.ldw + c.samp_st] = scale * h;
         if (NC == 3) {
           const double hp = 1.0 - h * h;
           const double z1 = acc[1][jj], z2 = acc[2][jj];
@@ -248,14 +264,18 @@ __device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, i
 }
 
 // SingleTrafo forward (net.py:53-61), ping-pong between buffers uA (holding the input) and uB. Returns output base.
+// wofs >= 0: the value component of every layer output also goes to the activation workspace, hidden layers first (in layer
+// order), then the outputs -- the order mlp_load_activations reads them back in.
 template <int NC>
-__device__ __forceinline__ int mlp_forward(const Ctx& c, const Trafo& T, int uA, int uB, int cs) {
+__device__ __forceinline__ int mlp_forward(const Ctx& c, const Trafo& T, int uA, int uB, int cs, int wofs = -1) {
   int cur = uA, nxt = uB;
+  int wl = wofs;
   for (int k = 0; k < T.n_layers; ++k) {
     stage_weights(c, T.layer[k]);
     SYNC();
-    dense_layer<NC>(c, T.layer[k], cur, nxt, cs, (k == T.n_layers - 1) ? c.fp->alpha : 1.0);
+    dense_layer<NC>(c, T.layer[k], cur, nxt, cs, (k == T.n_layers - 1) ? c.fp->alpha : 1.0, wl);
     SYNC();
+    if (wl >= 0) wl += T.layer[k].n_out;
     const int t = cur; cur = nxt; nxt = t;
   }
   return cur;
@@ -271,7 +291,8 @@ __device__ __forceinline__ void halfstep_forward(const Ctx& c, const HalfStep& h
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) LD(r.A + cc * cs + i) = LD(r.X + cc * d + h.idx_a[i]);
   SYNC();
-  int us = mlp_forward<NC>(c, h.s, r.A, r.B, cs);
+  const bool keep = (c.actw != nullptr);
+  int us = mlp_forward<NC>(c, h.s, r.A, r.B, cs, keep ? h.act_off_s : -1);
   int ut = 0;
   const int coupling = c.fp->coupling;
   if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) {
@@ -284,7 +305,7 @@ __device__ __forceinline__ void halfstep_forward(const Ctx& c, const HalfStep& h
         for (int cc = 0; cc < NC; ++cc) LD(r.A + cc * cs + i) = LD(r.X + cc * d + h.idx_a[i]);
     }
     SYNC();
-    ut = mlp_forward<NC>(c, h.t, r.A, r.B, cs);
+    ut = mlp_forward<NC>(c, h.t, r.A, r.B, cs, keep ? h.act_off_t : -1);
   }
   if (!W0) return;     // (the next stage starts with a barrier that wave 0 reaches after the update below)
   for (int k = 0; k < h.n_c; ++k) {
@@ -471,6 +492,17 @@ __device__ __forceinline__ void mlp_forward_store(const Ctx& c, const Trafo& T, 
   }
 }
 
+// The same result read back from the activation workspace the forward pass filled (mlp_forward with wofs >= 0): hidden
+// activations behind the n_in inputs already in ACT, outputs to uOUT.  Units go round-robin over the waves.
+__device__ __forceinline__ void mlp_load_activations(const Ctx& c, const Trafo& T, int uACT, int uOUT, int wofs) {
+  const int nh = T.sum_hidden, total = nh + T.n_out;
+  for (int u = c.wave; u < total; u += c.nw) {
+    const double v = c.actw[(int64_t)(wofs + u) * c.ldw + c.samp_ld];
+    LD((u < nh) ? (uACT + T.n_in + u) : (uOUT + u - nh)) = v;
+  }
+  SYNC();
+}
+
 // Reverse pass through one SingleTrafo with output cotangent in uW: writes the parameter-gradient rows of this
 // sample into JT (bias: delta_j, kernel: a_i delta_j) and accumulates the input gradient into GAM.
 // Cooperative: every layer is split by INPUT unit i (wave w owns i = w, w+nw, ...): the owner forms
@@ -543,13 +575,15 @@ __device__ __forceinline__ void halfstep_backward(const Ctx& c, const HalfStep& 
   SYNC();
   if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) {
     // t enters additively (net.py:94): its output cotangent is G_c itself
-    mlp_forward_store(c, h.t, r.ACT, r.OUTT);
+    if (c.actw) mlp_load_activations(c, h.t, r.ACT, r.OUTT, h.act_off_t);
+    else mlp_forward_store(c, h.t, r.ACT, r.OUTT);
     if (W0)
       for (int k = 0; k < h.n_c; ++k) LD(r.DW + k) = LD(r.G + h.idx_c[k]);
     mlp_backward(c, h.t, r, r.OUTT, r.DW, JT, ldj, n, active);     // (starts with wave 0's part, then a barrier)
     // ACT[0..n_a) still holds the half-step input for the s network
   }
-  mlp_forward_store(c, h.s, r.ACT, r.OUTS);
+  if (c.actw) mlp_load_activations(c, h.s, r.ACT, r.OUTS, h.act_off_s);
+  else mlp_forward_store(c, h.s, r.ACT, r.OUTS);
   if (W0) {
     for (int k = 0; k < h.n_c; ++k) {
       const int ix = h.idx_c[k];
@@ -628,7 +662,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_eval_kernel(const Flow
                                                       int64_t N, const double* __restrict__ dirs, int n_dirs,
                                                       double* __restrict__ logp, double* __restrict__ g,
                                                       double* __restrict__ hv, void* __restrict__ JT, int64_t ldj, int jt_f32,
-                                                      int lanes, Regions r) {
+                                                      double* __restrict__ actw, int64_t ldw, int lanes, Regions r) {
   extern __shared__ double lds[];
   Ctx c;
   c.lds = lds;
@@ -639,6 +673,9 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_eval_kernel(const Flow
   c.th = th;
   c.fp = fp;
   c.jt_f32 = jt_f32;
+  const bool reverse = (g != nullptr || JT != nullptr);
+  c.actw = reverse ? actw : nullptr;      // nothing to keep if no reverse sweep follows
+  c.ldw = ldw;
   // lanes beyond `lanes` (narrow workgroups of very wide networks) shadow lane 0: same sample, same LDS slots, same
   // values, in lockstep with it inside the wave -- they must stay alive for the workgroup barriers
   const int lane = (int)threadIdx.x & 63;
@@ -650,11 +687,15 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_eval_kernel(const Flow
   const int64_t nn = (n < N) ? n : (N - 1);
   c.joff = (uint32_t)n * (jt_f32 ? 4u : 8u);
   c.jpitch = ldj * (jt_f32 ? 4 : 8);
+  c.samp_st = n;
+  c.samp_ld = nn;
+  c.act_store = false;
 
   // wave 0 owns the per-sample state and the scalar results; all waves walk the same sequence of stages
   double lp_val = 0.0;
   if (n_dirs > 0 && hv != nullptr) {
     for (int k = 0; k < n_dirs; ++k) {
+      c.act_store = active && c.actw != nullptr && k == 0;       // the value component is the same for every direction
       if (W0)
         for (int i = 0; i < d; ++i) {
           LD(r.X + i) = x[nn * d + i];
@@ -673,6 +714,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_eval_kernel(const Flow
       }
     }
   } else {
+    c.act_store = active && c.actw != nullptr;
     if (W0)
       for (int i = 0; i < d; ++i) LD(r.X + i) = x[nn * d + i];
     double lj[1] = {0}, lp[1];
@@ -686,7 +728,12 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_eval_kernel(const Flow
     }
   }
   if (logp != nullptr && active && W0) logp[n] = lp_val;
-  if (g == nullptr && JT == nullptr) return;
+  if (!reverse) return;
+  c.act_store = false;
+  if (c.actw) {          // the stores above must be visible to the loads of the reverse sweep (other waves of this workgroup)
+    __threadfence_block();
+    SYNC();
+  }
 
   // reverse sweep: X currently holds z
   if (W0) latent_backward(c, lc, r, JT, ldj, n, active);
@@ -713,6 +760,10 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_sample_kernel(const Fl
   c.th = th;
   c.fp = fp;
   c.jt_f32 = 0;
+  c.actw = nullptr;
+  c.ldw = 0;
+  c.samp_st = c.samp_ld = 0;
+  c.act_store = false;
   const int lane = (int)threadIdx.x & 63;
   const bool lane_ok = lane < lanes;
   c.lane = lane_ok ? lane : 0;            // see flow_eval_kernel
@@ -917,9 +968,15 @@ int vmcpde_prepare_latent_internal(vmcpde_model* m, const double* theta, hipStre
   return 0;
 }
 
+extern "C" int64_t vmcpde_flow_eval_workspace_bytes(const vmcpde_model* m, int64_t n_samples) {
+  if (!m || n_samples <= 0) return 0;
+  const int64_t ldw = (n_samples + 63) / 64 * 64;
+  return (int64_t)m->host.act_units * ldw * (int64_t)sizeof(double);
+}
+
 extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const double* x, int64_t n_samples,
                                 const double* dirs, int32_t n_dirs, double* logp, double* g, double* hv,
-                                void* JT, int64_t ldj, int32_t jt_f32, void* stream) {
+                                void* JT, int64_t ldj, int32_t jt_f32, void* workspace, int64_t workspace_bytes, void* stream) {
   VMC_REQUIRE(n_samples >= 0, "negative sample count");
   if (n_samples == 0) return 0;   // empty batch (torch gives a NULL data pointer for it)
   VMC_REQUIRE(m && theta && x, "vmcpde_flow_eval: null argument");
@@ -943,8 +1000,11 @@ extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const doub
     }
   }
   const int64_t grid = (n_samples + lanes - 1) / lanes;
+  VMC_REQUIRE(workspace == nullptr || workspace_bytes >= vmcpde_flow_eval_workspace_bytes(m, n_samples),
+              "flow_eval workspace too small: need %lld bytes", (long long)vmcpde_flow_eval_workspace_bytes(m, n_samples));
   hipLaunchKernelGGL(flow_eval_kernel, dim3((unsigned)grid), dim3(64 * pick_waves(m->host)), bytes, st, m->dev, m->cache, theta, x, n_samples,
-                     dirs, (hv ? n_dirs : 0), logp, g, hv, JT, ldj, (int)jt_f32, lanes, r);
+                     dirs, (hv ? n_dirs : 0), logp, g, hv, JT, ldj, (int)jt_f32, static_cast<double*>(workspace),
+                     (int64_t)((n_samples + 63) / 64 * 64), lanes, r);
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -181,9 +181,13 @@ extern "C" int vmcpde_create(const vmcpde_model_desc* desc, vmcpde_model** out) 
     h1.has_t = has_t;
     fill_trafo(h1.s, d.n_up, n_dn, d, tab->off[b][0]);
     if (has_t) fill_trafo(h1.t, d.n_up, n_dn, d, tab->off[b][2]);
-    for (const HalfStep* h : {&h0, &h1}) {
+    for (HalfStep* h : {&h0, &h1}) {
       fp.max_width = std::max(fp.max_width, h->s.max_width);
       fp.max_sum_act = std::max(fp.max_sum_act, h->s.n_in + h->s.sum_hidden);
+      h->act_off_s = fp.act_units;
+      fp.act_units += h->s.sum_hidden + h->s.n_out;
+      h->act_off_t = fp.act_units;
+      if (has_t) fp.act_units += h->t.sum_hidden + h->t.n_out;
     }
   }
 

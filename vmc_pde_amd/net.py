@@ -164,7 +164,7 @@ class INNwProb:
                     raise NotImplementedError("evaluate=True with inv=True is never used by the reference")
                 logp = torch.empty(n, dtype=global_defs.tReal, device=self.device)
                 nat.call("vmcpde_flow_eval", self.handle, nat.ptr(theta), nat.ptr(xb), n, None, 0, nat.ptr(logp), None, None,
-                         None, 0, 0, nat.stream())
+                         None, 0, 0, None, 0, nat.stream())
                 return logp[0] if single else logp
             y = torch.empty_like(xb)
             logp = torch.empty(n, dtype=global_defs.tReal, device=self.device)

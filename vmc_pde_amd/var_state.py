@@ -33,6 +33,11 @@ class VarState:
         self.device = global_defs.my_device()
         assert jacobian_dtype in (torch.float64, torch.float32)
         self.jacobian_dtype = jacobian_dtype      # float32 = BASELINE config 5 (fp32 Jacobian, fp64 S/F accumulation)
+        # True: the forward pass of flow_eval keeps every network's activations in an HBM workspace and the reverse sweep reads them
+        # back instead of re-evaluating the networks.  Identical results; measured SLOWER (C2 0.78 ms against 0.71 ms, C3 2.40 against
+        # 2.32): the whole activation function costs 0.05 ms of the kernel's 0.71 (tools/diag/flow_where.sh), the kernel is bound by
+        # its ~170 workgroup barriers per sample group, and the global round trip adds latency to that chain.  Off by default.
+        self.keep_activations = False
         self.net, self._theta = self.init_net(network_args, *args, inds_up=inds_up, inds_down=inds_down)
         self.numParameters = self.net.numParameters                       # var_state.py:27
         self.paramShapes = [(int(np.prod(s)), tuple(s)) for _, _, s in self.net.layout]   # var_state.py:25
@@ -85,10 +90,19 @@ class VarState:
             dirs_t = self._dirs(dirs)
             D = dirs_t.shape[0]
             hv = torch.empty((n, D), dtype=global_defs.tReal, device=self.device)
+        act = None
+        if (want_g or want_J) and self.keep_activations:
+            # activation workspace of the reverse sweep (hidden activations + outputs of every MLP, [unit][sample]): the forward
+            # pass fills it, the reverse sweep reads it back instead of re-evaluating the networks
+            if ws.get("act") is None:
+                need = nat.lib().vmcpde_flow_eval_workspace_bytes(self.net.handle, n)
+                ws["act"] = torch.empty(max(need // 8, 1), dtype=global_defs.tReal, device=self.device)
+            act = ws["act"]
         with torch.cuda.device(self.device):
             nat.call("vmcpde_flow_eval", self.net.handle, nat.ptr(self._theta), nat.ptr(x), n, nat.ptr(dirs_t), D,
                      nat.ptr(ws["logp"]), nat.ptr(ws["g"]) if want_g else None, nat.ptr(hv),
-                     nat.ptr(ws["JT"]) if want_J else None, ws["ldj"], 1 if self.jacobian_dtype == torch.float32 else 0, nat.stream())
+                     nat.ptr(ws["JT"]) if want_J else None, ws["ldj"], 1 if self.jacobian_dtype == torch.float32 else 0,
+                     nat.ptr(act), 0 if act is None else act.numel() * 8, nat.stream())
         P = self.numParameters
         return dict(x=x, logp=ws["logp"], g=ws["g"], hv=hv, JT=ws["JT"], ldj=ws["ldj"], n=n,
                     J=ws["JT"][:P, :n].T[None, ...] if want_J else None)
