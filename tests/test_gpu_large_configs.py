@@ -79,6 +79,22 @@ def test_cholesky_side_stream_branch_on_small_matrices(P, monkeypatch):
     assert torch.equal(Ap2[:P, :P].tril(), Ap[:P, :P].tril())       # both schedules do the same arithmetic
 
 
+@pytest.mark.parametrize("P", [300, 1000, 4213])
+def test_cholesky_one_launch_per_panel_schedule(P, monkeypatch):
+    # VMCPDE_CHOL_PANEL=1: strips, next diagonal block and trailing tiles of a panel as counter-chained workgroups of one launch
+    # (chol_panel_kernel; opt-in because it measured slower) -- same arithmetic as the default schedule up to the order in which
+    # the first block column is updated
+    A = _spd_gpu(P, P + 1)
+    Ap0, *_ = _factor(A, P)
+    monkeypatch.setenv("VMCPDE_CHOL_PANEL", "1")
+    Ap1, Pp, ws, need, info = _factor(A, P)
+    assert int(info.item()) == 0                      # (a timed-out wait would set bit 30)
+    L0, L1 = torch.tril(Ap0[:P, :P]), torch.tril(Ap1[:P, :P])
+    assert float((L0 - L1).abs().max() / L0.abs().max()) < 1e-13
+    Lref = torch.linalg.cholesky(A)
+    assert float((L1 - Lref).abs().max() / Lref.abs().max()) < 1e-11
+
+
 def _gram_full(JT, ldj, P, N):
     npk = nat.lib().vmcpde_gram_packed_doubles(P)
     packed = torch.empty(npk, dtype=torch.float64, device=DEV)

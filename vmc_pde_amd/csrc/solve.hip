@@ -442,13 +442,12 @@ constexpr int SP = SK + 2;        // LDS pitch: 4r + 2k dwords mod 64 distinct o
 // workgroup: 2.88 -> 2.67 ms for the whole factorisation at P = 4213), 32 beyond that (each workgroup re-reads the 128 KB B
 // operand, so twice the workgroups is a loss once they no longer run concurrently).
 template <int SR>
-__global__ __launch_bounds__(256, 1) void chol_strip_kernel(double* __restrict__ A, int64_t lda, int P, int k0, int mode,
-                                                            const double* __restrict__ Linv) {
-  extern __shared__ double lds[];          // Bs[128][SP] then As[SR][SP]
+__device__ __forceinline__ void strip_body(double* __restrict__ A, int64_t lda, int P, int k0, int mode, const double* __restrict__ Linv,
+                                           int strip, double* __restrict__ lds /* Bs[128][SP] then As[SR][SP] */) {
   double* Bs = lds;
   double* As = lds + NB * SP;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int row0 = k0 + NB + blockIdx.x * SR;            // first row of this strip (a row below the panel)
+  const int row0 = k0 + NB + strip * SR;                 // first row of this strip (a row below the panel)
   const int c0 = k0 + NB;                                // first row of the B operand in mode 1
   const double* __restrict__ Bsrc = mode ? (A + (int64_t)c0 * lda + k0) : Linv;
   const int64_t ldb = mode ? lda : NB;
@@ -519,19 +518,22 @@ __global__ __launch_bounds__(256, 1) void chol_strip_kernel(double* __restrict__
       }
 }
 
+template <int SR>
+__global__ __launch_bounds__(256, 1) void chol_strip_kernel(double* __restrict__ A, int64_t lda, int P, int k0, int mode,
+                                                            const double* __restrict__ Linv) {
+  extern __shared__ double lds[];
+  strip_body<SR>(A, lda, P, k0, mode, Linv, (int)blockIdx.x, lds);
+}
+
 // Trailing update A22 -= L21 L21^T on the lower-triangle tiles (syrk, K = n): see chol_syrk_diag_kernel.
 __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, int64_t lda, int k0, int n, double* __restrict__ Linv,
                                                        int* __restrict__ info, int phase) {
   chol_diag_body(A, lda, k0, n, Linv, info, phase);
 }
 
-// One 128 x 128 tile (ti, tj >= 1: the first block column belongs to chol_strip_kernel mode 1) of A22 -= L21 L21^T.
-__device__ __forceinline__ void syrk_tile(double* __restrict__ A, int64_t lda, int P, int k0, int n, int tile) {
+// One 128 x 128 tile (ti >= tj, block indices inside the trailing matrix) of A22 -= L21 L21^T.
+__device__ __forceinline__ void syrk_tile_at(double* __restrict__ A, int64_t lda, int P, int k0, int n, int ti, int tj) {
   extern __shared__ double lds[];
-  int ti, tj;
-  tri_decode(tile, ti, tj);
-  ++ti;
-  ++tj;
   const int base = k0 + n;
   const int rowA0 = base + ti * TILE, rowB0 = base + tj * TILE;
   const int rowsA = (P - rowA0 < TILE) ? (P - rowA0) : TILE;
@@ -543,6 +545,84 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int64_t lda, i
     for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
   tile_mainloop_dma<16>(acc, A + k0, lda, rowA0, A + k0, lda, rowB0, ti == tj, 0, n, lds);
   tile_store_global(acc, A + (int64_t)rowA0 * lda + rowB0, lda, rowsA, rowsB, 1);
+}
+
+// (ti, tj >= 1: in the multi-launch schedule the first block column belongs to chol_strip_kernel mode 1)
+__device__ __forceinline__ void syrk_tile(double* __restrict__ A, int64_t lda, int P, int k0, int n, int tile) {
+  int ti, tj;
+  tri_decode(tile, ti, tj);
+  syrk_tile_at(A, lda, P, k0, n, ti + 1, tj + 1);
+}
+
+// ---- one launch per panel ---------------------------------------------------------------------------------------------------
+// The chain of a panel is  panel solve (strips, mode 0)  ->  update of the next diagonal tile (mode 1 of the strips of the first
+// block row below)  ->  factorisation of that tile  ||  rest of the trailing update.  As three launches it costs 9.5 + 9.5 + 57 us
+// per panel, a good part of it launch and drain time; here the pieces are workgroups of ONE launch chained by counters in
+// global memory (opt-in, VMCPDE_CHOL_PANEL=1: measured slower than the three launches, see vmcpde_cholesky):
+//   blocks [0, S)        strips: mode 0, then count[block row] += 1; the strips of block row 0 wait for count[0] == spb (all of
+//                        L21's first block row is there), run mode 1 on their rows of tile (0,0), then count[nrem] += 1
+//   block  S             waits for count[nrem] == spb, then factors the next diagonal block
+//   blocks (S, S+1+T)    trailing tiles (ti, tj) != (0,0): wait for count[ti] == count[tj] == spb, then the syrk tile
+// Workgroups are dispatched in block order and only ever wait for strips, which come first and fit the chip together
+// (S + 1 <= 256 workgroups at one per CU, checked by the host), so every wait ends; waits are bounded in time all the same
+// (a timeout flags `info` and lets the grid drain).  Release / acquire at agent scope: the L2 of each XCD is written back /
+// invalidated by the fences, as for any cross-workgroup hand-over on this chip.
+constexpr long long SPIN_TIMEOUT_TICKS = 20LL * 1000 * 1000;     // wall_clock64 runs at 100 MHz: 0.2 s
+
+__device__ __forceinline__ void signal_count(unsigned int* p) {
+  __syncthreads();                               // every wave's stores are issued and complete (vmcnt(0) inside)
+  if (threadIdx.x == 0) {
+    __threadfence();                             // release
+    __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__device__ __forceinline__ void wait_count(const unsigned int* p, unsigned int target, int* __restrict__ info) {
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > SPIN_TIMEOUT_TICKS) {
+        atomicOr(info, 0x40000000);              // the host's pinned-pivot / residual guard turns this into an error
+        break;
+      }
+    }
+    __threadfence();                             // acquire: invalidates this CU's L1 and the stale lines of its XCD's L2 -- cache
+  }                                              // operations, so one wave does it for the workgroup before the others load
+  __syncthreads();
+}
+
+template <int SR>
+__global__ __launch_bounds__(256, 1) void chol_panel_kernel(double* __restrict__ A, int64_t lda, int P, int k0,
+                                                            const double* __restrict__ Linv_k, double* __restrict__ Linv_next,
+                                                            int* __restrict__ info, unsigned int* __restrict__ count, int nrem,
+                                                            int phase) {
+  extern __shared__ double lds[];
+  constexpr int SPB = NB / SR;                   // strips per block row
+  const int S = nrem * SPB;
+  const int b = (int)blockIdx.x;
+  if (b < S) {
+    const int br = b / SPB;
+    strip_body<SR>(A, lda, P, k0, 0, Linv_k, b, lds);
+    signal_count(count + br);
+    if (br == 0) {
+      wait_count(count, SPB, info);
+      strip_body<SR>(A, lda, P, k0, 1, Linv_k, b, lds);        // its rows of the next diagonal tile (B = L21's first block row)
+      signal_count(count + nrem);
+    }
+    return;
+  }
+  if (b == S) {
+    wait_count(count + nrem, SPB, info);
+    const int k1 = k0 + NB;
+    chol_diag_body(A, lda, k1, (P - k1 < NB) ? (P - k1) : NB, Linv_next, info, phase);
+    return;
+  }
+  int ti, tj;
+  tri_decode(b - S, ti, tj);                     // b - S >= 1: every lower tile except (0,0)
+  wait_count(count + ti, SPB, info);
+  if (tj != ti) wait_count(count + tj, SPB, info);
+  syrk_tile_at(A, lda, P, k0, NB, ti, tj);
 }
 
 // Lookahead, small trailing matrices: one launch holds the trailing update of panel k AND, as workgroup 0, the
@@ -708,10 +788,13 @@ __global__ void pinv_coeffs_kernel(const double* __restrict__ ev, const double* 
 
 }  // namespace
 
+// workspace: nb inverse diagonal blocks (128 x 128 doubles each), then the per-panel counters of the one-launch-per-panel schedule
+static int64_t chol_counter_bytes(int nb) { return (((int64_t)nb * (nb + 2) * (int64_t)sizeof(unsigned int)) + 255) / 256 * 256; }
+
 extern "C" int64_t vmcpde_chol_workspace_bytes(int32_t P) {
   if (P <= 0) return 0;
   const int nb = (P + NB - 1) / NB;
-  return (int64_t)nb * NB * NB * (int64_t)sizeof(double);
+  return (int64_t)nb * NB * NB * (int64_t)sizeof(double) + chol_counter_bytes(nb);
 }
 
 extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info, void* workspace, int64_t workspace_bytes,
@@ -736,6 +819,8 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
       VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_strip_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds));
       VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_syrk_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
       VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_DMA_LDS_BYTES));
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_panel_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_panel_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
       ctx->attr_chol = true;
     }
     if (ctx->side == nullptr) {
@@ -757,6 +842,13 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
   const int diag_phase = 5;
 #endif
   const int fused_max = env_int("VMCPDE_CHOL_FUSED_MAX", FUSED_MAX_TILES);
+  // 1: one launch per panel (chol_panel_kernel).  Off by default -- NEGATIVE RESULT: 2.88 ms against 2.46 ms at P = 4213, 0.324
+  // against 0.314 ms at P = 640.  Each hand-over between workgroups costs a release (L2 write-back of the XCD) + a polled counter
+  // + an acquire (L1 / L2 invalidate) = ~3 us, as much as the launch boundary it replaces, and the invalidates evict the operand
+  // panels the other workgroups of that XCD were re-using.
+  const int panel_mode = env_int("VMCPDE_CHOL_PANEL", 0);
+  unsigned int* counters = reinterpret_cast<unsigned int*>(static_cast<char*>(workspace) + (int64_t)nb * NB * NB * (int64_t)sizeof(double));
+  if (panel_mode) VMC_CHECK_HIP(hipMemsetAsync(counters, 0, (size_t)chol_counter_bytes(nb), st));
   hipStream_t side = ctx->side;
   hipEvent_t ev_fork = ctx->ev_fork, ev_join = ctx->ev_join;
   {
@@ -769,6 +861,24 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
     const int rem = P - (k0 + n);
     if (rem <= 0) break;
     const int nrem = (rem + TILE - 1) / TILE;
+    double* Linv_nextp = Linv + (int64_t)(k + 1) * NB * NB;
+    const int64_t tiles_all = tri_count(nrem) - 1;                 // every lower tile of the trailing matrix but the next diagonal one
+    if (panel_mode && tiles_all <= fused_max) {
+      // one launch per panel (chol_panel_kernel): the strips and the next diagonal block must be resident together
+      const bool sr16 = (8 * nrem + 1 <= 232);
+      const int S = sr16 ? 8 * nrem : 4 * nrem;
+      if (S + 1 <= 248) {
+        unsigned int* cnt = counters + (int64_t)k * (nb + 2);
+        const unsigned grid = (unsigned)(S + 1 + tiles_all);
+        if (sr16)
+          hipLaunchKernelGGL(chol_panel_kernel<16>, dim3(grid), dim3(256), diag_lds, st, A, lda, P, k0, Linv + (int64_t)k * NB * NB, Linv_nextp,
+                             info, cnt, nrem, diag_phase);
+        else
+          hipLaunchKernelGGL(chol_panel_kernel<32>, dim3(grid), dim3(256), diag_lds, st, A, lda, P, k0, Linv + (int64_t)k * NB * NB, Linv_nextp,
+                             info, cnt, nrem, diag_phase);
+        continue;
+      }
+    }
     // n == NB here (a panel with rows below it is always full); row strips of 32 over the zero-padded row range
     if (8 * nrem <= 256) {
       hipLaunchKernelGGL(chol_strip_kernel<16>, dim3(8 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 0, Linv + (int64_t)k * NB * NB);
