@@ -735,6 +735,69 @@ __global__ __launch_bounds__(256) void solve_bwd_step(const double* __restrict__
   if (b == k - 1) diag_apply(Linv_all + (int64_t)b * NB * NB, r + b0, NB, 1, sh, part);
 }
 
+// The whole back substitution L^T u = y as ONE launch: workgroup b owns block b of the solution, applies the updates
+// r_b -= L[k][b]^T u_k for k = nb-1 .. b+1 as the u_k are published (a counter per block, release / acquire at agent scope),
+// then u_b = Linv_b^T r_b and publishes it.  The 128 x 128 tile of every update and the inverse diagonal block are fetched
+// into registers BEFORE the wait, so one link of the chain is: see the flag, read 1 KB of u_k, 64 FMAs per thread, a reduction
+// through LDS, publish -- against a launch boundary (~9 us) per block in the one-launch-per-block version.
+// All nb workgroups are resident together (nb <= 256 checked by the host), block nb-1 waits for nothing, so every wait ends;
+// waits are bounded in time anyway and poison the result with NaN when they give up.
+__global__ __launch_bounds__(256, 1) void solve_bwd_persistent(const double* __restrict__ L, int64_t lda, int P, int nb,
+                                                               const double* __restrict__ y, double* __restrict__ u,
+                                                               const double* __restrict__ Linv_all, unsigned int* __restrict__ flags) {
+  __shared__ double uk[NB], rb[NB], part[2 * NB];
+  __shared__ int poisoned;
+  const int t = threadIdx.x;
+  const int b = nb - 1 - (int)blockIdx.x;       // the head of the chain is dispatched first
+  const int b0 = b * NB;
+  const int nbk = (P - b0 < NB) ? (P - b0) : NB;
+  const int j = t & (NB - 1), half = t >> 7;    // column j of a tile, two halves of its row range
+  if (t == 0) poisoned = 0;
+  if (t < NB) rb[t] = (t < nbk) ? y[b0 + t] : 0.0;
+  double w[NB / 2];                              // this thread's half column of Linv_b (rows m = half, half + 2, ...)
+  const double* __restrict__ Lb = Linv_all + (int64_t)b * NB * NB;
+#pragma unroll
+  for (int q = 0; q < NB / 2; ++q) w[q] = Lb[(half + 2 * q) * NB + j];
+  for (int k = nb - 1; k > b; --k) {
+    const int k0 = k * NB;
+    const int nk = (P - k0 < NB) ? (P - k0) : NB;
+    double v[NB / 2];
+#pragma unroll
+    for (int q = 0; q < NB / 2; ++q) v[q] = L[(int64_t)(k0 + half + 2 * q) * lda + b0 + j];     // rows >= P: zero padding / masked by uk
+    if (t == 0) {
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > SPIN_TIMEOUT_TICKS) { poisoned = 1; break; }
+      }
+      __threadfence();                           // acquire (cache operations: one wave does it for the workgroup)
+    }
+    __syncthreads();
+    if (t < NB) uk[t] = (t < nk) ? u[k0 + t] : 0.0;
+    __syncthreads();
+    double s0 = 0.0;
+#pragma unroll
+    for (int q = 0; q < NB / 2; ++q) s0 = fma(v[q], uk[half + 2 * q], s0);
+    part[half * NB + j] = s0;
+    __syncthreads();
+    if (t < NB) rb[t] -= part[t] + part[NB + t];
+    __syncthreads();
+  }
+  // u_b = Linv_b^T r_b
+  double s1 = 0.0;
+#pragma unroll
+  for (int q = 0; q < NB / 2; ++q) s1 = fma(w[q], rb[half + 2 * q], s1);
+  __syncthreads();
+  part[half * NB + j] = s1;
+  __syncthreads();
+  if (t < nbk) u[b0 + t] = poisoned ? __builtin_nan("") : (part[t] + part[NB + t]);
+  __syncthreads();
+  if (t == 0) {
+    __threadfence();                             // release
+    __hip_atomic_fetch_add(flags + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 __global__ __launch_bounds__(256) void solve_diag_only(double* __restrict__ r, int P, int k, int trans, const double* __restrict__ Linv_all) {
   __shared__ double sh[NB];
   __shared__ double part[2 * NB];
@@ -937,8 +1000,16 @@ extern "C" int vmcpde_chol_backsolve(const double* L, int64_t lda, int32_t P, co
   hipStream_t st = (hipStream_t)stream;
   const double* Linv = static_cast<const double*>(workspace);
   const int nb = (P + NB - 1) / NB;
-  if (u != y) VMC_CHECK_HIP(hipMemcpyAsync(u, y, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, st));
   // L^T u = y
+  if (env_int("VMCPDE_BACKSOLVE_PERSISTENT", 1) && nb <= 256 && u != y) {
+    // one launch, workgroups chained by per-block flags (the counter area of the workspace is free once the factor exists)
+    unsigned int* flags = reinterpret_cast<unsigned int*>(static_cast<char*>(workspace) + (int64_t)nb * NB * NB * (int64_t)sizeof(double));
+    VMC_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)nb * sizeof(unsigned int), st));
+    hipLaunchKernelGGL(solve_bwd_persistent, dim3(nb), dim3(256), 0, st, L, lda, P, nb, y, u, Linv, flags);
+    VMC_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+  if (u != y) VMC_CHECK_HIP(hipMemcpyAsync(u, y, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(solve_diag_only, dim3(1), dim3(256), 0, st, u, P, nb - 1, 1, Linv);
   for (int k = nb - 1; k >= 1; --k) hipLaunchKernelGGL(solve_bwd_step, dim3(k), dim3(256), 0, st, L, lda, P, k, u, Linv);
   VMC_CHECK_HIP(hipGetLastError());
