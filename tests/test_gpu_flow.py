@@ -84,7 +84,9 @@ def test_flow_sample_and_eval_parity(cfg):
 @pytest.mark.parametrize("cfg", [CONFIGS[3], CONFIGS[8], CONFIGS[11]])
 def test_activation_workspace_variant_gives_identical_results(cfg):
     """vmcpde_flow_eval with a workspace (the forward pass keeps the activations, the reverse sweep reads them back) against the
-    default (re-evaluation): same arithmetic on the same values, so logp, grad_x and the Jacobian must agree bit for bit."""
+    default (re-evaluation).  The forward results (logp, directional second derivatives) are the same code: bit for bit.  The
+    reverse sweep of the default walks the state backwards through the exact inverse of every coupling step (x = y e^{-s}), which
+    reproduces the forward activations only to rounding, so grad_x and the Jacobian agree to ~1e-15, not bitwise."""
     spec, th, z = _setup(cfg, 150)
     out = {}
     for keep in (False, True):
@@ -93,8 +95,9 @@ def test_activation_workspace_variant_gives_identical_results(cfg):
         x, _ = vs.flow_sample(z)
         r = vs.evaluate(x, dirs=np.eye(spec.dim)[:2])
         out[keep] = (r["logp"].clone(), r["g"].clone(), r["J"].clone(), r["hv"].clone())
-    for a, b in zip(out[False], out[True]):
-        assert torch.equal(a, b)
+    assert torch.equal(out[False][0], out[True][0]) and torch.equal(out[False][3], out[True][3])
+    assert rel_err(out[True][1], out[False][1]) < 1e-13
+    assert float((out[True][2] - out[False][2]).abs().max()) < 1e-13 * float(out[False][2].abs().max())
 
 
 def test_empty_and_single_sample():
