@@ -16,7 +16,8 @@ res = {"source": "tools/profile_round.sh: rocprofv3 --kernel-trace --stats (benc
 stats = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
-HOT = ("gram_dma_kernel", "gram_f32_kernel", "gram_kernel", "row_moments_kernel", "flow_eval_kernel", "chol_diag_kernel", "chol_syrk_diag_kernel", "reduce_splits_kernel")
+HOT = ("gram_dma_kernel", "gram_f32_kernel", "gram_kernel", "row_moments_kernel", "flow_eval_kernel", "chol_diag_kernel", "chol_syrk_diag_kernel",
+       "reduce_splits_kernel", "solve_bwd_persistent", "finalize_S_kernel")
 acc = defaultdict(lambda: defaultdict(list))
 dur = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
@@ -39,5 +40,7 @@ for k in acc:
         cycles = g["GRBM_GUI_ACTIVE"]["mean"] / 8.0
         g["mfma_busy_frac_of_cycles"] = g["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (cycles * 256 * 4)
         g["clock_ghz"] = cycles / (g["GRBM_GUI_ACTIVE"]["mean_ms"] * 1e6)
+import datetime
+res["date"] = datetime.date.today().isoformat()
 json.dump(res, open(os.path.join(out, f"{tag}_gram_pmc.json"), "w"), indent=1)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if not isinstance(vv, dict)} for k, v in res.items() if isinstance(v, dict)}, indent=1))
