@@ -16,7 +16,10 @@
 // (144 B pitch: the 16 rows x 2 k-columns a ds_read_b64 wave-instruction touches fall on 64 distinct banks).
 // Split-K over the sample axis gives >= 8 work units per CU-slot; partial tiles go to a workspace and are summed by
 // a deterministic second kernel (no atomics: bitwise reproducible, which the replicated multi-GPU solve relies on).
+#include <algorithm>
 #include <cstdlib>
+#include <utility>
+#include <vector>
 
 #include "mfma_tile.hpp"
 
@@ -39,7 +42,7 @@ struct GramPlan {
   int64_t chunk;   // samples per split (multiple of BK)
 };
 
-constexpr int DEFAULT_ORDER = 1;
+constexpr int DEFAULT_ORDER = 2;
 int gram_order() { return env_int("VMCPDE_GRAM_ORDER", DEFAULT_ORDER); }
 
 GramPlan make_plan(int P, int64_t N, int slots /* resident workgroups: 256 CUs x 2 (register-staged) or x 3 (DMA) */) {
@@ -59,13 +62,14 @@ GramPlan make_plan(int P, int64_t N, int slots /* resident workgroups: 256 CUs x
   int64_t ns = want < maxsplit ? want : maxsplit;
   if (ns < 1) ns = 1;
   if (ns > 1) {
-    const bool per_xcd = gram_order() == 1;
-    const int64_t units1 = per_xcd ? (g.ntiles + 7) / 8 : g.ntiles;      // units per split in one scheduling domain
-    const int64_t dom_slots = per_xcd ? slots / 8 : slots;
+    const int order = gram_order();
+    const int64_t dom_slots = order >= 1 ? slots / 8 : slots;
     double best = 1e30;
     int64_t pick = ns;
     for (int64_t c = (ns > 3 ? ns - 2 : 1); c <= ns + 10 && c <= maxsplit; ++c) {
-      const int64_t rounds = (units1 * c + dom_slots - 1) / dom_slots;
+      // units of the busiest scheduling domain: order 1 -- ceil(ntiles/8) tiles of every split; order 2 -- balanced to one unit
+      const int64_t units = order == 1 ? (int64_t)((g.ntiles + 7) / 8) * c : (order == 2 ? (g.ntiles * c + 7) / 8 : g.ntiles * c);
+      const int64_t rounds = (units + dom_slots - 1) / dom_slots;
       const double cost = (double)rounds / (double)c;                      // time ~ rounds x (samples per unit ~ 1/c)
       if (cost < best - 1e-9) { best = cost; pick = c; }
     }
@@ -84,7 +88,31 @@ GramPlan make_plan(int P, int64_t N, int slots /* resident workgroups: 256 CUs x
 // sweep the SAME sample chunk at the same time -- slot -> (split, local tile), XCD x owns a contiguous run of that split's
 // tiles -- which keeps the chip-wide working set at one or two chunks of J (Infinity-Cache sized) and neighbouring tiles
 // (shared operand panels) on one L2.  order 0: one sample chunk per XCD (eight chunks in flight).
-__device__ __forceinline__ bool gram_unit(int ntiles, int nsplit, int total_units, int units_per_xcd, int order, int& split, int& tile) {
+// order 2: the tiles are laid along a Z-order (Morton) curve through the lower triangle (perm: position -> tile index) and every
+// XCD owns a contiguous piece of the curve in every sample split, so the 64 workgroups resident on an XCD work on a compact
+// 2-D patch of tiles and share ~16 operand panels per K-step in that XCD's L2 instead of ~26 for two or three whole tile rows.
+// The pieces are balanced: with ntiles = 8 q + r every XCD gets q tiles per split and the r left-over tiles rotate over the
+// XCDs from split to split (XCDs (s r + i) mod 8, i < r), so the per-XCD totals differ by at most one unit (order 1 gives
+// seven XCDs ceil(ntiles/8) tiles and the last one the rest: 71 against 64 at C2, i.e. 1.2 % more rounds than necessary).
+__device__ __forceinline__ int xcd_extra(int xcd, int split, int r) { return (((xcd - split * r) % 8) + 8) % 8 < r ? 1 : 0; }
+
+__device__ __forceinline__ bool gram_unit(int ntiles, int nsplit, int total_units, int units_per_xcd, int order, const int* __restrict__ perm,
+                                          int& split, int& tile) {
+  if (order == 2) {
+    const int xcd = (int)(blockIdx.x & 7), q = ntiles >> 3, r = ntiles & 7;
+    int rem = (int)(blockIdx.x >> 3), s = 0;
+    for (; s < nsplit; ++s) {
+      const int cnt = q + xcd_extra(xcd, s, r);
+      if (rem < cnt) break;
+      rem -= cnt;
+    }
+    if (s == nsplit) return false;
+    int start = q * xcd;
+    for (int x = 0; x < xcd; ++x) start += xcd_extra(x, s, r);
+    split = s;
+    tile = perm[start + rem];
+    return true;
+  }
   if (order == 1) {
     const int slot = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
     split = slot / units_per_xcd;                      // units_per_xcd = tiles per XCD per split here
@@ -103,10 +131,10 @@ template <bool CENTER, bool SCALE, typename TIn>
 __global__ __launch_bounds__(256, 2) void gram_kernel(const TIn* __restrict__ JT, int64_t ldj, int P, int64_t N,
                                                       const double* __restrict__ c, const double* __restrict__ scale,
                                                       int ntiles, int nsplit, int64_t chunk, int total_units,
-                                                      int units_per_xcd, int order, double* __restrict__ out) {
+                                                      int units_per_xcd, int order, const int* __restrict__ perm, double* __restrict__ out) {
   extern __shared__ double lds[];
   int split, tile;
-  if (!gram_unit(ntiles, nsplit, total_units, units_per_xcd, order, split, tile)) return;
+  if (!gram_unit(ntiles, nsplit, total_units, units_per_xcd, order, perm, split, tile)) return;
   int ti, tj;
   tri_decode(tile, ti, tj);
   const int64_t k0 = (int64_t)split * chunk;
@@ -126,10 +154,10 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const TIn* __restrict__ JT
 // the steady-state variant (fp64, uncentred, unweighted): DMA-staged main loop
 __global__ __launch_bounds__(256, GRAM_BKD == 8 ? 3 : 2) void gram_dma_kernel(const double* __restrict__ JT, int64_t ldj, int64_t N, int ntiles, int nsplit,
                                                           int64_t chunk, int total_units, int units_per_xcd, int order,
-                                                          double* __restrict__ out) {
+                                                          const int* __restrict__ perm, double* __restrict__ out) {
   extern __shared__ double lds[];
   int split, tile;
-  if (!gram_unit(ntiles, nsplit, total_units, units_per_xcd, order, split, tile)) return;
+  if (!gram_unit(ntiles, nsplit, total_units, units_per_xcd, order, perm, split, tile)) return;
   int ti, tj;
   tri_decode(tile, ti, tj);
   const int64_t k0 = (int64_t)split * chunk;
@@ -148,10 +176,10 @@ __global__ __launch_bounds__(256, GRAM_BKD == 8 ? 3 : 2) void gram_dma_kernel(co
 // the DMA staging, the swizzled LDS image and the fragment reads those of the fp64 kernel; N2, chunk2 and ldj2 are in pairs.
 __global__ __launch_bounds__(256, 2) void gram_f32_kernel(const double* __restrict__ JT2, int64_t ldj2, int64_t N2, int ntiles, int nsplit,
                                                           int64_t chunk2, int total_units, int units_per_xcd, int order,
-                                                          double* __restrict__ out) {
+                                                          const int* __restrict__ perm, double* __restrict__ out) {
   extern __shared__ double lds[];
   int split, tile;
-  if (!gram_unit(ntiles, nsplit, total_units, units_per_xcd, order, split, tile)) return;
+  if (!gram_unit(ntiles, nsplit, total_units, units_per_xcd, order, perm, split, tile)) return;
   int ti, tj;
   tri_decode(tile, ti, tj);
   const int64_t k0 = (int64_t)split * chunk2;
@@ -383,14 +411,47 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
   hipStream_t st = (hipStream_t)stream;
   const int order = gram_order();   // tuning knob
   const int total = g.ntiles * g.nsplit;
-  const int per_xcd = (order == 1) ? (g.ntiles + 7) / 8 : (total + 7) / 8;
-  const int grid = (order == 1) ? per_xcd * 8 * g.nsplit : per_xcd * 8;
+  int per_xcd = (order == 1) ? (g.ntiles + 7) / 8 : (total + 7) / 8;
+  int grid = (order == 1) ? per_xcd * 8 * g.nsplit : per_xcd * 8;
+  if (order == 2) {        // slots of the busiest XCD (gram_unit's balanced deal)
+    const int q = g.ntiles / 8, r = g.ntiles % 8;
+    int most = 0;
+    for (int x = 0; x < 8; ++x) {
+      int cnt = 0;
+      for (int sp = 0; sp < g.nsplit; ++sp) cnt += q + (((((x - sp * r) % 8) + 8) % 8 < r) ? 1 : 0);
+      most = cnt > most ? cnt : most;
+    }
+    per_xcd = most;
+    grid = most * 8;
+  }
   // tuning knob: extra dynamic LDS forces one workgroup per CU (to measure what the co-resident partner is worth)
   const size_t lds_pad = (size_t)env_int("VMCPDE_GRAM_LDSPAD", 0);
   const size_t lds_bytes = TILE_LDS_BYTES + lds_pad;
   DeviceCtx* ctx = device_ctx();
   if (!ctx) return -2;
   DeviceCtxLock lock;      // first-use attribute changes; held over the (asynchronous) launches below, which is harmless
+  const int* perm = nullptr;
+  if (order == 2) {
+    if (ctx->gram_perm_nb != g.nb) {       // (re)build the Z-order tile list for this matrix size: once per size and GPU
+      std::vector<std::pair<uint64_t, int>> keyed;
+      keyed.reserve(g.ntiles);
+      auto spread = [](uint32_t v) { uint64_t x = v; x = (x | (x << 16)) & 0x0000FFFF0000FFFFull; x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+                                     x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full; x = (x | (x << 2)) & 0x3333333333333333ull;
+                                     x = (x | (x << 1)) & 0x5555555555555555ull; return x; };
+      for (int ti = 0; ti < g.nb; ++ti)
+        for (int tj = 0; tj <= ti; ++tj) keyed.push_back({(spread((uint32_t)ti) << 1) | spread((uint32_t)tj), ti * (ti + 1) / 2 + tj});
+      std::sort(keyed.begin(), keyed.end());
+      std::vector<int> host(g.ntiles);
+      for (int i = 0; i < g.ntiles; ++i) host[i] = keyed[i].second;
+      if (ctx->gram_perm) (void)hipFree(ctx->gram_perm);
+      ctx->gram_perm = nullptr;
+      ctx->gram_perm_nb = 0;
+      VMC_CHECK_HIP(hipMalloc(&ctx->gram_perm, (size_t)g.ntiles * sizeof(int)));
+      VMC_CHECK_HIP(hipMemcpy(ctx->gram_perm, host.data(), (size_t)g.ntiles * sizeof(int), hipMemcpyHostToDevice));
+      ctx->gram_perm_nb = g.nb;
+    }
+    perm = ctx->gram_perm;
+  }
   if (!ctx->attr_gram || lds_pad) {
 #define VMC_ATTR(CEN, SCA, T) VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<CEN, SCA, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes))
     VMC_ATTR(false, false, double); VMC_ATTR(true, false, double); VMC_ATTR(false, true, double); VMC_ATTR(true, true, double);
@@ -400,7 +461,7 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
   }
 #define VMC_LAUNCH_GRAM(CEN, SCA, T)                                                                                              \
   hipLaunchKernelGGL((gram_kernel<CEN, SCA, T>), dim3(grid), dim3(256), lds_bytes, st, static_cast<const T*>(JT), ldj, P, n_samples, c, w, \
-                     g.ntiles, g.nsplit, g.chunk, total, per_xcd, order, out)
+                     g.ntiles, g.nsplit, g.chunk, total, per_xcd, order, perm, out)
 #define VMC_LAUNCH_GRAM_T(T)                          \
   do {                                                \
     if (c && w) VMC_LAUNCH_GRAM(true, true, T);       \
@@ -414,7 +475,7 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
       ctx->attr_gram_f32 = true;
     }
     hipLaunchKernelGGL(gram_f32_kernel, dim3(grid), dim3(256), TILE_DMA_LDS_BYTES, st, static_cast<const double*>(JT), ldj / 2,
-                       (n_samples + 1) / 2, g.ntiles, g.nsplit, g.chunk, total, per_xcd, order, out);
+                       (n_samples + 1) / 2, g.ntiles, g.nsplit, g.chunk, total, per_xcd, order, perm, out);
   } else if (dma) {
     const size_t dma_lds = 4 * DmaGeom<GRAM_BKD>::DT * sizeof(double) + lds_pad;
     if ((!ctx->attr_gram_dma || lds_pad) && dma_lds > 64 * 1024) {
@@ -422,7 +483,7 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
       ctx->attr_gram_dma = true;
     }
     hipLaunchKernelGGL(gram_dma_kernel, dim3(grid), dim3(256), dma_lds, st, static_cast<const double*>(JT), ldj, n_samples, g.ntiles,
-                       g.nsplit, g.chunk, total, per_xcd, order, out);
+                       g.nsplit, g.chunk, total, per_xcd, order, perm, out);
   } else if (jt_f32) VMC_LAUNCH_GRAM_T(float);
   else VMC_LAUNCH_GRAM_T(double);
 #undef VMC_LAUNCH_GRAM_T
