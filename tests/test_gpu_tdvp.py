@@ -218,15 +218,66 @@ def test_heun_step_parity_and_value_semantics():
     assert "entropy" in info
 
 
-def test_adaptive_heun_runs_and_uses_SExp():
+def test_adaptive_heun_step_parity():
+    """One AdaptiveHeun step (stepper.py:45-91: five right-hand sides per attempt, error in the SExp norm of the LAST evaluation,
+    tdvp.py:47) of the product against the oracle's restatement, with the stage draws injected.  tol is chosen so that the first
+    attempt is rejected and the second accepted: both branches of the step-size control run."""
     import vmc_pde_amd as V
-    dim, depth, hidden, latent, coupling, eq, N = 2, 2, (2,), "Gauss", "no_add", "diffusion", 512
-    spec, th, *_ = _problem(dim, depth, hidden, latent, coupling, eq, N)
-    vs = make_varstate(spec, th)
-    st = V.AdaptiveHeun(timeStep=1e-3, tol=1e-2, maxStep=1e-2)
-    y, dt, info = st.step(0, V.TDVP(solver="eigh"), th.cuda(), evolutionEq=V.EvolutionEquation(dim=2, name="diffusion"), psi=vs,
-                          nSamplesTDVP=N, nSamplesObs=N, normFunction=lambda v, S: v @ S @ v, timings=V.util.Timings())
-    assert y.shape == th.shape and dt > 0 and torch.isfinite(y).all()
+    from vmc_pde_amd import _native as nat
+    dim, depth, hidden, latent, coupling, eq, N = 2, 4, (1,), "Gauss", "no_add", "diffusion", 1024      # the net of the Heun test
+    spec, th, nrm, chi2, eo, ep = _problem(dim, depth, hidden, latent, coupling, eq, N)
+    g = torch.Generator().manual_seed(5)
+    normals = [torch.randn(N, dim, generator=g, dtype=torch.float64) for _ in range(10)]     # two attempts x five stages
+
+    vo, to = O.VarStateOracle(spec, th), O.TDVPOracle()
+    calls_o = []
+
+    def f_o(y, t, k):
+        z = O.latent_from_normals(spec, y, normals[len(calls_o)], None)
+        calls_o.append(k)
+        u, aux = to.rhs(y, t, vo, eo, z)
+        return u, aux
+
+    dt0, maxStep = 2e-3, 1.0
+    # a first pass with a huge tolerance measures the error of the first attempt; the real tolerance sits a factor 3 below it
+
+    class Rec:
+        pass
+    rec = Rec()
+
+    def norm_rec(v, S):
+        rec.err = O.norm_fun(v, S)
+        return rec.err
+    O.adaptive_heun_step(f_o, th.clone(), 0.0, dt0, 1e30, maxStep, norm_rec, lambda: to.SExp)
+    tol = float(rec.err) / 3.0
+    calls_o.clear()
+    y_o, real_o, next_o, _ = O.adaptive_heun_step(f_o, th.clone(), 0.0, dt0, tol, maxStep, O.norm_fun, lambda: to.SExp)
+    assert len(calls_o) == 10 and calls_o[:5] == [0, 1, 2, 3, 4]                      # rejected once, accepted on the second attempt
+
+    class StageSampler:
+        key = 1
+
+        def __init__(self):
+            self.k = 0
+
+        def __call__(self, numSamples, dist_params, multipleOf=1):
+            z = torch.empty((N, dim), dtype=torch.float64, device="cuda")
+            nrm_d = normals[self.k].cuda()
+            nat.call("vmcpde_latent_from_normals", dist_params["_model"].handle, nat.ptr(dist_params["_theta"]),
+                     nat.ptr(nrm_d), None, N, nat.ptr(z), nat.stream())
+            self.k += 1
+            return z[None]
+
+    smp = StageSampler()
+    vs = make_varstate(spec, th, sampler=smp)
+    st = V.AdaptiveHeun(timeStep=dt0, tol=tol, maxStep=maxStep)
+    tp = V.TDVP(solver="eigh")
+    y_p, real_p, info = st.step(0.0, tp, th.cuda(), evolutionEq=ep, psi=vs, nSamplesTDVP=N, nSamplesObs=N,
+                                normFunction=lambda v, S: v @ S @ v, timings=None)
+    assert smp.k == 10
+    assert real_p == pytest.approx(real_o, rel=1e-6) and st.dt == pytest.approx(next_o, rel=1e-5)   # dt of the retry ~ err^(1/3) of the first attempt
+    assert rel_err(y_p, y_o) < 1e-6          # dt * (update differences along near-null modes of S, see the rhs test)
+    assert rel_err(tp.SExp, to.SExp) < 1e-7 and "entropy" in info        # (evaluated at the last stage's state, itself equal to ~1e-8)
 
 
 def test_timings_sections_match_reference_names():

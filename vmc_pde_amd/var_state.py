@@ -25,6 +25,25 @@ def _round_up(v, m):
     return (v + m - 1) // m * m
 
 
+class _LatentParams(dict):
+    """The `dist_params` dict of var_state.py:77 ({"S", "mu", "dist_params"}).  The covariance S = L L^T (util.py:21-26) is only
+    built when a sampler actually reads it: the native sampler rebuilds the factor on the device from the flat parameter vector
+    (csrc/flow.hip::latent_prepare_kernel) and never does -- ten tiny launches per TDVP call otherwise."""
+
+    def __init__(self, p, dim, model, theta):
+        super().__init__(mu=p["mu"], dist_params=p["dist_params"], _model=model, _theta=theta)
+        self._p, self._dim = p, dim
+
+    def __missing__(self, key):
+        if key == "S":
+            self["S"] = util.build_cov_matrix(self._p["L"], self._p["L_diag"], self._dim)
+            return self["S"]
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return key == "S" or super().__contains__(key)
+
+
 class VarState:
 
     def __init__(self, sampler, dim, *args, network_args={}, inds_up=None, inds_down=None, jacobian_dtype=torch.float64):
@@ -163,8 +182,7 @@ class VarState:
     def sample(self, numSamples):
         """var_state.py:76-79: latent samples -> inverse flow -> (x (1,n,d), logp (1,n))."""
         p = self.params["params"]
-        dist_params = {"S": util.build_cov_matrix(p["L"], p["L_diag"], self.dim), "mu": p["mu"], "dist_params": p["dist_params"],
-                       "_model": self.net, "_theta": self._theta}
+        dist_params = _LatentParams(p, self.dim, self.net, self._theta)
         z = self.sampler(numSamples, dist_params)
         return self.flow_sample(z)
 
