@@ -28,7 +28,7 @@ def test_argument_validation_needs_no_gpu(lib_built):
     assert L.vmcpde_gram_packed_doubles(128) == 128 * 128
     ws = L.vmcpde_gram_workspace_bytes(4213, 65536)
     assert ws % ((33 * 34 // 2) * 128 * 128 * 8) == 0 and 8 <= ws // ((33 * 34 // 2) * 128 * 128 * 8) <= 12   # split-K factor
-    assert L.vmcpde_chol_workspace_bytes(129) == 2 * 128 * 128 * 8
+    assert L.vmcpde_chol_workspace_bytes(129) == 2 * 128 * 128 * 8 + 256      # two inverse blocks + the counters of the chained launches
     assert L.vmcpde_num_parameters(None) == -1
     rc = L.vmcpde_gram(None, 0, 0, 0, 0, None, None, None, None, 0, None)
     assert rc == -1 and b"null" in L.vmcpde_last_error()
