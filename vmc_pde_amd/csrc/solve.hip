@@ -85,25 +85,29 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double& d, double& inv_d) {
 // fenced in groups of 8 so that at most 16 SGPRs are in flight.
 // L goes to the lower triangle; X = L^-1 is kept transposed in the dead strict upper part: X[r][c] <-> a[c][r+1].
 // scr: 64-double dump line for the masked-out stores.
-__device__ __forceinline__ int factor_inverse_32(double* a, int j0, double* scr, bool do_inverse) {
+// (S = 32: the block of the 32-wide schedule, all 64 lanes; S = 16: the 16-wide schedule -- lanes 0..15 rows, 16..31 columns
+// of the inverse, lanes 32..63 shadow them with identical values and identical store addresses.)
+template <int S, int PITCH>
+__device__ __forceinline__ int factor_inverse(double* a, int base /* offset of the block's (0,0) element */, double* scr, bool do_inverse) {
   int lane = threadIdx.x & 63;
   // opaque per call: otherwise LICM hoists the lane-only values below (delta, store addresses) out of the caller's
   // sub-block loop and keeps them alive across it -- hundreds of spilled VGPRs
   asm volatile("" : "+v"(lane));
-  const int i = lane & 31;                          // row (lower half) / column of X (upper half)
-  const bool lower = lane < 32;
-  const int rowbase = (j0 + i) * DP + j0;
+  const int i = lane & (S - 1);                     // row (lower half) / column of X (upper half)
+  const int lane2 = lane & (2 * S - 1);
+  const bool lower = lane2 < S;
+  const int rowbase = base + i * PITCH;
   const double di = (double)i;
-  double v[SB];
+  double v[S];
 #pragma unroll
-  for (int c = 0; c < SB; ++c) {
+  for (int c = 0; c < S; ++c) {
     const double aic = a[rowbase + c];
     const double delta = 1.0 - __builtin_fmin(__builtin_fabs(di - (double)c), 1.0);
     v[c] = lower ? aic : delta;
   }
   int pinned = 0;
 #pragma unroll
-  for (int j = 0; j < SB; ++j) {
+  for (int j = 0; j < S; ++j) {
     const double p = readlane_f64(v[j], j);
     const bool bad = !(p > 0.0) || !isfinite(p);     // wave-uniform: dead / padded parameter (H7) -> unit row
     pinned += bad ? 1 : 0;
@@ -113,12 +117,12 @@ __device__ __forceinline__ int factor_inverse_32(double* a, int j0, double* scr,
     inv_d = bad ? 0.0 : inv_d;                       // pinned: no multipliers below, unit diagonal for the inverse
     const double scale = lower ? inv_d : (bad ? 1.0 : inv_d);
     double m = v[j] * scale;                         // L[i][j] (junk for rows above j: never stored) | x_j of column q
-    m = (lane == j) ? d : m;                         // lane j keeps the diagonal entry itself (also when the pivot is NaN)
+    m = (lane2 == j) ? d : m;                        // lane j keeps the diagonal entry itself (also when the pivot is NaN)
     v[j] = m;
     // groups of 8: all broadcasts of a group first (16 distinct SGPRs), then its FMAs -- left to itself hipcc chains
     // readlane, readlane, s_nop, fma through one SGPR pair, which serialises the whole column
 #pragma unroll
-    for (int g = 0; g < SB / 8; ++g) {
+    for (int g = 0; g < S / 8; ++g) {
       if (8 * g + 7 > j) {                                     // (compile-time after unrolling)
         double lk[8];
 #pragma unroll
@@ -137,13 +141,21 @@ __device__ __forceinline__ int factor_inverse_32(double* a, int j0, double* scr,
   const int dump = (int)(scr - a) + lane;
   const int up = lower ? 0 : 1;
 #pragma unroll
-  for (int c = 0; c < SB; ++c) {
-    const int keep = lower ? min(max(i - c + 1, 0), 1) : (do_inverse ? min(max(c - i + 1, 0), 1) : 0);
-    const int real = rowbase + c + up;
-    a[dump + keep * (real - dump)] = v[c];
+  for (int c = 0; c < S; ++c) {
+    const bool keep = lower ? (c <= i) : (do_inverse && c >= i);
+    a[keep ? (rowbase + c + up) : dump] = v[c];
   }
   __builtin_amdgcn_wave_barrier();
   return pinned;
+}
+
+// (Tried and dropped for the 16-wide sweep, all within 5 % of this one at ~2.5 us per 16 x 16 block: a root-free variant with
+// only a reciprocal on the chain and the sixteen inverse square roots as one vector chain at the end; the same with the
+// broadcasts through an LDS line instead of v_readlane; and the matrix-pipe variant below.  In-kernel cycle stamps: a column
+// costs ~160 cycles + ~13 per remaining row whatever feeds the FMAs, and load + final stores are a quarter of the sweep.)
+
+__device__ __forceinline__ int factor_inverse_32(double* a, int j0, double* scr, bool do_inverse) {
+  return factor_inverse<SB, DP>(a, j0 * DP + j0, scr, do_inverse);
 }
 
 // The same job on the matrix pipe, without lane broadcasts.  The 32 x 32 block lives in registers in the f64 MFMA C/D layout
@@ -429,6 +441,226 @@ __device__ __forceinline__ void chol_diag_body(double* __restrict__ A, int64_t l
   }
 }
 
+// ---- 16-wide schedule of the diagonal block -----------------------------------------------------------------------------------
+// Same job as chol_diag_body (factor the 128 x 128 block, write L back, X = L^-1 to Linv), organised in eight 16-wide steps so
+// that the sequential part -- the single-wave pivot sweep -- shrinks: a 16 x 16 sweep costs ~130 ns per pivot against ~210 ns
+// in a 32 x 32 one (the broadcasts per pivot grow with the block width), and everything else is 16 x 16 x 16 MFMA products:
+//   S1 (wave 0)  factor_inverse<16> on the diagonal block of step jb                       -> L_jj, X_jj
+//   S2 (all)     panel below:  L(i,jb) = A(i,jb) X_jj^T, i > jb;   row jb of the inverse:  X(jb,c) = X_jj R(jb,c), c < jb
+//   S3 (wave 0)  next diagonal block A(jb+1,jb+1) -= L(jb+1,jb) L(jb+1,jb)^T, then straight on to S1 of step jb+1, while
+//      (waves 1..3) the rest of the trailing update A(i,c) -= L(i,jb) L(c,jb)^T and the running sums of the inverse
+//                   R(i,c) -= L(i,jb) X(jb,c)  (i > jb >= c),  and the write-back of block column jb of L.
+// R(i,c) = -sum_{m<i} L(i,m) X(m,c) is the block forward substitution of L X = I in right-looking form; it lives where X(i,c)
+// will end up: transposed in the strict upper part, one column to the right (X[r][c] <-> a[c][r+1], as in chol_diag_body).
+// LDS: the 128 x 129 block + the dump line of the sweep.
+#ifdef VMC_DIAG16_STAMPS      // diagnostic build: wall-clock stamps (100 MHz) of wave 0 at the stage boundaries of the last call
+__device__ long long g_diag16_stamps[64];
+#define D16_STAMP(i) { if (t == 0) g_diag16_stamps[i] = wall_clock64(); }
+#define D16_STAMP1(i) { if (t == 64 && jb == 0) g_diag16_stamps[i] = wall_clock64(); }
+#else
+#define D16_STAMP(i)
+#define D16_STAMP1(i)
+#endif
+
+// 16 x 16 x 16 block products of the 16-wide schedule, by KIND (compile-time strides and masks), one or two at a time.
+// The LDS image is BLOCKED: an 8 x 8 grid of 16 x 17 slots (pitch 17: the 16 rows x 2 k-columns of a half-wave's ds_read_b64 fall
+// on distinct banks, as in mfma_tile.hpp; with the 128 x 129 row-major image of the 32-wide schedule every operand fetch and
+// every accumulator access is a 2-way bank conflict, and the shared LDS pipe, not the matrix pipe, limited the three update waves).
+//   slot (bi, bj), bi >  bj : block (bi, bj) of A, later of L                        element (r, c) at [r 17 + c]
+//   slot (bi, bi)           : lower triangle L_ii; X_ii = L_ii^-1 in the strict upper part, X_ii[r][c] (r >= c) at [c 17 + r + 1]
+//   slot (bi, bj), bi <  bj : R(bj, bi), later X(bj, bi) -- block (bj, bi) of the inverse, element (r, c) at [r 17 + c]
+// p = {first-operand slot, second-operand slot, result slot}:
+//   KIND 0  panel:            C[r][c]  = sum_{k<=c} A[r][k] X_jj[c][k]           (p0 = slot (i,jb), p1 = slot (jb,jb), pc = p0)
+//   KIND 1  row of inverse:   C[r][c]  = sum_{k<=r} X_jj[r][k] R[k][c]           (p0 = slot (jb,jb), p1 = pc = slot (cb,jb))
+//   KIND 2  trailing update:  C[r][c] -= sum_k L(i,jb)[r][k] L(c',jb)[c][k]
+//   KIND 3  inverse sums:     C[r][c] -= sum_k L(i,jb)[r][k] X(jb,cb)[k][c]      (dg: X(jb,jb) = X_jj, zero for k < c)
+constexpr int BP = 17, BLK = 16 * BP;
+__device__ __forceinline__ constexpr int slot16(int bi, int bj) { return (bi * 8 + bj) * BLK; }
+struct P3 { int p0, p1, pc; bool dg; };
+
+template <int KIND>
+__device__ __forceinline__ void blk16_operands(const double* __restrict__ a, const P3& d, int lr, int k, double& fa, double& fb) {
+  if (KIND == 0) {
+    fa = a[d.p0 + lr * BP + k];
+    fb = (k <= lr) ? a[d.p1 + k * BP + lr + 1] : 0.0;
+  } else if (KIND == 1) {
+    fa = (k <= lr) ? a[d.p0 + k * BP + lr + 1] : 0.0;
+    fb = a[d.p1 + k * BP + lr];
+  } else if (KIND == 2) {
+    fa = -a[d.p0 + lr * BP + k];
+    fb = a[d.p1 + lr * BP + k];
+  } else {
+    fa = -a[d.p0 + lr * BP + k];
+    fb = d.dg ? ((k < lr) ? 0.0 : a[d.p1 + lr * BP + k + 1]) : a[d.p1 + k * BP + lr];
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ void blk16_one(double* __restrict__ a, const P3& x) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  double4_t ax = {0.0, 0.0, 0.0, 0.0};
+  if (KIND >= 2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ax[q] = a[x.pc + (lk + 4 * q) * BP + lr];
+  }
+  double fa[4], fb[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) blk16_operands<KIND>(a, x, lr, 4 * s + lk, fa[s], fb[s]);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) ax = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s], fb[s], ax, 0, 0, 0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a[x.pc + (lk + 4 * q) * BP + lr] = ax[q];
+}
+
+template <int KIND>
+__device__ __forceinline__ void blk16_two(double* __restrict__ a, const P3& x, const P3& y) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  double4_t ax = {0.0, 0.0, 0.0, 0.0}, ay = {0.0, 0.0, 0.0, 0.0};
+  if (KIND >= 2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ax[q] = a[x.pc + (lk + 4 * q) * BP + lr];
+      ay[q] = a[y.pc + (lk + 4 * q) * BP + lr];
+    }
+  }
+  double fax[4], fbx[4], fay[4], fby[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    blk16_operands<KIND>(a, x, lr, 4 * s + lk, fax[s], fbx[s]);
+    blk16_operands<KIND>(a, y, lr, 4 * s + lk, fay[s], fby[s]);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    ax = __builtin_amdgcn_mfma_f64_16x16x4f64(fax[s], fbx[s], ax, 0, 0, 0);
+    ay = __builtin_amdgcn_mfma_f64_16x16x4f64(fay[s], fby[s], ay, 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    a[x.pc + (lk + 4 * q) * BP + lr] = ax[q];
+    a[y.pc + (lk + 4 * q) * BP + lr] = ay[q];
+  }
+}
+
+// items [first, count) step `stride` of one kind, two at a time
+template <int KIND, class MK>
+__device__ __forceinline__ void blk16_range(double* __restrict__ a, int first, int count, int stride, MK make) {
+  int it = first;
+  for (; it + stride < count; it += 2 * stride) blk16_two<KIND>(a, make(it), make(it + stride));
+  if (it < count) blk16_one<KIND>(a, make(it));
+}
+
+template <int NT>      // threads of the workgroup: 256 or 512 (wave 0 runs the chain, the other NT/64 - 1 waves the updates)
+__device__ __forceinline__ void chol_diag16_body(double* __restrict__ A, int64_t lda, int k0, int n, double* __restrict__ Linv,
+                                                 int* __restrict__ info) {
+  extern __shared__ double a[];                    // 64 slots of 16 x 17, then the dump line of the sweep
+  constexpr int S16 = 16, NS = NB / S16;          // 8 steps
+  double* scr = a + 64 * BLK;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // wave-uniform: the item bookkeeping below runs on the scalar unit
+  // waves; update waves -- with eight waves, wave 4 shares SIMD 0 with the chain wave and is kept off the matrix pipe (it only
+  // writes finished columns of L back); double2 loads per thread
+  constexpr int NW = NT / 64, NU = (NW == 8) ? 6 : NW - 1, NLD = NB * (NB / 2) / NT;
+  const int worker = (NW == 8) ? ((wave < 4) ? wave - 1 : wave - 2) : wave - 1;     // -1: the chain wave; (NW == 8) wave 4 -> 2, unused
+  const bool updates = (wave != 0) && !(NW == 8 && wave == 4);
+  // load the lower triangle (identity beyond n); everything else starts at zero (the R sums, the strict upper part of diagonal slots)
+  {
+    double2_t v[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      const int e = t + NT * q, i = e >> 6, jp = (e & 63) * 2;
+      v[q] = (double2_t){0.0, 0.0};
+      if (jp <= i && i < n) v[q] = *reinterpret_cast<const double2_t*>(A + (int64_t)(k0 + i) * lda + k0 + jp);   // jp + 1 <= i + 1 <= n: in range of the padded row
+    }
+    for (int idx = t; idx < 64 * BLK; idx += NT) a[idx] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      const int e = t + NT * q, i = e >> 6, jp = (e & 63) * 2;
+      const bool rowok = i < n;
+      if (jp <= i) {
+        const int at = slot16(i >> 4, jp >> 4) + (i & 15) * BP + (jp & 15);
+        a[at] = rowok ? v[q].x : ((jp == i) ? 1.0 : 0.0);
+        if (jp + 1 <= i) a[at + 1] = (rowok && jp + 1 < n) ? v[q].y : ((jp + 1 == i) ? 1.0 : 0.0);
+      }
+    }
+  }
+  __syncthreads();
+
+  auto sweep = [&](int jb) {
+    const int pinned = factor_inverse<S16, BP>(a, slot16(jb, jb), scr, true);
+    if (lane == 0 && pinned) atomicAdd(info, pinned);
+  };
+  D16_STAMP(0)
+  if (wave == 0) sweep(0);
+  __syncthreads();
+  D16_STAMP(1)
+
+#pragma nounroll
+  for (int jb = 0; jb < NS; ++jb) {
+    const int j0 = jb * S16;
+    const int nbel = NS - 1 - jb;                  // 16-row blocks below this step's diagonal block
+    const int djj = slot16(jb, jb);
+    // ---- S2: nbel panel blocks  L(i,jb) = A(i,jb) X_jj^T  and jb blocks of row jb of the inverse  X(jb,c) = X_jj R(jb,c);
+    // every block has one owner, which reads its operands completely before it writes the result in place.  The panel blocks
+    // go to the waves first (the chain needs block row jb+1).
+    blk16_range<0>(a, wave, nbel, NW, [&](int it) { const int sl = slot16(jb + 1 + it, jb); return P3{sl, djj, sl, false}; });
+    blk16_range<1>(a, (wave + NW - nbel % NW) % NW, jb, NW, [&](int cb) { const int sl = slot16(cb, jb); return P3{djj, sl, sl, false}; });
+    __syncthreads();
+    D16_STAMP(2 + 4 * jb)
+    if (wave == 0) {
+      if (nbel > 0) {
+        // ---- S3a: the next diagonal block  A(jb+1,jb+1) -= L(jb+1,jb) L(jb+1,jb)^T,  then its sweep (the chain)
+        blk16_one<2>(a, P3{slot16(jb + 1, jb), slot16(jb + 1, jb), slot16(jb + 1, jb + 1), false});
+        __builtin_amdgcn_wave_barrier();
+        D16_STAMP(3 + 4 * jb)
+        sweep(jb + 1);
+        D16_STAMP(4 + 4 * jb)
+      }
+    } else if (updates) {
+      // ---- S3b: rest of the trailing update, lower block pairs (i,c) of the remaining grid except the first, and
+      // ---- S3c: R(i,cb) -= L(i,jb) X(jb,cb), i > jb, cb <= jb  (X(jb,jb) = X_jj is lower triangular: k >= c only)
+      const int n3b = nbel * (nbel + 1) / 2 - 1, n3c = nbel * (jb + 1);
+      D16_STAMP1(50)
+      blk16_range<2>(a, worker, n3b, NU, [&](int it) {
+        // (bi, bc) of the it+1-th lower pair, it + 1 <= 27: row starts 0, 1, 3, 6, 10, 15, 21 (a compare chain, no sqrt)
+        const int pr = it + 1;
+        const int bi = (pr >= 1) + (pr >= 3) + (pr >= 6) + (pr >= 10) + (pr >= 15) + (pr >= 21);
+        const int bc = pr - bi * (bi + 1) / 2;
+        return P3{slot16(jb + 1 + bi, jb), slot16(jb + 1 + bc, jb), slot16(jb + 1 + bi, jb + 1 + bc), false};
+      });
+      D16_STAMP1(51)
+      blk16_range<3>(a, (worker + NU - n3b % NU) % NU, n3c, NU, [&](int u) {
+        const int ii = u / (jb + 1), cb = u - ii * (jb + 1), i = jb + 1 + ii;
+        return P3{slot16(i, jb), (cb == jb) ? djj : slot16(cb, jb), slot16(cb, i), cb == jb};
+      });
+      D16_STAMP1(52)
+    }
+    // block column jb of L is final: write it back (rows j0.., 16 columns) -- every wave but the chain wave; with eight waves the
+    // upper four, so that the wave that stays off the matrix pipe carries its share from the start
+    if (NW == 8 ? (wave >= 4) : (wave != 0)) {
+      const int first = (NW == 8) ? t - 256 : t - 64, step = (NW == 8) ? 256 : NT - 64;
+      for (int idx = first; idx < (NB - j0) * S16; idx += step) {
+        const int i = j0 + idx / S16, jj = idx & (S16 - 1);
+        if (i < n && j0 + jj <= i) A[(int64_t)(k0 + i) * lda + k0 + j0 + jj] = a[slot16(i >> 4, jb) + (i & 15) * BP + jj];
+      }
+    }
+    D16_STAMP1(53)
+    __syncthreads();
+    D16_STAMP(5 + 4 * jb)
+  }
+  D16_STAMP(40)
+  // X = L^-1: dense lower triangular, zero elsewhere
+#pragma unroll 16
+  for (int q = 0; q < NB * NB / NT; ++q) {
+    const int idx = t + NT * q, i = idx / NB, c = idx - i * NB;
+    const int ib = i >> 4, cb = c >> 4, ri = i & 15, ci = c & 15;
+    double v = 0.0;
+    if (i < n && c <= i) v = (ib == cb) ? a[slot16(ib, ib) + ci * BP + ri + 1] : a[slot16(cb, ib) + ri * BP + ci];
+    Linv[idx] = v;
+  }
+  D16_STAMP(41)
+}
+
 // Latency-optimised strip kernel for the two short dependent GEMMs of every panel (K = 128 exactly):
 //   mode 0 (panel solve):        A[row0.., k0:k0+128] <- A[row0.., k0:k0+128] * Linv^T          (B = Linv, 128 x 128)
 //   mode 1 (next-panel update):  A[row0.., c0:c0+128] -= A[row0.., k0:k0+128] * A[c0.., k0:k0+128]^T   (c0 = k0+128)
@@ -529,6 +761,13 @@ __global__ __launch_bounds__(256, 1) void chol_strip_kernel(double* __restrict__
 __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, int64_t lda, int k0, int n, double* __restrict__ Linv,
                                                        int* __restrict__ info, int phase) {
   chol_diag_body(A, lda, k0, n, Linv, info, phase);
+}
+
+// the 16-wide schedule: 512 threads -- wave 0 runs the chain, seven waves share the 16 x 16 x 16 updates of a step
+constexpr int D16_THREADS = 512;
+__global__ __launch_bounds__(D16_THREADS) void chol_diag16_kernel(double* __restrict__ A, int64_t lda, int k0, int n, double* __restrict__ Linv,
+                                                                  int* __restrict__ info) {
+  chol_diag16_body<D16_THREADS>(A, lda, k0, n, Linv, info);
 }
 
 // One 128 x 128 tile (ti >= tj, block indices inside the trailing matrix) of A22 -= L21 L21^T.
@@ -637,6 +876,19 @@ __global__ __launch_bounds__(256) void chol_syrk_diag_kernel(double* __restrict_
     chol_diag_body(A, lda, k1, (P - k1 < NB) ? (P - k1) : NB, Linv_next, info, phase);
     return;
   }
+  syrk_tile(A, lda, P, k0, n, blockIdx.x - 1);
+}
+
+// ... with the 16-wide schedule for the diagonal block: workgroups of 512 threads, of which the tile workgroups use the first 256
+// (waves that have ended do not take part in the workgroup barriers of the tile engine)
+__global__ __launch_bounds__(D16_THREADS) void chol_syrk_diag16_kernel(double* __restrict__ A, int64_t lda, int P, int k0, int n,
+                                                                       double* __restrict__ Linv_next, int* __restrict__ info) {
+  if (blockIdx.x == 0) {
+    const int k1 = k0 + n;
+    chol_diag16_body<D16_THREADS>(A, lda, k1, (P - k1 < NB) ? (P - k1) : NB, Linv_next, info);
+    return;
+  }
+  if (threadIdx.x >= 256) return;
   syrk_tile(A, lda, P, k0, n, blockIdx.x - 1);
 }
 
@@ -854,6 +1106,13 @@ __global__ void pinv_coeffs_kernel(const double* __restrict__ ev, const double* 
 // workspace: nb inverse diagonal blocks (128 x 128 doubles each), then the per-panel counters of the one-launch-per-panel schedule
 static int64_t chol_counter_bytes(int nb) { return (((int64_t)nb * (nb + 2) * (int64_t)sizeof(unsigned int)) + 255) / 256 * 256; }
 
+#ifdef VMC_DIAG16_STAMPS
+extern "C" int vmcpde_debug_read_diag16_stamps(long long* out_host) {
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_diag16_stamps), sizeof(long long) * 64);
+}
+
+#endif
+
 extern "C" int64_t vmcpde_chol_workspace_bytes(int32_t P) {
   if (P <= 0) return 0;
   const int nb = (P + NB - 1) / NB;
@@ -884,6 +1143,8 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
       VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_DMA_LDS_BYTES));
       VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_panel_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
       VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_panel_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_diag16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_syrk_diag16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
       ctx->attr_chol = true;
     }
     if (ctx->side == nullptr) {
@@ -905,18 +1166,24 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
   const int diag_phase = 5;
 #endif
   const int fused_max = env_int("VMCPDE_CHOL_FUSED_MAX", FUSED_MAX_TILES);
-  // 1: one launch per panel (chol_panel_kernel).  Off by default -- NEGATIVE RESULT: 2.88 ms against 2.46 ms at P = 4213, 0.324
+  // 1: one launch per panel (chol_panel_kernel, with the 32-wide diagonal block).  Off by default -- NEGATIVE RESULT: 2.88 ms against 2.46 ms at P = 4213, 0.324
   // against 0.314 ms at P = 640.  Each hand-over between workgroups costs a release (L2 write-back of the XCD) + a polled counter
   // + an acquire (L1 / L2 invalidate) = ~3 us, as much as the launch boundary it replaces, and the invalidates evict the operand
   // panels the other workgroups of that XCD were re-using.
   const int panel_mode = env_int("VMCPDE_CHOL_PANEL", 0);
+  // the 16-wide schedule of the diagonal block (chol_diag16_body; 0: the 32-wide chol_diag_body, which the debug phases belong to)
+  const bool diag16 = env_int("VMCPDE_CHOL_DIAG16", 1) != 0 && diag_phase == 5;
+  auto launch_diag = [&](hipStream_t s_, int kk0, int nn, double* Li) {
+    if (diag16) hipLaunchKernelGGL(chol_diag16_kernel, dim3(1), dim3(D16_THREADS), diag_lds, s_, A, lda, kk0, nn, Li, info);
+    else hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), diag_lds, s_, A, lda, kk0, nn, Li, info, diag_phase);
+  };
   unsigned int* counters = reinterpret_cast<unsigned int*>(static_cast<char*>(workspace) + (int64_t)nb * NB * NB * (int64_t)sizeof(double));
   if (panel_mode) VMC_CHECK_HIP(hipMemsetAsync(counters, 0, (size_t)chol_counter_bytes(nb), st));
   hipStream_t side = ctx->side;
   hipEvent_t ev_fork = ctx->ev_fork, ev_join = ctx->ev_join;
   {
     const int n0 = (P < NB) ? P : NB;
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), diag_lds, st, A, lda, 0, n0, Linv, info, diag_phase);
+    launch_diag(st, 0, n0, Linv);
   }
   for (int k = 0; k < nb; ++k) {
     const int k0 = k * NB;
@@ -955,14 +1222,17 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
     const int n1 = (P - k1 < NB) ? (P - k1) : NB;
     const int64_t tiles = (nrem > 1) ? tri_count(nrem - 1) : 0;
     if (tiles == 0) {
-      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), diag_lds, st, A, lda, k1, n1, Linv_next, info, diag_phase);
+      launch_diag(st, k1, n1, Linv_next);
     } else if (tiles <= fused_max) {
-      hipLaunchKernelGGL(chol_syrk_diag_kernel, dim3(1u + (unsigned)tiles), dim3(256), diag_lds, st, A, lda, P, k0, n, Linv_next, info,
-                         diag_phase);
+      if (diag16)
+        hipLaunchKernelGGL(chol_syrk_diag16_kernel, dim3(1u + (unsigned)tiles), dim3(D16_THREADS), diag_lds, st, A, lda, P, k0, n, Linv_next, info);
+      else
+        hipLaunchKernelGGL(chol_syrk_diag_kernel, dim3(1u + (unsigned)tiles), dim3(256), diag_lds, st, A, lda, P, k0, n, Linv_next, info,
+                           diag_phase);
     } else {
       VMC_CHECK_HIP(hipEventRecord(ev_fork, st));
       VMC_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), diag_lds, side, A, lda, k1, n1, Linv_next, info, diag_phase);
+      launch_diag(side, k1, n1, Linv_next);
       VMC_CHECK_HIP(hipEventRecord(ev_join, side));
       hipLaunchKernelGGL(chol_syrk_kernel, dim3((unsigned)tiles), dim3(256), TILE_DMA_LDS_BYTES, st, A, lda, P, k0, n);
       VMC_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
