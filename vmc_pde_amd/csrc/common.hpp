@@ -65,6 +65,7 @@ struct FlowProgram {
   int32_t off_L, off_Ldiag, off_dist, off_mu;
   int32_t max_width;     // widest MLP layer (incl. inputs/outputs)
   int32_t max_sum_act;   // max over trafos of (n_in + sum_hidden)
+  int32_t max_mlp_weights; // max over the MLPs of the doubles of all its layers' kernels and biases (the LDS weight stage)
   int32_t act_units;     // activation workspace: sum over all MLPs of (hidden widths + outputs) doubles per sample
   double alpha;          // SingleTrafo.alpha = 10 (net.py:50)
   int32_t global_change; // net.py:72: block b ends with y -> th[off_gscale[b]] * y + th[off_goffset[b] + i]

@@ -56,7 +56,7 @@ struct Regions {
   int Y, Q; // whitened residual y = U^-1 r and q = U^-T y (d each)
   int cs;   // component stride of A/B = widest layer
   int total;
-  int wgt;  // doubles of the workgroup-shared weight stage behind the per-lane vectors (kernel + bias of one layer)
+  int wgt;  // doubles of the workgroup-shared weight stage behind the per-lane vectors (kernels + biases of ALL layers of one MLP)
 };
 
 // values-only passes (flow_sample): state, two single-component MLP buffers, the s stash and the latent line
@@ -71,7 +71,7 @@ Regions make_regions_values(const FlowProgram& fp) {
   r.SOUT = u; u += d;
   r.LAT = u; u += d;
   r.total = u;
-  r.wgt = W * W + W;
+  r.wgt = fp.max_mlp_weights;
   return r;
 }
 
@@ -102,7 +102,7 @@ Regions make_regions(const FlowProgram& fp) {
   r.Y = u; u += d;
   r.Q = u; u += d;
   r.total = (u > end_taylor) ? u : end_taylor;
-  r.wgt = W * W + W;
+  r.wgt = fp.max_mlp_weights;
   return r;
 }
 
@@ -208,19 +208,31 @@ __device__ __forceinline__ double fast_tanh(double x) {
 // synchronises).  The layer loops then read weights as LDS broadcasts: in-order returns that hipcc can pipeline against the
 // per-lane LDS reads, where scalar loads (out-of-order, 33 KB of weights against a 16 KB scalar cache) forced a full
 // lgkmcnt(0) stall of several hundred cycles per input unit.
-__device__ __forceinline__ void stage_weights(const Ctx& c, const DenseLayer& L) {
-  const int nk = L.n_in * L.n_out;
-  for (int idx = threadIdx.x; idx < nk + L.n_out; idx += blockDim.x)
-    c.wl[idx] = c.th[(idx < nk) ? (L.off_kernel + idx) : (L.off_bias + idx - nk)];
+// The whole MLP at once (layer k at layer_woff(T, k): kernel [n_in][n_out], then bias [n_out]): one round trip to the
+// parameter vector and one barrier per network instead of one per layer -- the kernel is bound by exactly these chains.
+__device__ __forceinline__ int layer_woff(const Trafo& T, int k) {
+  int off = 0;
+  for (int q = 0; q < k; ++q) off += T.layer[q].n_in * T.layer[q].n_out + T.layer[q].n_out;
+  return off;
+}
+__device__ __forceinline__ void stage_weights(const Ctx& c, const Trafo& T) {
+  int off = 0;
+  for (int k = 0; k < T.n_layers; ++k) {
+    const DenseLayer& L = T.layer[k];
+    const int nk = L.n_in * L.n_out;
+    for (int idx = threadIdx.x; idx < nk + L.n_out; idx += blockDim.x)
+      c.wl[off + idx] = c.th[(idx < nk) ? (L.off_kernel + idx) : (L.off_bias + idx - nk)];
+    off += nk + L.n_out;
+  }
 }
 
 // y = tanh-layer(x): z_j = b_j + sum_i W[i][j] a_i (net.py:55-61), with NC Taylor components.
 // Cooperative: the input must be visible to all waves on entry; the caller synchronises before the output is read.
 template <int NC>
-__device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, int uin, int uout, int cs, double scale, int wofs = -1) {
+__device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, int woff, int uin, int uout, int cs, double scale, int wofs = -1) {
   const int n_in = L.n_in, n_out = L.n_out;
-  const double* __restrict__ W = c.wl;                  // staged by the caller (stage_weights + barrier)
-  const double* __restrict__ Bv = c.wl + n_in * n_out;
+  const double* __restrict__ W = c.wl + woff;           // staged by the caller (stage_weights + barrier)
+  const double* __restrict__ Bv = W + n_in * n_out;
   for (int j0 = c.wave * JB; j0 < n_out; j0 += c.nw * JB) {     // output blocks round-robin over the waves
     double acc[NC][JB];
 #pragma unroll
@@ -269,13 +281,14 @@ __device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, i
 template <int NC>
 __device__ __forceinline__ int mlp_forward(const Ctx& c, const Trafo& T, int uA, int uB, int cs, int wofs = -1) {
   int cur = uA, nxt = uB;
-  int wl = wofs;
+  int wl = wofs, woff = 0;
+  stage_weights(c, T);
+  SYNC();                                   // (also orders the previous user's reads of the stage before this write: every pass ends with a barrier)
   for (int k = 0; k < T.n_layers; ++k) {
-    stage_weights(c, T.layer[k]);
-    SYNC();
-    dense_layer<NC>(c, T.layer[k], cur, nxt, cs, (k == T.n_layers - 1) ? c.fp->alpha : 1.0, wl);
+    dense_layer<NC>(c, T.layer[k], woff, cur, nxt, cs, (k == T.n_layers - 1) ? c.fp->alpha : 1.0, wl);
     SYNC();
     if (wl >= 0) wl += T.layer[k].n_out;
+    woff += T.layer[k].n_in * T.layer[k].n_out + T.layer[k].n_out;
     const int t = cur; cur = nxt; nxt = t;
   }
   return cur;
@@ -479,15 +492,16 @@ __device__ __forceinline__ void latent_forward(const Ctx& c, const LatentCache* 
 
 // SingleTrafo forward keeping every layer input in ACT (input already in ACT[0..n_in)); outputs go to uOUT.
 __device__ __forceinline__ void mlp_forward_store(const Ctx& c, const Trafo& T, int uACT, int uOUT) {
-  int in = uACT;
+  int in = uACT, woff = 0;
+  stage_weights(c, T);
+  SYNC();
   for (int k = 0; k < T.n_layers; ++k) {
     const DenseLayer& L = T.layer[k];
     const bool last = (k == T.n_layers - 1);
     const int out = last ? uOUT : in + L.n_in;
-    stage_weights(c, L);
+    dense_layer<1>(c, L, woff, in, out, 0, last ? c.fp->alpha : 1.0);
     SYNC();
-    dense_layer<1>(c, L, in, out, 0, last ? c.fp->alpha : 1.0);
-    SYNC();
+    woff += L.n_in * L.n_out + L.n_out;
     in = out;
   }
 }
@@ -508,10 +522,12 @@ __device__ __forceinline__ void mlp_load_activations(const Ctx& c, const Trafo& 
 // Cooperative: every layer is split by INPUT unit i (wave w owns i = w, w+nw, ...): the owner forms
 // eps_i = sum_j W[i][j] delta_j, stores the kernel rows (i, :) of JT, and turns eps_i into the next delta_i; bias rows go
 // round-robin by output block.  On entry OUT/ACT are visible to all waves and uW was written by wave 0.
+// staged: the weights of T are already in the LDS stage (the forward-store pass of the same network ran just before).
 __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const Regions& r, int uOUT, int uW,
-                                             void* __restrict__ JT, int64_t ldj, int64_t n, bool active) {
+                                             void* __restrict__ JT, int64_t ldj, int64_t n, bool active, bool staged) {
   const double alpha = c.fp->alpha;
   const int nl = T.n_layers;
+  if (!staged) stage_weights(c, T);
   if (W0) {
     const DenseLayer& L = T.layer[nl - 1];
     for (int j = 0; j < L.n_out; ++j) {
@@ -526,9 +542,9 @@ __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const
     const int n_in = L.n_in, n_out = L.n_out;
     in_off -= n_in;
     const int uin = r.ACT + in_off;
-    stage_weights(c, L);
-    SYNC();                                   // also publishes wave 0's DEL0 (first layer) / the previous layer's deltas
-    const double* __restrict__ W = c.wl;
+    if (k == nl - 1) SYNC();                  // publishes wave 0's DEL0 (and the weights if they were staged here); later layers
+                                              // start behind the barrier that closed the previous one
+    const double* __restrict__ W = c.wl + layer_woff(T, k);
     for (int i = c.wave; i < n_in; i += c.nw) LD(r.EPS + i) = 0.0;
     for (int j0 = 0, blk = 0; j0 < n_out; j0 += JB, ++blk) {
       double dl[JB];
@@ -579,7 +595,7 @@ __device__ __forceinline__ void halfstep_backward(const Ctx& c, const HalfStep& 
     else mlp_forward_store(c, h.t, r.ACT, r.OUTT);
     if (W0)
       for (int k = 0; k < h.n_c; ++k) LD(r.DW + k) = LD(r.G + h.idx_c[k]);
-    mlp_backward(c, h.t, r, r.OUTT, r.DW, JT, ldj, n, active);     // (starts with wave 0's part, then a barrier)
+    mlp_backward(c, h.t, r, r.OUTT, r.DW, JT, ldj, n, active, c.actw == nullptr);     // (starts with wave 0's part, then a barrier)
     // ACT[0..n_a) still holds the half-step input for the s network
   }
   if (c.actw) mlp_load_activations(c, h.s, r.ACT, r.OUTS, h.act_off_s);
@@ -609,7 +625,7 @@ __device__ __forceinline__ void halfstep_backward(const Ctx& c, const HalfStep& 
       LD(r.G + ix) = gnew;
     }
   }
-  mlp_backward(c, h.s, r, r.OUTS, r.DW, JT, ldj, n, active);
+  mlp_backward(c, h.s, r, r.OUTS, r.DW, JT, ldj, n, active, c.actw == nullptr);
   if (W0)
     for (int i = 0; i < h.n_a; ++i) LD(r.G + h.idx_a[i]) += LD(r.GAM + i);
 }
