@@ -176,7 +176,7 @@ extern "C" int vmcpde_tdvp_prepare(const double* eloc, int64_t n_samples, const 
   VMC_REQUIRE(n_samples >= 1, "empty sample set");
   VMC_REQUIRE((row_e == nullptr) == (row_one == nullptr), "row_e and row_one go together");
   VMC_REQUIRE(workspace_bytes >= vmcpde_tdvp_prepare_workspace_bytes(), "prepare workspace too small");
-  int blocks = (int)((n_samples + 511) / 512);
+  int blocks = (int)((n_samples + 2047) / 2048);      // (more, smaller blocks are slower: every block pays a release fence)
   if (blocks > PREP_BLOCKS_MAX) blocks = PREP_BLOCKS_MAX;
   hipLaunchKernelGGL(tdvp_prepare_kernel, dim3(blocks), dim3(PREP_THREADS), 0, (hipStream_t)stream, eloc, n_samples, cE_dev, row_e, row_one,
                      sums3, count, max_out, static_cast<double*>(workspace));
