@@ -27,7 +27,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "published_diffusion_d8_gauss.npz"), **g)
     with h5py.File(REF + "data_diffusion/dim8_StudentT_nu2_NsamplesTDVP10000_NsamplesObs10000/infos.hdf5", "r") as f:
         s = dict(times=f["times"][:], entropy=f["entropy"][:], dist_params=f["dist_params"][:, 0], tdvp_error=f["tdvp_error"][:],
-                 solver_res=f["solver_res"][:], covar_diag=np.diagonal(f["covar"][:], axis1=1, axis2=2).copy())
+                 solver_res=f["solver_res"][:], covar_diag=np.diagonal(f["covar"][:], axis1=1, axis2=2).copy(),
+                 ev_first=f["ev"][0], ev_last=f["ev"][-1], snr_first=f["snr"][0])
     np.savez_compressed(os.path.join(OUT, "published_diffusion_d8_student_t.npz"), **s)
     # phase space (3 damped oscillators, evolutionEq.py:107-119): the reference's own Langevin ensemble for T = 10 up to t = 5,
     # every 10th record; and the flow run's step schedule / solver diagnostics (its temperatures differ per oscillator and
@@ -37,7 +38,7 @@ def main():
         w = dict(times=f["times"][sel], x1=f["x1"][sel], covar=f["covar"][sel])
     with h5py.File(REF + "data_phaseSpace/INN/NsamplesTDVP10000_NsamplesObs10000_Tdifferent/infos.hdf5", "r") as f:
         w.update(inn_times=f["times"][:], inn_tdvp_error=f["tdvp_error"][:], inn_solver_res=f["solver_res"][:],
-                 inn_n_param=np.int64(f["ev"].shape[1]))
+                 inn_n_param=np.int64(f["ev"].shape[1]), inn_ev_first=f["ev"][0], inn_ev_last=f["ev"][-1])
     np.savez_compressed(os.path.join(OUT, "published_phase_space.npz"), **w)
     print("phase space: wiener", w["times"].shape, "covar diag at t=5", np.diagonal(w["covar"][-1]), "inn steps", w["inn_times"].shape,
           "tdvp_error median/max", np.median(w["inn_tdvp_error"]), w["inn_tdvp_error"].max())

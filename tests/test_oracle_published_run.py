@@ -129,3 +129,59 @@ def test_oracle_follows_published_first_steps():
     assert 0.1 < np.median(err) / np.median(ref["tdvp_error"][:n_steps]) < 10 and err.max() < 5e-3
     # the frozen latent covariance stayed at the identity (A = 0 is a fixed point of the pseudo-inverse flow)
     assert float(y[list(frozen)].abs().max()) == 0.0
+
+
+def test_oracle_reproduces_published_student_t_step0():
+    """The published d = 8 Student-t diffusion run (nu = 2 initially; 393 = 320 + 8 + 64 + 1 parameters, same configuration as the
+    Gaussian run plus the shape parameter): step-0 record lambda_max 708.1, numerical rank 151, seven leading eigenvalues
+    637..708 and a gap behind them, solver residual 7.1e-7 (four orders of magnitude above the Gaussian run's: the heavy tails put
+    eigenvalues onto the soft cut-off), TDVP error 0.219."""
+    ref = np.load(os.path.join(GOLD, "published_diffusion_d8_student_t.npz"))
+    pub = np.sort(ref["ev_first"])[::-1]
+    assert pub.shape == (393,) and int((pub > 1e-9 * pub[0]).sum()) == 151
+    for seed in (1, 2):
+        ups, dns = O.random_partitions(DIM, DEPTH, seed)
+        spec = O.NetSpec(dim=DIM, inds_up=ups, inds_down=dns, intmediate=HIDDEN, offset=[0.0] * DIM, latentSpaceName="Student_t")
+        th = O.init_parameters(spec, seed)
+        names = [n for n, s in O.param_layout(spec) for _ in range(int(np.prod(s)))]
+        frozen = tuple(i for i, n in enumerate(names) if n in ("L", "L_diag"))
+        assert O.num_parameters(spec) - len(frozen) + DIM * DIM == 393
+        g = torch.Generator().manual_seed(seed)
+        chi2 = torch.from_numpy(np.random.default_rng(seed).chisquare(2.0, N))           # nu = exp(0) + 1 = 2 (net.py:32)
+        z = O.latent_from_normals(spec, th, torch.randn(N, DIM, generator=g, dtype=torch.float64), chi2)
+        to = O.TDVPOracle(frozen=frozen)
+        to.rhs(th, 0.0, O.VarStateOracle(spec, th), O.EvolutionEquationOracle(DIM, "diffusion"), z)
+        ev = spectrum_with_A_columns(to.ev.numpy(), len(frozen))
+        assert abs(int((ev > 1e-9 * ev[0]).sum()) - 151) <= 1                 # 150 / 151 for the two seeds
+        assert abs(ev[0] / pub[0] - 1) < 0.08                                  # 683 / 708 against 708.1
+        assert ev[6] > 600 and ev[7] < 0.8 * ev[6] and pub[6] > 600 and pub[7] < 0.8 * pub[6]       # seven, then the gap
+        assert 0.5 * ref["solver_res"][0] < float(to.solverResidual) < 2.0 * ref["solver_res"][0]  # 7.5e-7 / 6.9e-7 against 7.1e-7
+        assert abs(float(to.tdvp_error) - ref["tdvp_error"][0]) < 0.03                              # 0.209 / 0.213 against 0.219
+
+
+def test_oracle_reproduces_published_phase_space_spectrum():
+    """The published phase-space run of the flow (data_phaseSpace/INN: d = 6, 4 blocks x hidden (3,), different_add, latent
+    covariance L L^T as checked out -- main.py:43-58 "harmonicOsc: DifferentAdd ... L @ L.T" --, P = 411 with every parameter
+    active): the spectrum of S does not depend on the equation, so the unrecorded per-oscillator temperatures of that run do not
+    matter.  Numerical rank 171 at the first and the last step; six leading eigenvalues 940..1570, then a gap; residual 8.9e-11."""
+    ref = np.load(os.path.join(GOLD, "published_phase_space.npz"))
+    pub = np.sort(ref["inn_ev_first"])[::-1]
+    assert pub.shape == (411,) and int((pub > 1e-9 * pub[0]).sum()) == 171
+    assert int((np.sort(ref["inn_ev_last"])[::-1] > 1e-9 * ref["inn_ev_last"].max()).sum()) == 171
+    dim = 6
+    for seed in (1, 2):
+        ups, dns = O.random_partitions(dim, 4, seed)
+        spec = O.NetSpec(dim=dim, inds_up=ups, inds_down=dns, intmediate=(3,), offset=[1.0, 0.0, 1.0, 0.0, 1.0, 0.0],
+                         latentSpaceName="Gauss", different_add=True, no_add=False)
+        th = O.init_parameters(spec, seed)
+        assert O.num_parameters(spec) == 411
+        g = torch.Generator().manual_seed(seed)
+        z = O.latent_from_normals(spec, th, torch.randn(N, dim, generator=g, dtype=torch.float64))
+        to = O.TDVPOracle()
+        to.rhs(th, 0.0, O.VarStateOracle(spec, th), O.EvolutionEquationOracle(dim, "advection_hamiltonian_wDiss"), z)
+        ev = np.sort(to.ev.numpy())[::-1]
+        assert int((ev > 1e-9 * ev[0]).sum()) == 171                           # structural: exactly the published rank
+        assert abs(int((ev > 1e-11 * ev[0]).sum()) - int((pub > 1e-11 * pub[0]).sum())) <= 8
+        assert 0.7 < ev[0] / pub[0] < 1.4                                      # 1978 / 1893 against 1570 (three hidden units: wide spread)
+        assert ev[5] > 900 and ev[6] < 0.8 * ev[5] and pub[5] > 900 and pub[6] < 0.8 * pub[5]       # six, then the gap
+        assert 0.5 * ref["inn_solver_res"][:20].min() < float(to.solverResidual) < 2.0 * ref["inn_solver_res"][:20].max()
