@@ -1,6 +1,6 @@
 """GPU tests at BASELINE config 3 (P = 16 181, hidden (43,43)) and config 4's per-GPU shard (d = 6, hidden (19,19), P = 4155,
-32 768 samples): the code paths only large problems reach -- `chol_strip_kernel<32>` (P >~ 4350), the side-stream trailing
-update of the blocked Cholesky (P >~ 6000), the one-workgroup-per-CU flow geometry of the (43,43) net, the Gram kernel without
+32 768 samples): the code paths only large problems reach -- `chol_strip_kernel<32>` (P >~ 4350), the two-level (super-panel) schedule
+of the blocked Cholesky (P > 7040), the one-workgroup-per-CU flow geometry of the (43,43) net, the Gram kernel without
 sample splits.  Reference shapes: var_state.py:110-124; tdvp.py:36-94.
 
 Oracle comparisons run at sizes the CPU oracle finishes in seconds; the full-size runs are checked through size-independent
@@ -43,7 +43,7 @@ def _factor(A, P):
 
 @pytest.mark.parametrize("P", [4400, 6300, 16181])
 def test_cholesky_large_P_against_rocsolver(P):
-    # 4400: chol_strip_kernel<32>; 6300: first panels take the side-stream branch; 16181: BASELINE config 3
+    # 4400: chol_strip_kernel<32>; 6300: updates of more than 1024 tiles; 16181: BASELINE config 3 (super-panels of 8)
     A = _spd_gpu(P, P)
     Ap, Pp, ws, need, info = _factor(A, P)
     assert int(info.item()) == 0
@@ -63,8 +63,10 @@ def test_cholesky_large_P_against_rocsolver(P):
 
 @pytest.mark.parametrize("P", [300, 1000])
 def test_cholesky_side_stream_branch_on_small_matrices(P, monkeypatch):
-    # VMCPDE_CHOL_FUSED_MAX=1 sends every trailing update with more than one tile through the fork/join branch
-    # (chol_syrk_kernel on the caller's stream, the next diagonal block on the device's side stream)
+    # the round-1 schedule (32-wide diagonal block, VMCPDE_CHOL_DIAG16=0) is kept for A/B: VMCPDE_CHOL_FUSED_MAX=1 sends every
+    # trailing update with more than one tile through its fork/join branch (chol_syrk_kernel on the caller's stream, the next
+    # diagonal block on the device's side stream)
+    monkeypatch.setenv("VMCPDE_CHOL_DIAG16", "0")
     monkeypatch.setenv("VMCPDE_CHOL_FUSED_MAX", "1")
     rng = np.random.default_rng(P)
     Q, _ = np.linalg.qr(rng.standard_normal((P, P)))
@@ -76,7 +78,30 @@ def test_cholesky_side_stream_branch_on_small_matrices(P, monkeypatch):
     assert np.abs(L - Lref).max() < 1e-10 * np.abs(Lref).max()
     monkeypatch.delenv("VMCPDE_CHOL_FUSED_MAX")
     Ap2, *_ = _factor(torch.as_tensor(Amat).to(DEV), P)
-    assert torch.equal(Ap2[:P, :P].tril(), Ap[:P, :P].tril())       # both schedules do the same arithmetic
+    assert torch.equal(Ap2[:P, :P].tril(), Ap[:P, :P].tril())       # fused and forked launches do the same arithmetic
+
+
+@pytest.mark.parametrize("P,W", [(300, 2), (1000, 2), (1000, 3), (1000, 8), (1500, 4), (2049, 16)])
+def test_cholesky_super_panels_on_small_matrices(P, W, monkeypatch):
+    # the two-level schedule large matrices use (super-panels of W block columns: K = 128 W trailing updates, chunked strips,
+    # two tiles per workgroup), forced onto small ones; ragged last block, last super-panel shorter than W, W > number of panels
+    rng = np.random.default_rng(P + W)
+    Q, _ = np.linalg.qr(rng.standard_normal((P, P)))
+    Amat = (Q * np.logspace(0, -4, P)) @ Q.T
+    monkeypatch.setenv("VMCPDE_CHOL_SUPER", str(W))
+    Ap, Pp, ws, need, info = _factor(torch.as_tensor(Amat).to(DEV), P)
+    assert int(info.item()) == 0
+    L = np.tril(Ap.cpu().numpy()[:P, :P])
+    Lref = np.linalg.cholesky(Amat)
+    assert np.abs(L - Lref).max() < 1e-10 * np.abs(Lref).max()
+    v = rng.standard_normal(P)
+    u = torch.empty(P, dtype=torch.float64, device=DEV)
+    b = torch.as_tensor(Amat @ v).to(DEV)
+    nat.call("vmcpde_chol_solve", nat.ptr(Ap), Pp, P, nat.ptr(b), nat.ptr(u), nat.ptr(ws), need, nat.stream())
+    assert np.linalg.norm(u.cpu().numpy() - v) / np.linalg.norm(v) < 1e-7
+    monkeypatch.setenv("VMCPDE_CHOL_SUPER", "1")
+    Ap1, *_ = _factor(torch.as_tensor(Amat).to(DEV), P)
+    assert float((Ap1[:P, :P].tril() - Ap[:P, :P].tril()).abs().max()) < 1e-12 * np.abs(Lref).max()
 
 
 @pytest.mark.parametrize("P", [300, 1000, 4213])

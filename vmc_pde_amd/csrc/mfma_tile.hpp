@@ -385,10 +385,12 @@ constexpr int F32_BLOCK_STEPS = 4;
 template <int BKD, bool F32 = false>
 __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const double* __restrict__ A, int64_t lda, int rowA0,
                                                   const double* __restrict__ B, int64_t ldb, int rowB0, bool alias, int64_t k0,
-                                                  int64_t k1, double* __restrict__ lds) {
+                                                  int64_t k1, double* __restrict__ lds, int tid = -1) {
   using G = DmaGeom<BKD>;
   constexpr int DTB = G::DT;
-  const int t = threadIdx.x, lane = t & 63;
+  // tid: index of this thread among the 256 that form the tile (default threadIdx.x; workgroups that carry two tiles pass
+  // threadIdx.x & 255 and a private `lds` per tile -- both tiles must then run the same number of K steps, the barriers are shared)
+  const int t = (tid < 0) ? (int)threadIdx.x : tid, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), wr = wave >> 1, wc = wave & 1;
   const double* __restrict__ tA = A + (int64_t)rowA0 * lda;
   const double* __restrict__ tB = B + (int64_t)rowB0 * ldb;

@@ -19,8 +19,8 @@ constexpr int DP = NB + 1;      // LDS pitch of the diagonal block (odd: column 
 
 // acc -> C[row0.., col0..] (ldc), mode 0: C = acc, mode 1: C -= acc
 __device__ __forceinline__ void tile_store_global(const double4_t (&acc)[4][4], double* __restrict__ C, int64_t ldc, int rows, int cols,
-                                                  int mode) {
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
+                                                  int mode, int tid = -1) {
+  const int t = (tid < 0) ? (int)threadIdx.x : tid, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -37,6 +37,8 @@ __device__ __forceinline__ void tile_store_global(const double4_t (&acc)[4][4], 
 }
 
 constexpr int SB = 32;          // sub-block width inside a 128-wide panel
+constexpr int SUPER_MIN_BLOCKS = 56;    // from this many 128-wide panels on (P > 7040) the factorisation groups them into super-panels
+constexpr int SUPER_WIDTH = 8;          //   of this many: measured best of 1, 2, 4, 8, 16 at P = 8192, 12 288, 16 181 (tools/diag/chol_schedule_ab.sh)
 constexpr int FUSED_MAX_TILES = 1024;   // trailing-update size up to which the next diagonal block rides in the same launch
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -673,19 +675,30 @@ constexpr int SP = SK + 2;        // LDS pitch: 4r + 2k dwords mod 64 distinct o
 // SR = rows per strip workgroup: 16 while 8 strips per block row still fit one round of the 256 CUs (half the MFMA chain per
 // workgroup: 2.88 -> 2.67 ms for the whole factorisation at P = 4213), 32 beyond that (each workgroup re-reads the 128 KB B
 // operand, so twice the workgroups is a loss once they no longer run concurrently).
+// General form (two-level schedule, see vmcpde_cholesky): the strips cover the rows from c0 downwards; the contraction runs over
+// the columns kc0 .. kc0 + 128 * nchunk (nchunk = 1 in mode 0, up to the super-panel width in mode 1), 128 at a time; mode 0
+// overwrites the columns kc0.., mode 1 updates the block column c0.. (whose rows c0..c0+127 are also the B operand).
 template <int SR>
-__device__ __forceinline__ void strip_body(double* __restrict__ A, int64_t lda, int P, int k0, int mode, const double* __restrict__ Linv,
-                                           int strip, double* __restrict__ lds /* Bs[128][SP] then As[SR][SP] */) {
+__device__ __forceinline__ void strip_body(double* __restrict__ A, int64_t lda, int P, int kc0, int nchunk, int c0, int mode,
+                                           const double* __restrict__ Linv, int strip, double* __restrict__ lds /* Bs[128][SP] then As[SR][SP] */) {
   double* Bs = lds;
   double* As = lds + NB * SP;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int row0 = k0 + NB + strip * SR;                 // first row of this strip (a row below the panel)
-  const int c0 = k0 + NB;                                // first row of the B operand in mode 1
+  const int row0 = c0 + strip * SR;                      // first row of this strip (a row below the panel)
+  constexpr int NA = SR / 8, NI = SR / 16;
+  double4_t acc[NI][2];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const int lr = lane & 15, lk = lane >> 4;
+  for (int ch = 0; ch < nchunk; ++ch) {
+  const int k0 = kc0 + ch * NB;
+  if (ch) __syncthreads();                               // the previous chunk's fragment reads are done
   const double* __restrict__ Bsrc = mode ? (A + (int64_t)c0 * lda + k0) : Linv;
   const int64_t ldb = mode ? lda : NB;
   const double* __restrict__ Asrc = A + (int64_t)row0 * lda + k0;
   // ---- issue every load: per K-half 16 double2 of B (128 rows x 32 double2) and SR/8 of A (SR rows x 32 double2) per thread
-  constexpr int NA = SR / 8, NI = SR / 16;
   double2_t vb[2][16], va[2][NA];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -700,12 +713,6 @@ __device__ __forceinline__ void strip_body(double* __restrict__ A, int64_t lda, 
       va[h][q] = *reinterpret_cast<const double2_t*>(Asrc + (int64_t)r * lda + h * SK + kp);
     }
   }
-  double4_t acc[NI][2];
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (h) __syncthreads();
@@ -733,8 +740,9 @@ __device__ __forceinline__ void strip_body(double* __restrict__ A, int64_t lda, 
       }
     }
   }
+  }   // chunks
   // ---- epilogue: wave w owns columns 32w..32w+31 of the strip
-  double* __restrict__ C = A + (int64_t)row0 * lda + (mode ? c0 : k0);
+  double* __restrict__ C = A + (int64_t)row0 * lda + (mode ? c0 : kc0);
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -751,10 +759,10 @@ __device__ __forceinline__ void strip_body(double* __restrict__ A, int64_t lda, 
 }
 
 template <int SR>
-__global__ __launch_bounds__(256, 1) void chol_strip_kernel(double* __restrict__ A, int64_t lda, int P, int k0, int mode,
+__global__ __launch_bounds__(256, 1) void chol_strip_kernel(double* __restrict__ A, int64_t lda, int P, int kc0, int nchunk, int c0, int mode,
                                                             const double* __restrict__ Linv) {
   extern __shared__ double lds[];
-  strip_body<SR>(A, lda, P, k0, mode, Linv, (int)blockIdx.x, lds);
+  strip_body<SR>(A, lda, P, kc0, nchunk, c0, mode, Linv, (int)blockIdx.x, lds);
 }
 
 // Trailing update A22 -= L21 L21^T on the lower-triangle tiles (syrk, K = n): see chol_syrk_diag_kernel.
@@ -784,6 +792,22 @@ __device__ __forceinline__ void syrk_tile_at(double* __restrict__ A, int64_t lda
     for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
   tile_mainloop_dma<16>(acc, A + k0, lda, rowA0, A + k0, lda, rowB0, ti == tj, 0, n, lds);
   tile_store_global(acc, A + (int64_t)rowA0 * lda + rowB0, lda, rowsA, rowsB, 1);
+}
+
+// One 128 x 128 tile (block row bi >= block column bj of the whole matrix) of  A[bi][bj] -= A[bi][kc0 : kc0+K] A[bj][kc0 : kc0+K]^T,
+// by the 256 threads `tid` of a workgroup with their own 64 KB of LDS (two such tiles per 512-thread workgroup).
+__device__ __forceinline__ void syrk_tile_abs(double* __restrict__ A, int64_t lda, int P, int kc0, int K, int bi, int bj,
+                                              double* __restrict__ lds, int tid) {
+  const int rowA0 = bi * TILE, rowB0 = bj * TILE;
+  const int rowsA = (P - rowA0 < TILE) ? (P - rowA0) : TILE;
+  const int rowsB = (P - rowB0 < TILE) ? (P - rowB0) : TILE;
+  double4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  tile_mainloop_dma<16>(acc, A + kc0, lda, rowA0, A + kc0, lda, rowB0, bi == bj, 0, K, lds, tid);
+  tile_store_global(acc, A + (int64_t)rowA0 * lda + rowB0, lda, rowsA, rowsB, 1, tid);
 }
 
 // (ti, tj >= 1: in the multi-launch schedule the first block column belongs to chol_strip_kernel mode 1)
@@ -842,11 +866,11 @@ __global__ __launch_bounds__(256, 1) void chol_panel_kernel(double* __restrict__
   const int b = (int)blockIdx.x;
   if (b < S) {
     const int br = b / SPB;
-    strip_body<SR>(A, lda, P, k0, 0, Linv_k, b, lds);
+    strip_body<SR>(A, lda, P, k0, 1, k0 + NB, 0, Linv_k, b, lds);
     signal_count(count + br);
     if (br == 0) {
       wait_count(count, SPB, info);
-      strip_body<SR>(A, lda, P, k0, 1, Linv_k, b, lds);        // its rows of the next diagonal tile (B = L21's first block row)
+      strip_body<SR>(A, lda, P, k0, 1, k0 + NB, 1, Linv_k, b, lds);        // its rows of the next diagonal tile (B = L21's first block row)
       signal_count(count + nrem);
     }
     return;
@@ -879,17 +903,38 @@ __global__ __launch_bounds__(256) void chol_syrk_diag_kernel(double* __restrict_
   syrk_tile(A, lda, P, k0, n, blockIdx.x - 1);
 }
 
-// ... with the 16-wide schedule for the diagonal block: workgroups of 512 threads, of which the tile workgroups use the first 256
-// (waves that have ended do not take part in the workgroup barriers of the tile engine)
-__global__ __launch_bounds__(D16_THREADS) void chol_syrk_diag16_kernel(double* __restrict__ A, int64_t lda, int P, int k0, int n,
-                                                                       double* __restrict__ Linv_next, int* __restrict__ info) {
+// The update launch of the two-level schedule (vmcpde_cholesky): workgroup 0 factors the next diagonal block (first row k1), every
+// other workgroup of 512 threads carries TWO tiles (waves 0-3 and 4-7, 64 KB of LDS each, all tiles of a launch run the same K so
+// the shared barriers match) -- the occupancy of two 256-thread workgroups per CU under the diagonal block's 140 KB LDS size, so
+// the lookahead rides in the launch for every size.  tpw = tiles per workgroup: 1 while the tiles fit one round of the CUs that
+// way (a K = 128 tile keeps the matrix pipes of a CU busy for 15 us; two on one CU take 30 us next to the 35 us diagonal block).  Tiles: block columns [jlo, jhi) of the lower triangle, rows j .. nbk-1 of
+// column j, updated with the operand columns kc0 .. kc0+K.
+__global__ __launch_bounds__(D16_THREADS) void chol_update_diag16_kernel(double* __restrict__ A, int64_t lda, int P, int kc0, int K, int jlo,
+                                                                         int jhi, int nbk, int ntiles, int tpw, int k1,
+                                                                         double* __restrict__ Linv_next, int* __restrict__ info) {
   if (blockIdx.x == 0) {
-    const int k1 = k0 + n;
     chol_diag16_body<D16_THREADS>(A, lda, k1, (P - k1 < NB) ? (P - k1) : NB, Linv_next, info);
     return;
   }
-  if (threadIdx.x >= 256) return;
-  syrk_tile(A, lda, P, k0, n, blockIdx.x - 1);
+  extern __shared__ double lds[];
+  const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+  int idx = tpw * ((int)blockIdx.x - 1) + half;
+  if (half >= tpw || idx >= ntiles) return;      // (waves that have ended do not take part in the barriers)
+  int bi, bj;
+  if (jhi == nbk) {
+    int ti, tj;
+    tri_decode(idx, ti, tj);
+    bi = jlo + ti;
+    bj = jlo + tj;
+  } else {
+    bj = jlo;
+    while (idx >= nbk - bj) {
+      idx -= nbk - bj;
+      ++bj;
+    }
+    bi = bj + idx;
+  }
+  syrk_tile_abs(A, lda, P, kc0, K, bi, bj, lds + half * (int)(TILE_DMA_LDS_BYTES / sizeof(double)), (int)threadIdx.x & 255);
 }
 
 // Large trailing matrices: the update alone, two workgroups per CU; the next diagonal block is factored on a side stream.
@@ -1144,7 +1189,7 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
       VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_panel_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
       VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_panel_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
       VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_diag16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
-      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_syrk_diag16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_update_diag16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
       ctx->attr_chol = true;
     }
     if (ctx->side == nullptr) {
@@ -1154,7 +1199,9 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
     }
   }
   VMC_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), st));
-  // Lookahead: the diagonal block of panel k+1 only depends on the first block column of panel k's trailing update.
+  // Lookahead: the diagonal block of panel k+1 only depends on the first block column of panel k's trailing update, so it is
+  // factored next to the rest of that update.  Default: the two-level schedule below (16-wide diagonal block, every update launch
+  // carries the block as workgroup 0).  The round-1 schedule around the 32-wide diagonal block is kept for A/B (VMCPDE_CHOL_DIAG16=0):
   //  * up to FUSED_MAX_TILES tiles in the rest of that update: workgroup 0 of the same launch factors it
   //    (chol_syrk_diag_kernel) -- the update is short, the single-workgroup factorisation is the critical path;
   //  * more: the update is the critical path; it runs at two workgroups per CU on the caller's stream while the block is
@@ -1185,6 +1232,42 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
     const int n0 = (P < NB) ? P : NB;
     launch_diag(st, 0, n0, Linv);
   }
+  // Two-level schedule (default).  Panels are grouped into super-panels of W block columns.  Inside a super-panel panel k updates
+  // only the block columns up to the super-panel's end (column k+1 by the strips, the others by tiles with K = 128); when the
+  // super-panel is complete, everything to its right is updated ONCE with K = 128 W (the first of those block columns by the strips,
+  // which the next diagonal block waits for).  A K = 128 tile re-reads and re-writes its 128 KB of C for 4.2 MFLOP and runs at
+  // ~31 TFLOP/s (measured at P = 16 181, tools/diag/chol_large_prof.sh); K = 512 amortises that four times.  W = 1 is the
+  // one-level right-looking schedule.  Every update launch carries the next diagonal block as workgroup 0 (chol_update_diag16_kernel).
+  if (diag16 && !panel_mode) {
+    static_assert(2 * TILE_DMA_LDS_BYTES <= ((size_t)NB * DP + 4 * SB * 17 + 2 * SB) * sizeof(double), "two tiles per workgroup of the update launch");
+    int W = env_int("VMCPDE_CHOL_SUPER", 0);
+    if (W <= 0) W = (nb >= SUPER_MIN_BLOCKS) ? SUPER_WIDTH : 1;
+    for (int k = 0; k + 1 < nb; ++k) {
+      const int k0 = k * NB;
+      const int nrem = nb - (k + 1);                                  // block rows below the panel
+      const int s0 = (k / W) * W, s1 = (s0 + W < nb) ? (s0 + W) : nb; // the super-panel of k: block columns [s0, s1)
+      const bool last_of_super = (k + 1 == s1);
+      const int kc0 = last_of_super ? s0 * NB : k0;                   // operand columns of this panel's update
+      const int nchunk = last_of_super ? (k + 1 - s0) : 1;
+      const int c0 = k0 + NB;
+      const double* Lk = Linv + (int64_t)k * NB * NB;
+      if (8 * nrem <= 256) {
+        hipLaunchKernelGGL(chol_strip_kernel<16>, dim3(8 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 1, c0, 0, Lk);
+        hipLaunchKernelGGL(chol_strip_kernel<16>, dim3(8 * nrem), dim3(256), strip_lds, st, A, lda, P, kc0, nchunk, c0, 1, Lk);
+      } else {
+        hipLaunchKernelGGL(chol_strip_kernel<32>, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 1, c0, 0, Lk);
+        hipLaunchKernelGGL(chol_strip_kernel<32>, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, P, kc0, nchunk, c0, 1, Lk);
+      }
+      const int jlo = k + 2, jhi = last_of_super ? nb : s1;
+      int64_t ntiles = 0;
+      for (int j = jlo; j < jhi; ++j) ntiles += nb - j;
+      const int tpw = (ntiles <= 255) ? 1 : 2;
+      hipLaunchKernelGGL(chol_update_diag16_kernel, dim3(1u + (unsigned)((ntiles + tpw - 1) / tpw)), dim3(D16_THREADS), diag_lds, st, A, lda, P, kc0,
+                         nchunk * NB, jlo, jhi, nb, (int)ntiles, tpw, c0, Linv + (int64_t)(k + 1) * NB * NB, info);
+    }
+    VMC_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   for (int k = 0; k < nb; ++k) {
     const int k0 = k * NB;
     const int n = (P - k0 < NB) ? (P - k0) : NB;
@@ -1211,11 +1294,11 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
     }
     // n == NB here (a panel with rows below it is always full); row strips of 32 over the zero-padded row range
     if (8 * nrem <= 256) {
-      hipLaunchKernelGGL(chol_strip_kernel<16>, dim3(8 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 0, Linv + (int64_t)k * NB * NB);
-      hipLaunchKernelGGL(chol_strip_kernel<16>, dim3(8 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 1, Linv);
+      hipLaunchKernelGGL(chol_strip_kernel<16>, dim3(8 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 1, k0 + NB, 0, Linv + (int64_t)k * NB * NB);
+      hipLaunchKernelGGL(chol_strip_kernel<16>, dim3(8 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 1, k0 + NB, 1, Linv);
     } else {
-      hipLaunchKernelGGL(chol_strip_kernel<32>, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 0, Linv + (int64_t)k * NB * NB);
-      hipLaunchKernelGGL(chol_strip_kernel<32>, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 1, Linv);
+      hipLaunchKernelGGL(chol_strip_kernel<32>, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 1, k0 + NB, 0, Linv + (int64_t)k * NB * NB);
+      hipLaunchKernelGGL(chol_strip_kernel<32>, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 1, k0 + NB, 1, Linv);
     }
     double* Linv_next = Linv + (int64_t)(k + 1) * NB * NB;
     const int k1 = k0 + n;
@@ -1224,11 +1307,7 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
     if (tiles == 0) {
       launch_diag(st, k1, n1, Linv_next);
     } else if (tiles <= fused_max) {
-      if (diag16)
-        hipLaunchKernelGGL(chol_syrk_diag16_kernel, dim3(1u + (unsigned)tiles), dim3(D16_THREADS), diag_lds, st, A, lda, P, k0, n, Linv_next, info);
-      else
-        hipLaunchKernelGGL(chol_syrk_diag_kernel, dim3(1u + (unsigned)tiles), dim3(256), diag_lds, st, A, lda, P, k0, n, Linv_next, info,
-                           diag_phase);
+      hipLaunchKernelGGL(chol_syrk_diag_kernel, dim3(1u + (unsigned)tiles), dim3(256), diag_lds, st, A, lda, P, k0, n, Linv_next, info, diag_phase);
     } else {
       VMC_CHECK_HIP(hipEventRecord(ev_fork, st));
       VMC_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
