@@ -14,14 +14,15 @@ for r in csv.DictReader(open(st)):
     if float(r['Percentage']) > 0.5:
         print(f"{r['Name'][:70]:70s} calls {r['Calls']:>6s} total {float(r['TotalDurationNs'])/1e6:9.3f} ms avg {float(r['AverageNs'])/1e3:9.1f} us")
 tr = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(tr)) if 'chol_syrk' in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open(tr)) if 'chol_syrk' in r['Kernel_Name'] or 'chol_update' in r['Kernel_Name']]
 per = len(rows) // 4
 last = rows[-per:]
-print("trailing updates of the last factorisation: grid -> us, TFLOP/s (K = 128)")
-for r in last[::max(1, per // 16)]:
+print("update launches of the last factorisation (workgroups; duration)")
+big = sorted(last, key=lambda r: int(r['End_Timestamp']) - int(r['Start_Timestamp']))[-16:]
+for r in sorted(big, key=lambda r: int(r['Start_Timestamp'])):
     wg = int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']) if 'Grid_Size_X' in r else int(r['Grid_Size']) // int(r['Workgroup_Size'])
     us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    print(f"  {r['Kernel_Name'][:40]:40s} tiles {wg:6d}  {us:8.1f} us  {wg * 2 * 128**3 / us / 1e6:6.1f} TF")
+    print(f"  {r['Kernel_Name'][:40]:40s} workgroups {wg:6d}  {us:8.1f} us")
 t0 = int(last[0]['Start_Timestamp']); t1 = int(last[-1]['End_Timestamp'])
 print("span of the updates", (t1 - t0) / 1e6, "ms; sum of their durations", sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in last) / 1e6, "ms")
 PY
