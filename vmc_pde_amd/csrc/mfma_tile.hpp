@@ -369,7 +369,12 @@ __device__ __forceinline__ void flush_f32_blocks(double4_t (&acc)[4][4], float4_
 // One K step of this wave's quadrant.  On a diagonal tile (alias) the quadrant above the diagonal is skipped (a quarter of
 // the tile's MFMAs; the freed matrix-pipe slots go to the co-resident workgroups' waves).  Also forming only the lower
 // 16 x 16 blocks of the two quadrants ON the diagonal needs a second copy of the K step, and with two copies hipcc spills
-// ~190 VGPRs around the 128 accumulator registers -- measured 2x slower, so it is not done.
+// ~190 VGPRs around the 128 accumulator registers -- measured 2x slower, so it is not done.  Round 2 tried the balanced split
+// twice more (10 / 8 / 8 / 10 lower blocks per wave instead of 16 / 0 / 16 / 16): (a) one loop with a wave-uniform block mask
+// and a scalar branch around each MFMA -- the whole Gram 12 % SLOWER (17.25 -> 19.4 ms; the branches break the interleave of
+// fragment reads and MFMAs); (b) a separate branch-free loop per wave role for diagonal tiles (no spills, 175 VGPRs) -- no
+// change at P = 4213 / 4155 (17.17 vs 17.18 ms, 8.68 vs 8.68 ms, alternating runs on one box) and 4 % slower at P = 16 181
+// (259.9 vs 249.8 ms).  Freed matrix-pipe slots do not turn into time on this chip: the fp64 MFMA rate is power-managed.
 template <int BKD>
 __device__ __forceinline__ void mma_kstep_sym(double4_t (&acc)[4][4], const double* __restrict__ lds, int offAs, int offBs, int wr, int wc,
                                               const int (&koff)[BKD / 4], bool alias) {
