@@ -153,6 +153,11 @@ def test_exact_sampler_statistics(latent):
     # successive calls use fresh streams; same key + same call index reproduces
     z2 = vs.sampler(1000, dist)[0]
     assert not torch.equal(z2.cpu(), z[:1000])
+    # sampler.py:86 adds the SAMPLER's offset (mcmc_info), which a caller may choose different from the network's
+    import vmc_pde_amd as V
+    s2 = V.Sampler(key=1, dim=3, name=latent, mcmc_info={"offset": np.asarray(spec.offset) + np.array([0.5, -1.0, 2.0]), "bound": 0.25})
+    za, zb = s2(1000, dist)[0].cpu(), V.Sampler(key=1, dim=3, name=latent, mcmc_info={"offset": np.asarray(spec.offset), "bound": 0.25})(1000, dist)[0].cpu()
+    assert float((za - zb - torch.tensor([0.5, -1.0, 2.0], dtype=torch.float64)).abs().max()) < 1e-14
 
 
 def test_sample_sharding_is_world_size_invariant():

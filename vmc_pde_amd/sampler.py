@@ -57,7 +57,9 @@ class Sampler:
     def __call__(self, numSamples, dist_params, multipleOf=1):
         """sampler.py:72-86.  Returns latent samples (1, n_local, dim), already shifted by mcmc_info["offset"]."""
         stream_id = self._next_stream()
-        offset = torch.as_tensor(np.asarray(self.mcmc_info["offset"], dtype=np.float64), device=self.device)
+        # (the offset stays on the host until a branch needs it on the device: an upload from pageable memory is a blocking copy,
+        # i.e. a host synchronisation per call, and the native exact sampler reads the offset from the model descriptor)
+        offset_host = np.asarray(self.mcmc_info["offset"], dtype=np.float64).reshape(-1)
         if not self.exact_samples:
             if self.states is None:
                 self.mc_init()
@@ -67,7 +69,7 @@ class Sampler:
             states = self.states[0].clone().contiguous()   # the reference never writes self.states back
             out = torch.empty((steps * chains, 2), dtype=global_defs.tReal, device=self.device)
             n_acc = torch.zeros(1, dtype=torch.int64, device=self.device)
-            off2 = (C.c_double * 2)(float(offset[0]), float(offset[1]))
+            off2 = (C.c_double * 2)(float(offset_host[0]), float(offset_host[1]))
             with torch.cuda.device(self.device):
                 nat.call("vmcpde_mcmc", self.key, stream_id + (mpi_wrapper.get_rank() << 20), chains, steps,
                          float(self.mcmc_info["bound"]), off2, nat.ptr(states), nat.ptr(out), nat.ptr(n_acc), nat.stream())
@@ -82,6 +84,11 @@ class Sampler:
             with torch.cuda.device(self.device):
                 nat.call("vmcpde_sample_latent", model.handle, nat.ptr(theta), self.key, stream_id, first, n_local, nat.ptr(z),
                          nat.stream())
+            # the kernel adds the NETWORK's offset (one descriptor); sampler.py:86 adds mcmc_info["offset"] -- the same vector in
+            # the reference's driver (main.py:69-73); if a caller makes them differ, the difference is added here
+            d_off = offset_host - np.asarray(model.offset, dtype=np.float64).reshape(-1)
+            if np.any(d_off != 0.0):
+                z += torch.as_tensor(d_off, device=self.device)
             return z[None, ...]
         # generic (S, mu) given by the caller: small torch ops, same law (sampler.py:26,33-34)
         g = torch.Generator(device=self.device).manual_seed(self.key * 1000003 + stream_id * 4099 + mpi_wrapper.get_rank())
@@ -93,4 +100,4 @@ class Sampler:
             nu = float(torch.exp(dist_params["dist_params"][0]) + 1.0)
             u = torch.distributions.Chi2(torch.tensor(nu, dtype=global_defs.tReal)).sample((n_local,)).to(self.device)
             z = torch.sqrt(nu / u)[:, None] * y + mu
-        return (z + offset)[None, ...]
+        return (z + torch.as_tensor(offset_host, device=self.device))[None, ...]
