@@ -189,6 +189,14 @@ int vmcpde_tdvp_moments(const double* packed, int32_t P, int32_t bordered, doubl
 int vmcpde_tdvp_diagnostics(const double* u, const double* S0u, const double* F, const double* diagS, int32_t P, double diagonal_shift,
                             const double* floor_dev, const double* scal, const int32_t* info, double* out, void* stream);
 
+/* tdvp.py:143-150, the observables of one sample set x[n][dim] (row-major, dim <= 16) in two launches:
+ *   out = mean[dim] (x1) | covar[dim*dim] (1/n, about the mean) | x3[dim] x4[dim] x5[dim] x6[dim] (central moments) |
+ *         entropy = -mean(logp) | max(eloc)          ([dev] dim*dim + 5*dim + 2; logp / eloc NULL: 0 / -inf)
+ * workspace: vmcpde_observables_workspace_bytes(), zero-initialised once by the caller (the kernels leave it zeroed). */
+int64_t vmcpde_observables_workspace_bytes(void);
+int vmcpde_observables(const double* x, int64_t n_samples, int32_t dim, const double* logp, const double* eloc, double* out,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- mpi_wrapper.py:129-163 (global_sum) ---------------------------------------------------------------------- */
 /* The single collective of a TDVP step: packed[0..count) <- sum over the ranks of `comm`, in place, fp64, on `stream`
  * (ncclAllReduce of RCCL over xGMI; replaces the reference's pmap psum + host-buffer MPI.Allreduce, ten calls per step).

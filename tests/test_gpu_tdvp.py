@@ -431,3 +431,28 @@ def test_fp32_block_gram_refuses_small_shift_with_cholesky():
     upd_w, _ = tw(th.cuda(), 0.2, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None)
     assert torch.isfinite(upd).all() and int(tp.cholInfo.item()) == int(tw.cholInfo.item())
     assert float(torch.linalg.norm(tw.S0 @ (upd - upd_w)) / torch.linalg.norm(tw.F0)) < 1e-3
+
+
+@pytest.mark.parametrize("n,d", [(1, 2), (70, 3), (1024, 2), (10000, 6), (65536, 2), (4099, 16)])
+def test_observables_kernel_against_numpy(n, d):
+    # tdvp.py:143-150 through the C ABI: mean, covariance (1/n), central moments 3-6, entropy, max Eloc
+    from vmc_pde_amd import _native as nat
+    rng = np.random.default_rng(n + d)
+    x = rng.standard_normal((n, d)) * rng.uniform(0.5, 2.0, d) + rng.uniform(-3, 3, d)
+    lp, el = rng.standard_normal(n), rng.standard_normal(n) * 10
+    dev = torch.device("cuda", 0)
+    xd, lpd, eld = (torch.as_tensor(a).to(dev) for a in (x, lp, el))
+    ws = torch.zeros(nat.lib().vmcpde_observables_workspace_bytes() // 8, dtype=torch.float64, device=dev)
+    out = torch.full((d * d + 5 * d + 2,), float("nan"), dtype=torch.float64, device=dev)
+    for _ in range(2):      # twice: the workspace counter must be left at zero
+        nat.call("vmcpde_observables", nat.ptr(xd), n, d, nat.ptr(lpd), nat.ptr(eld), nat.ptr(out), nat.ptr(ws), ws.numel() * 8, nat.stream())
+    o = out.cpu().numpy()
+    m = x.mean(0)
+    X = x - m
+    assert np.allclose(o[:d], m, rtol=1e-13, atol=1e-13)
+    assert np.allclose(o[d:d + d * d].reshape(d, d), X.T @ X / n, rtol=1e-12, atol=1e-13)
+    for k, pw in enumerate([3, 4, 5, 6]):
+        ref = (X ** pw).mean(0)
+        assert np.allclose(o[d + d * d + k * d:d + d * d + (k + 1) * d], ref, rtol=1e-11, atol=1e-11 * np.abs(ref).max()), pw
+    assert abs(o[d * d + 5 * d] + lp.mean()) < 1e-13 and o[d * d + 5 * d + 1] == el.max()
+    assert float(ws.abs().max()) == 0.0 or int(ws[-2:].view(torch.int64)[0]) == 0

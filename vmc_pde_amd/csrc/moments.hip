@@ -166,6 +166,103 @@ __global__ __launch_bounds__(1024) void tdvp_diagnostics_kernel(const double* __
   }
 }
 
+
+// ---- observables of a sample set (tdvp.py:143-150) in two launches -----------------------------------------------------------
+// phase 0: sum x_j, sum log p, max Eloc  ->  out: mean[d], entropy, max;   phase 1: central sums about that mean ->  covariance
+// (1/n), central moments 3..6.  A workgroup stages OBS_CHUNK samples in LDS and thread q accumulates quantity q over them (at
+// most OBS_QMAX quantities, two per thread); block partials go to ws[block][OBS_QMAX] and the last block to arrive adds them in
+// block order (deterministic), as in tdvp_prepare_kernel.  The reference runs ~40 eager array ops here; in torch they were 0.4 ms
+// of launches per call, a quarter of a step of the reference's own problem sizes.
+constexpr int OBS_DMAX = 16, OBS_CHUNK = 256, OBS_THREADS = 256, OBS_BLOCKS_MAX = 64;
+constexpr int OBS_QMAX = OBS_DMAX * OBS_DMAX + 4 * OBS_DMAX;            // 320
+
+template <int PHASE>
+__global__ __launch_bounds__(OBS_THREADS) void observables_kernel(const double* __restrict__ x, int64_t n, int d, const double* __restrict__ logp,
+                                                                  const double* __restrict__ eloc, double* __restrict__ out, double* __restrict__ ws) {
+  __shared__ double xs[OBS_CHUNK * (OBS_DMAX + 2)];     // per sample: d coordinates (centred in phase 1), then log p, Eloc (phase 0)
+  __shared__ double mean[OBS_DMAX];
+  __shared__ bool last;
+  const int t = threadIdx.x, nb = gridDim.x;
+  const int w = d + (PHASE == 0 ? 2 : 0);                // doubles per staged sample
+  const int nq = (PHASE == 0) ? d + 2 : d * d + 4 * d;
+  if (PHASE == 1) {
+    if (t < d) mean[t] = out[t];
+    __syncthreads();
+  }
+  const int64_t per = (n + nb - 1) / nb;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < n) ? (lo + per) : n;
+  double acc[2] = {0.0, 0.0};
+  if (PHASE == 0) { if (t == d + 1) acc[0] = -INFINITY; if (t + OBS_THREADS == d + 1) acc[1] = -INFINITY; }
+  for (int64_t c0 = lo; c0 < hi; c0 += OBS_CHUNK) {
+    const int m = (int)((hi - c0 < OBS_CHUNK) ? (hi - c0) : OBS_CHUNK);
+    for (int e = t; e < m * d; e += OBS_THREADS) {
+      const int sidx = e / d, j = e - sidx * d;
+      const double v = x[c0 * d + e];
+      xs[sidx * w + j] = (PHASE == 1) ? v - mean[j] : v;
+    }
+    if (PHASE == 0)
+      for (int sidx = t; sidx < m; sidx += OBS_THREADS) {
+        xs[sidx * w + d] = logp ? logp[c0 + sidx] : 0.0;
+        xs[sidx * w + d + 1] = eloc ? eloc[c0 + sidx] : -INFINITY;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int q = t + k * OBS_THREADS;
+      if (q >= nq) break;
+      double a = acc[k];
+      if (PHASE == 0) {
+        if (q == d + 1) for (int sidx = 0; sidx < m; ++sidx) a = fmax(a, xs[sidx * w + q]);
+        else for (int sidx = 0; sidx < m; ++sidx) a += xs[sidx * w + q];
+      } else if (q < d * d) {
+        const int i = q / d, j = q - i * d;
+        for (int sidx = 0; sidx < m; ++sidx) a = fma(xs[sidx * w + i], xs[sidx * w + j], a);
+      } else {
+        const int pw = 3 + (q - d * d) / d, j = (q - d * d) % d;
+        for (int sidx = 0; sidx < m; ++sidx) {
+          const double v = xs[sidx * w + j], v2 = v * v;
+          a += (pw == 3) ? v2 * v : (pw == 4) ? v2 * v2 : (pw == 5) ? v2 * v2 * v : v2 * v2 * v2;
+        }
+      }
+      acc[k] = a;
+    }
+    __syncthreads();
+  }
+  unsigned int* counter = reinterpret_cast<unsigned int*>(ws + (int64_t)OBS_BLOCKS_MAX * OBS_QMAX);
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (t + k * OBS_THREADS < nq) ws[(int64_t)blockIdx.x * OBS_QMAX + t + k * OBS_THREADS] = acc[k];
+  __syncthreads();
+  if (t == 0) {
+    __threadfence();
+    last = (atomicAdd(counter, 1u) == (unsigned int)(nb - 1));
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  const double inv_n = 1.0 / (double)n;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int q = t + k * OBS_THREADS;
+    if (q >= nq) break;
+    const bool is_max = (PHASE == 0 && q == d + 1);
+    double a = is_max ? -INFINITY : 0.0;
+    for (int b = 0; b < nb; ++b) {
+      const double v = const_cast<const volatile double*>(ws)[(int64_t)b * OBS_QMAX + q];
+      a = is_max ? fmax(a, v) : a + v;
+    }
+    // layout of out: mean[d] | covar[d*d] | x3[d] x4[d] x5[d] x6[d] | entropy | max Eloc
+    if (PHASE == 0) {
+      if (q < d) out[q] = a * inv_n;
+      else if (q == d) out[d + d * d + 4 * d] = -a * inv_n;            // tdvp.py:148
+      else out[d + d * d + 4 * d + 1] = a;                             // tdvp.py:150
+    } else {
+      out[d + q] = a * inv_n;
+    }
+  }
+  if (t == 0) *counter = 0u;
+}
+
 }  // namespace
 
 extern "C" int64_t vmcpde_tdvp_prepare_workspace_bytes(void) { return (int64_t)(4 * PREP_BLOCKS_MAX + 2) * (int64_t)sizeof(double); }
@@ -203,6 +300,24 @@ extern "C" int vmcpde_tdvp_diagnostics(const double* u, const double* S0u, const
   VMC_REQUIRE(u && S0u && F && diagS && scal && out && P >= 1, "vmcpde_tdvp_diagnostics: bad argument");
   hipLaunchKernelGGL(tdvp_diagnostics_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, u, S0u, F, diagS, P, diagonal_shift, floor_dev,
                      scal, info, out);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int64_t vmcpde_observables_workspace_bytes(void) { return ((int64_t)OBS_BLOCKS_MAX * OBS_QMAX + 2) * (int64_t)sizeof(double); }
+
+extern "C" int vmcpde_observables(const double* x, int64_t n_samples, int32_t dim, const double* logp, const double* eloc, double* out,
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
+  VMC_REQUIRE(x && out && workspace, "vmcpde_observables: null argument");
+  VMC_REQUIRE(n_samples >= 1, "empty sample set");
+  VMC_REQUIRE(dim >= 1 && dim <= OBS_DMAX, "vmcpde_observables: 1 <= dim <= 16");
+  VMC_REQUIRE(workspace_bytes >= vmcpde_observables_workspace_bytes(), "observables workspace too small");
+  int blocks = (int)((n_samples + 4 * OBS_CHUNK - 1) / (4 * OBS_CHUNK));
+  if (blocks > OBS_BLOCKS_MAX) blocks = OBS_BLOCKS_MAX;
+  hipLaunchKernelGGL(observables_kernel<0>, dim3(blocks), dim3(OBS_THREADS), 0, (hipStream_t)stream, x, n_samples, dim, logp, eloc, out,
+                     static_cast<double*>(workspace));
+  hipLaunchKernelGGL(observables_kernel<1>, dim3(blocks), dim3(OBS_THREADS), 0, (hipStream_t)stream, x, n_samples, dim, logp, eloc, out,
+                     static_cast<double*>(workspace));
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -420,6 +420,51 @@ class TDVP:
                 self._record_guard(out)
         return update, out[0], out[1]
 
+    # ---- tdvp.py:143-162 -----------------------------------------------------------------------------------------
+    def _observables(self, sampleConfigs, logProbs, Eloc):
+        """mean, covariance (1/n), entropy, central moments 3-6 of the samples and the largest Eloc: `vmcpde_observables` (two
+        launches) for fp64 samples on the device, the reference's array expressions otherwise."""
+        d = sampleConfigs.shape[-1]
+        x = sampleConfigs.reshape(-1, d)
+        info = {}
+        if x.is_cuda and x.dtype == global_defs.tReal and d <= 16 and x.shape[0] >= 1:
+            x = x.contiguous()
+            lp, el = logProbs.reshape(-1).contiguous(), Eloc.reshape(-1).contiguous()
+            ws = getattr(self, "_obs_ws", None)
+            if ws is None or ws.device != x.device:
+                ws = self._obs_ws = torch.zeros(nat.lib().vmcpde_observables_workspace_bytes() // 8, dtype=global_defs.tReal, device=x.device)
+            out = torch.empty(d * d + 5 * d + 2, dtype=global_defs.tReal, device=x.device)
+            with torch.cuda.device(x.device):
+                nat.call("vmcpde_observables", nat.ptr(x), x.shape[0], d, nat.ptr(lp), nat.ptr(el), nat.ptr(out), nat.ptr(ws), ws.numel() * 8,
+                         nat.stream())
+            info["x1"] = out[:d]
+            info["covar"] = out[d:d + d * d].reshape(d, d)
+            info["entropy"] = out[d * d + 5 * d]
+            for k, m in enumerate([3, 4, 5, 6]):
+                info[f"x{m}"] = out[d + d * d + k * d:d + d * d + (k + 1) * d]
+            info["max_grad"] = out[d * d + 5 * d + 1]
+            return info
+        mean = sampleConfigs.mean(dim=(0, 1), keepdim=True)
+        info["x1"] = mean[0, 0]
+        X = sampleConfigs[0] - mean[0]
+        # (a mean of outer products, not `X.T @ X`: for a d x N by N x d product rocBLAS runs one 128 x 128 macro tile over all N
+        # samples -- 6.9 ms at N = 65 536, a third of a TDVP step; tools/diag/observables_prof.sh)
+        info["covar"] = (X[:, :, None] * X[:, None, :]).mean(dim=0)
+        info["entropy"] = -logProbs.mean()
+        for m in [3, 4, 5, 6]:
+            info[f"x{m}"] = ((sampleConfigs - mean) ** m).mean(dim=(0, 1))
+        info["max_grad"] = Eloc.max()
+        return info
+
+    def _ball_samples(self, psi, n, dim):
+        """Uniform points in the unit ball for the small-ball integrals (tdvp.py:152-157).  The reference draws them from
+        `sampler.key`, which every sampler call advances (sampler.py:73): fresh points per call, here from the sampler's key and
+        call count."""
+        g = torch.Generator(device=psi.device).manual_seed(int(psi.sampler.key) + 104729 + 7919 * int(getattr(psi.sampler, "_calls", 0)))
+        samples = torch.randn((1, n, dim), generator=g, dtype=global_defs.tReal, device=psi.device)
+        radius = torch.rand((1, n), generator=g, dtype=global_defs.tReal, device=psi.device)
+        return samples / torch.linalg.norm(samples, dim=-1, keepdim=True) * radius[..., None] ** (1 / dim)
+
     # ---- tdvp.py:96-164 ------------------------------------------------------------------------------------------
     def __call__(self, netParameters, t, psi, evolutionEq, **rhsArgs):
         nSamplesTDVP = rhsArgs["nSamplesTDVP"]
@@ -464,22 +509,11 @@ class TDVP:
             print(self.F0)
             raise FloatingPointError("nan encountered in the TDVP update")
 
-        info = {}                                                             # tdvp.py:143-150
-        mean = sampleConfigs.mean(dim=(0, 1), keepdim=True)
-        info["x1"] = mean[0, 0]
-        X = sampleConfigs[0] - mean[0]
-        info["covar"] = X.T @ X / X.shape[0]
-        info["entropy"] = -logProbs.mean()
-        for m in [3, 4, 5, 6]:
-            info[f"x{m}"] = ((sampleConfigs - mean) ** m).mean(dim=(0, 1))
-        info["max_grad"] = Eloc.max()
+        info = self._observables(sampleConfigs, logProbs, Eloc)               # tdvp.py:143-150
 
         if rhsArgs.get("integrals", True) is not None:                        # tdvp.py:152-162: always evaluated by the reference
             dim = sampleConfigs.shape[-1]
-            g = torch.Generator(device=psi.device).manual_seed(int(psi.sampler.key) + 104729)
-            samples = torch.randn((1, nSamplesObs, dim), generator=g, dtype=global_defs.tReal, device=psi.device)
-            radius = torch.rand((1, nSamplesObs), generator=g, dtype=global_defs.tReal, device=psi.device)
-            samples = samples / torch.linalg.norm(samples, dim=-1, keepdim=True) * radius[..., None] ** (1 / dim)
+            samples = self._ball_samples(psi, nSamplesObs, dim)
             for lim_normal in [1, 0.5, 0.1]:
                 T = 10
                 lim = lim_normal * math.sqrt(T)
