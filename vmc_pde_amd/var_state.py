@@ -30,18 +30,22 @@ class _LatentParams(dict):
     built when a sampler actually reads it: the native sampler rebuilds the factor on the device from the flat parameter vector
     (csrc/flow.hip::latent_prepare_kernel) and never does -- ten tiny launches per TDVP call otherwise."""
 
-    def __init__(self, p, dim, model, theta):
-        super().__init__(mu=p["mu"], dist_params=p["dist_params"], _model=model, _theta=theta)
-        self._p, self._dim = p, dim
+    def __init__(self, owner, dim, model, theta):
+        super().__init__(_model=model, _theta=theta)
+        self._owner, self._dim = owner, dim
 
     def __missing__(self, key):
+        p = self._owner.params["params"]          # (builds the parameter tree: only the generic sampler path comes here)
         if key == "S":
-            self["S"] = util.build_cov_matrix(self._p["L"], self._p["L_diag"], self._dim)
+            self["S"] = util.build_cov_matrix(p["L"], p["L_diag"], self._dim)
             return self["S"]
+        if key in ("mu", "dist_params"):
+            self[key] = p[key]
+            return self[key]
         raise KeyError(key)
 
     def __contains__(self, key):
-        return key == "S" or super().__contains__(key)
+        return key in ("S", "mu", "dist_params") or super().__contains__(key)
 
 
 class VarState:
@@ -60,7 +64,7 @@ class VarState:
         self.net, self._theta = self.init_net(network_args, *args, inds_up=inds_up, inds_down=inds_down)
         self.numParameters = self.net.numParameters                       # var_state.py:27
         self.paramShapes = [(int(np.prod(s)), tuple(s)) for _, _, s in self.net.layout]   # var_state.py:25
-        self.params = self.net.tree_from_flat(self._theta)
+        self._params = None                                               # the nested dict of views, built on first access
         self._ws = {}
         self._dirs_cache = {}
 
@@ -181,8 +185,7 @@ class VarState:
 
     def sample(self, numSamples):
         """var_state.py:76-79: latent samples -> inverse flow -> (x (1,n,d), logp (1,n))."""
-        p = self.params["params"]
-        dist_params = _LatentParams(p, self.dim, self.net, self._theta)
+        dist_params = _LatentParams(self, self.dim, self.net, self._theta)
         z = self.sampler(numSamples, dist_params)
         return self.flow_sample(z)
 
@@ -200,7 +203,21 @@ class VarState:
     def set_parameters(self, p_new):
         self._theta = torch.as_tensor(p_new, dtype=global_defs.tReal, device=self.device).reshape(-1).clone()
         assert self._theta.numel() == self.numParameters
-        self.params = self.net.tree_from_flat(self._theta)
+        self._params = None
+
+    @property
+    def params(self):
+        """var_state.py:94-101: the nested {"params": {...}} dict of views into the flat vector (read by main.py:178,190 and
+        passed to net.apply by main.py:81-95).  Built on first access after set_parameters -- ~70 view objects, 0.2 ms of host
+        time that a TDVP call itself never needs."""
+        if self._params is None:
+            self._params = self.net.tree_from_flat(self._theta)
+        return self._params
+
+    @params.setter
+    def params(self, tree):
+        self._theta = self.net.flat_from_tree(tree).clone()
+        self._params = None
 
     def get_parameters(self):
         return self._theta.clone()
