@@ -16,7 +16,7 @@ res = {"source": "tools/profile_round.sh: rocprofv3 --kernel-trace --stats (benc
 stats = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
-HOT = ("gram_dma_kernel", "gram_f32_kernel", "gram_kernel", "row_moments_kernel", "flow_eval_kernel", "chol_diag_kernel", "chol_syrk_diag_kernel",
+HOT = ("gram_dma_kernel", "gram_f32_kernel", "gram_kernel", "row_moments_kernel", "flow_eval_kernel", "chol_diag_kernel", "chol_syrk_diag_kernel", "chol_update_diag16_kernel", "chol_strip_kernel",
        "reduce_splits_kernel", "solve_bwd_persistent", "finalize_S_kernel")
 acc = defaultdict(lambda: defaultdict(list))
 dur = defaultdict(lambda: defaultdict(list))
