@@ -227,6 +227,34 @@ def test_tdvp_rhs_parity_config4_net():
     assert float(torch.linalg.norm(upd_p.cpu() - exact) / torch.linalg.norm(exact)) < 1e-8
 
 
+def test_spectral_solve_on_device_by_default_at_config4_width():
+    """solver="eigh" (the reference's pseudo-inverse, tdvp.py:57-94) at P = 4155: diagonalizeOnDevice=None picks rocSOLVER from
+    640 parameters on; host LAPACK (the reference's default) must give the same update, and both the oracle's."""
+    import warnings
+    import vmc_pde_amd as V
+    from oracle import vmc_oracle as O
+    from helpers import make_spec, random_theta, make_varstate, FixedSampler
+    dim, N, eq = 6, 1024, "advection_hamiltonian_wDiss"
+    spec = make_spec(dim, 4, (19, 19), offset=np.linspace(0.4, -0.3, dim), seed=3)
+    th = random_theta(spec, 3, out_scale=0.03)
+    g = torch.Generator().manual_seed(4)
+    z = O.latent_from_normals(spec, th, torch.randn(N, dim, generator=g, dtype=torch.float64))
+    eo, ep = O.EvolutionEquationOracle(dim, eq), V.EvolutionEquation(dim=dim, name=eq)
+    to = O.TDVPOracle(svdTol=1e-8)
+    upd_o, _ = to.rhs(th, 0.1, O.VarStateOracle(spec, th), eo, z)
+    nF = torch.linalg.norm(to.F0)
+    ups = {}
+    for where in (None, False):
+        vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()))
+        tp = V.TDVP(svdTol=1e-8, diagonalizeOnDevice=where)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)       # (a non-converged rocSOLVER call falls back to the host)
+            ups[where], _ = tp(th.cuda(), 0.1, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+        assert tp.ev is not None and tp.ev.numel() == vs.numParameters
+        assert float(torch.linalg.norm(to.S0 @ (ups[where].cpu() - upd_o)) / nF) < 1e-9
+    assert float(torch.linalg.norm(to.S0 @ (ups[None] - ups[False]).cpu()) / nF) < 1e-9
+
+
 def _full_size_call(dim, hidden, N, eq, lam):
     import vmc_pde_amd as V
     ups = [[int(v) for v in np.random.default_rng(b).permutation(dim)[: dim // 2]] for b in range(4)]

@@ -43,6 +43,9 @@ def _lapack_threads(P):
     return threadpool_limits(limits=1 if P < 600 else (8 if P < 2000 else 16))
 
 
+DEVICE_EIGH_MIN_P = 640     # diagonalizeOnDevice=None: rocSOLVER's syevd overtakes thread-capped host LAPACK between P = 411 and 1024
+
+
 def _round_up(v, m):
     return (v + m - 1) // m * m
 
@@ -53,7 +56,11 @@ class TDVP:
     snrTol: float = 2e0
     svdTol: float = 1e-11
     diagonalShift: float = 0
-    diagonalizeOnDevice: bool = False
+    diagonalizeOnDevice: object = None   # tdvp.py:24,59-64.  False: host LAPACK (the reference's default), True: rocSOLVER on the device,
+                                  # None (default here): by size -- host below DEVICE_EIGH_MIN_P parameters, device from there on
+                                  # (P = 411: 5.2 ms host / 8.2 ms device; P = 1024: 57 / 22 ms; P = 4213: 864 / 147 ms;
+                                  # tools/microbench/eigh_variants.py).  Same decomposition either way; if rocSOLVER does not
+                                  # converge on a singular S the call falls back to the host with a warning.
     solver: str = "auto"          # "eigh": the reference's spectral pseudo-inverse (tdvp.py:57-94) -- what "auto" selects, so that the
                                   #   reference's constructor arguments solve the reference's system and publish ev / V / snr;
                                   # "cholesky": explicit opt-in to the on-device regularised Cholesky (no eigenbasis, hence no SNR)
@@ -355,7 +362,8 @@ class TDVP:
     def transform_to_eigenbasis(self, S, F, EOdata=None):
         P = F.numel()
         done = False
-        if self.diagonalizeOnDevice:
+        on_device = (P >= DEVICE_EIGH_MIN_P) if self.diagonalizeOnDevice is None else bool(self.diagonalizeOnDevice)
+        if on_device:
             try:
                 self.ev, self.V = torch.linalg.eigh(S)                        # tdvp.py:59 (rocSOLVER)
                 done = True
