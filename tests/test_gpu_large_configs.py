@@ -227,6 +227,32 @@ def test_tdvp_rhs_parity_config4_net():
     assert float(torch.linalg.norm(upd_p.cpu() - exact) / torch.linalg.norm(exact)) < 1e-8
 
 
+@pytest.mark.parametrize("dim,hidden,N", [(2, (21, 21), 65536), (2, (43, 43), 65536), (6, (19, 19), 32768)])
+def test_flow_round_trip_at_full_size(dim, hidden, N):
+    """Size-independent properties at BASELINE's full sample counts (C2, C3, C4 shard): latent -> real (net.py:214-217) -> latent
+    (net.py:209-213) returns the latent points; the log-density the sampling direction reports equals the one the evaluation
+    direction computes at the same points (both are latent pdf minus log-Jacobian); every sample is finite."""
+    import vmc_pde_amd as V
+    ups = [[int(v) for v in np.random.default_rng(b).permutation(dim)[: dim // 2]] for b in range(4)]
+    dns = [[i for i in range(dim) if i not in u] for u in ups]
+    off = np.linspace(0.5, -0.5, dim)
+    sampler = V.Sampler(key=5, dim=dim, name="Gauss", mcmc_info={"offset": off, "bound": 0.25})
+    vs = V.VarState(sampler, dim, 1, 4, network_args=dict(intmediate=hidden, offset=off, latentSpaceName="Gauss", dim=dim),
+                    inds_up=ups, inds_down=dns)
+    vs.set_parameters(vs.net.init(2, out_scale=0.1))
+    g = torch.Generator(device=DEV).manual_seed(N + dim)
+    z = torch.randn((N, dim), generator=g, dtype=torch.float64, device=DEV) + torch.as_tensor(off, device=DEV)
+    x, lp = vs.net.apply(vs.get_parameters(), z, evaluate=False, inv=True)
+    z2, _ = vs.net.apply(vs.get_parameters(), x, evaluate=False, inv=False)
+    assert bool(torch.isfinite(x).all()) and bool(torch.isfinite(lp).all())
+    assert float((z2 - z).abs().max()) < 1e-11 * max(1.0, float(z.abs().max()))
+    lp_eval = vs.net.apply(vs.get_parameters(), x, evaluate=True)
+    scale = float(lp.abs().max())
+    assert float((lp_eval - lp).abs().max()) < 1e-11 * scale
+    # (the second value of the forward call is, as net.py:213 writes it, the latent pdf of the INPUT minus the log-Jacobian --
+    # not a density of anything; pinned against the oracle in test_gpu_flow.py, not used here)
+
+
 def test_spectral_solve_on_device_by_default_at_config4_width():
     """solver="eigh" (the reference's pseudo-inverse, tdvp.py:57-94) at P = 4155: diagonalizeOnDevice=None picks rocSOLVER from
     640 parameters on; host LAPACK (the reference's default) must give the same update, and both the oracle's."""
