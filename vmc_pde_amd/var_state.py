@@ -64,6 +64,7 @@ class VarState:
         self.net, self._theta = self.init_net(network_args, *args, inds_up=inds_up, inds_down=inds_down)
         self.numParameters = self.net.numParameters                       # var_state.py:27
         self.paramShapes = [(int(np.prod(s)), tuple(s)) for _, _, s in self.net.layout]   # var_state.py:25
+        self.netTreeDef = ["/".join(p) for p, _, _ in self.net.layout]    # var_state.py:26: the leaf order of the parameter tree
         self._params = None                                               # the nested dict of views, built on first access
         self._ws = {}
         self._dirs_cache = {}
@@ -194,6 +195,11 @@ class VarState:
         z = torch.as_tensor(latent_space_samples, dtype=global_defs.tReal, device=self.device).reshape(-1, self.dim).contiguous()
         x, logp = self.net.apply(self._theta, z, evaluate=False, inv=True)
         return x[None, ...], logp[None, ...]
+
+    def average_tree(self, tree, axis=(0, 1)):    # var_state.py:81-86: leaf-wise mean of a nested dict
+        if isinstance(tree, dict):
+            return {k: self.average_tree(v, axis) for k, v in tree.items()}
+        return tree.mean(dim=axis)
 
     def integrate(self, grid):                    # var_state.py:88-91
         real_space_probs = self(torch.as_tensor(grid.coords)[None, ...], mode="eval")
