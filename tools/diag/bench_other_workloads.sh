@@ -1,3 +1,4 @@
+# bench lines for profiles/: the driver's launch form with one rank (torchrun), then the C3 and C4 workloads
 set -x
 cd $GRAFT_REPO_ROOT
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_torchrun1.log 2>&1 && tail -1 gpurun_out/bench_torchrun1.log | cut -c1-300
