@@ -36,6 +36,10 @@ namespace {
 #ifndef VMC_FLOW_MAX_WAVES
 #define VMC_FLOW_MAX_WAVES 8
 #endif
+#ifndef VMC_FLOW_UNROLL
+#define VMC_FLOW_UNROLL 1            // input units per trip of the dense-layer loops.  Measured (tools/diag/flow_unroll_ab.sh): unrolling by 2 / 3,
+                                     // i.e. the LDS reads of several units in flight together, is 3-5 % SLOWER on C2 / C3 / C4
+#endif
 constexpr int JB = VMC_FLOW_JB;  // output block held in registers by the dense-layer loops (measured: 6 x up-to-8 waves is the best compromise over C2/C3/C4)
 constexpr int MAX_WAVES = VMC_FLOW_MAX_WAVES;
 
@@ -106,6 +110,9 @@ Regions make_regions(const FlowProgram& fp) {
   return r;
 }
 
+#ifdef VMC_FLOW_STAMPS
+struct FlowStamps;
+#endif
 struct Ctx {
   double* lds;
   double* wl;     // weight stage: kernel [n_in][n_out] then bias [n_out] of the layer being evaluated
@@ -123,11 +130,30 @@ struct Ctx {
   int64_t ldw;                 // samples per workspace row
   int64_t samp_st, samp_ld;    // this lane's column for stores (its sample) / loads (clamped into range for idle lanes)
   bool act_store;              // this lane writes (a live sample) in a pass that is asked to store
+#ifdef VMC_FLOW_STAMPS
+  FlowStamps* st;              // wave 0 only (nullptr elsewhere)
+#endif
 };
 
 #define LD(u) (c.lds[(u) * c.lanes + c.lane])
+#ifdef VMC_FLOW_DIAG_NO_SYNC       // timing diagnostics only (results are wrong): what the workgroup barriers cost
+#define SYNC() ((void)0)
+#else
 #define SYNC() __syncthreads()
+#endif
 #define W0 (c.wave == 0)
+
+// -DVMC_FLOW_STAMPS (diagnostic builds, tools/diag/flow_stamps.py): wave 0 of every workgroup accumulates the shader-clock cycles it
+// spends in each phase of flow_eval_kernel; slots: 0 forward gather + barrier, 1 forward MLPs, 2 forward coupling algebra,
+// 3 latent forward, 4 latent backward, 5 reverse: activations again (forward-store), 6 reverse coupling algebra,
+// 7 reverse MLP backward (+ Jacobian stores), 8 rest, 9 workgroups counted
+#ifdef VMC_FLOW_STAMPS
+struct FlowStamps { unsigned long long last, acc[10]; };
+__device__ unsigned long long g_flow_stamps[10];
+#define FSTAMP(i) do { if (c.st) { const unsigned long long now_ = __builtin_readcyclecounter(); c.st->acc[i] += now_ - c.st->last; c.st->last = now_; } } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
 
 // Jacobian stores.  A row pointer is wave-uniform (base + row * pitch: SGPR arithmetic) and the lane only adds its 32-bit
 // byte offset, which lets the store use the scalar-base + vector-offset addressing form -- no 64-bit VALU address per element.
@@ -224,6 +250,9 @@ __device__ __forceinline__ void stage_weights(const Ctx& c, const Trafo& T) {
       c.wl[off + idx] = c.th[(idx < nk) ? (L.off_kernel + idx) : (L.off_bias + idx - nk)];
     off += nk + L.n_out;
   }
+  // JB doubles of zeros behind the last layer: the dense loops read whole output blocks of JB weights unconditionally (a block
+  // that sticks out of its row reads the next row, the bias row or this slack -- finite values whose products are dropped)
+  if (threadIdx.x < JB) c.wl[off + threadIdx.x] = 0.0;
 }
 
 // y = tanh-layer(x): z_j = b_j + sum_i W[i][j] a_i (net.py:55-61), with NC Taylor components.
@@ -241,7 +270,7 @@ __device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, i
 #pragma unroll
       for (int cc = 1; cc < NC; ++cc) acc[cc][jj] = 0.0;
     }
-#pragma unroll 1
+#pragma unroll VMC_FLOW_UNROLL
     for (int i = 0; i < n_in; ++i) {
       double a[NC];
 #pragma unroll
@@ -249,7 +278,7 @@ __device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, i
       const double* __restrict__ wr = W + i * n_out + j0;
 #pragma unroll
       for (int jj = 0; jj < JB; ++jj) {
-        const double w = (j0 + jj < n_out) ? wr[jj] : 0.0;
+        const double w = wr[jj];                              // (unconditional: see stage_weights)
 #pragma unroll
         for (int cc = 0; cc < NC; ++cc) acc[cc][jj] = fma(w, a[cc], acc[cc][jj]);
       }
@@ -284,9 +313,12 @@ __device__ __forceinline__ int mlp_forward(const Ctx& c, const Trafo& T, int uA,
   int wl = wofs, woff = 0;
   stage_weights(c, T);
   SYNC();                                   // (also orders the previous user's reads of the stage before this write: every pass ends with a barrier)
+  FSTAMP(3);
   for (int k = 0; k < T.n_layers; ++k) {
     dense_layer<NC>(c, T.layer[k], woff, cur, nxt, cs, (k == T.n_layers - 1) ? c.fp->alpha : 1.0, wl);
+    FSTAMP(1);
     SYNC();
+    FSTAMP(4);
     if (wl >= 0) wl += T.layer[k].n_out;
     woff += T.layer[k].n_in * T.layer[k].n_out + T.layer[k].n_out;
     const int t = cur; cur = nxt; nxt = t;
@@ -304,8 +336,10 @@ __device__ __forceinline__ void halfstep_forward(const Ctx& c, const HalfStep& h
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) LD(r.A + cc * cs + i) = LD(r.X + cc * d + h.idx_a[i]);
   SYNC();
+  FSTAMP(0);
   const bool keep = (c.actw != nullptr);
   int us = mlp_forward<NC>(c, h.s, r.A, r.B, cs, keep ? h.act_off_s : -1);
+  FSTAMP(1);
   int ut = 0;
   const int coupling = c.fp->coupling;
   if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) {
@@ -318,7 +352,9 @@ __device__ __forceinline__ void halfstep_forward(const Ctx& c, const HalfStep& h
         for (int cc = 0; cc < NC; ++cc) LD(r.A + cc * cs + i) = LD(r.X + cc * d + h.idx_a[i]);
     }
     SYNC();
+    FSTAMP(0);
     ut = mlp_forward<NC>(c, h.t, r.A, r.B, cs, keep ? h.act_off_t : -1);
+    FSTAMP(1);
   }
   if (!W0) return;     // (the next stage starts with a barrier that wave 0 reaches after the update below)
   for (int k = 0; k < h.n_c; ++k) {
@@ -356,6 +392,7 @@ __device__ __forceinline__ void halfstep_forward(const Ctx& c, const HalfStep& h
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) LD(r.X + cc * d + ix) = y[cc];
   }
+  FSTAMP(2);
 }
 
 // The global_change step that closes block b in the forward direction (net.py:115-116): y = scale * r + offset on all d
@@ -589,17 +626,21 @@ __device__ __forceinline__ void halfstep_backward(const Ctx& c, const HalfStep& 
     for (int i = 0; i < h.n_a; ++i) LD(r.ACT + i) = LD(r.X + h.idx_a[i]);
   }
   SYNC();
+  FSTAMP(6);
   if (coupling == VMCPDE_COUPLING_DIFFERENT_ADD) {
     // t enters additively (net.py:94): its output cotangent is G_c itself
     if (c.actw) mlp_load_activations(c, h.t, r.ACT, r.OUTT, h.act_off_t);
     else mlp_forward_store(c, h.t, r.ACT, r.OUTT);
+    FSTAMP(5);
     if (W0)
       for (int k = 0; k < h.n_c; ++k) LD(r.DW + k) = LD(r.G + h.idx_c[k]);
     mlp_backward(c, h.t, r, r.OUTT, r.DW, JT, ldj, n, active, c.actw == nullptr);     // (starts with wave 0's part, then a barrier)
+    FSTAMP(7);
     // ACT[0..n_a) still holds the half-step input for the s network
   }
   if (c.actw) mlp_load_activations(c, h.s, r.ACT, r.OUTS, h.act_off_s);
   else mlp_forward_store(c, h.s, r.ACT, r.OUTS);
+  FSTAMP(5);
   if (W0) {
     for (int k = 0; k < h.n_c; ++k) {
       const int ix = h.idx_c[k];
@@ -625,7 +666,9 @@ __device__ __forceinline__ void halfstep_backward(const Ctx& c, const HalfStep& 
       LD(r.G + ix) = gnew;
     }
   }
+  FSTAMP(6);
   mlp_backward(c, h.s, r, r.OUTS, r.DW, JT, ldj, n, active, c.actw == nullptr);
+  FSTAMP(7);
   if (W0)
     for (int i = 0; i < h.n_a; ++i) LD(r.G + h.idx_a[i]) += LD(r.GAM + i);
 }
@@ -673,7 +716,7 @@ __device__ __forceinline__ void latent_backward(const Ctx& c, const LatentCache*
   }
 }
 
-__global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_eval_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
+__global__ __launch_bounds__(64 * MAX_WAVES, 1) void flow_eval_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
                                                       const double* __restrict__ th, const double* __restrict__ x,
                                                       int64_t N, const double* __restrict__ dirs, int n_dirs,
                                                       double* __restrict__ logp, double* __restrict__ g,
@@ -706,6 +749,12 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_eval_kernel(const Flow
   c.samp_st = n;
   c.samp_ld = nn;
   c.act_store = false;
+#ifdef VMC_FLOW_STAMPS
+  FlowStamps stamps;
+  for (int i = 0; i < 10; ++i) stamps.acc[i] = 0;
+  stamps.last = __builtin_readcyclecounter();
+  c.st = (c.wave == 0) ? &stamps : nullptr;
+#endif
 
   // wave 0 owns the per-sample state and the scalar results; all waves walk the same sequence of stages
   double lp_val = 0.0;
@@ -724,9 +773,11 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_eval_kernel(const Flow
         if ((s & 1) && fp->global_change) global_forward<3>(c, s >> 1, r, lj);
       }
       if (W0) {
+        FSTAMP(8);
         latent_forward<3>(c, lc, r, r.X, lp);
         lp_val = lp[0] + lj[0];
         if (active) hv[n * n_dirs + k] = lp[2] + lj[2];
+        FSTAMP(3);
       }
     }
   } else {
@@ -752,14 +803,34 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_eval_kernel(const Flow
   }
 
   // reverse sweep: X currently holds z
+  FSTAMP(8);
   if (W0) latent_backward(c, lc, r, JT, ldj, n, active);
+  FSTAMP(4);
   for (int s = fp->n_half - 1; s >= 0; --s) {
     if ((s & 1) && fp->global_change) global_backward(c, s >> 1, r, JT, ldj, n, active);
     halfstep_backward(c, fp->hs[s], r, JT, ldj, n, active);
   }
   if (g != nullptr && active && W0)
     for (int i = 0; i < d; ++i) g[n * d + i] = LD(r.G + i);
+#ifdef VMC_FLOW_STAMPS
+  FSTAMP(8);
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 9; ++i) atomicAdd(&g_flow_stamps[i], stamps.acc[i]);
+    atomicAdd(&g_flow_stamps[9], 1ull);
+  }
+#endif
 }
+
+#ifdef VMC_FLOW_STAMPS
+extern "C" int vmcpde_debug_read_flow_stamps(unsigned long long* out_host, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_flow_stamps), sizeof(unsigned long long) * 10);
+  if (reset) {
+    unsigned long long z[10] = {0};
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_flow_stamps), z, sizeof(z));
+  }
+  return rc;
+}
+#endif
 
 // var_state.py:33 / net.py:214-217: (y, latent(x_in - offset) - log_jac) for either direction.
 __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_sample_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
@@ -780,6 +851,9 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_sample_kernel(const Fl
   c.ldw = 0;
   c.samp_st = c.samp_ld = 0;
   c.act_store = false;
+#ifdef VMC_FLOW_STAMPS
+  c.st = nullptr;
+#endif
   const int lane = (int)threadIdx.x & 63;
   const bool lane_ok = lane < lanes;
   c.lane = lane_ok ? lane : 0;            // see flow_eval_kernel

@@ -186,7 +186,7 @@ extern "C" int vmcpde_create(const vmcpde_model_desc* desc, vmcpde_model** out) 
       fp.max_sum_act = std::max(fp.max_sum_act, h->s.n_in + h->s.sum_hidden);
       int wsum = 0;
       for (int k = 0; k < h->s.n_layers; ++k) wsum += h->s.layer[k].n_in * h->s.layer[k].n_out + h->s.layer[k].n_out;
-      fp.max_mlp_weights = std::max(fp.max_mlp_weights, wsum);    // (the t network of a half-step has the same shape)
+      fp.max_mlp_weights = std::max(fp.max_mlp_weights, wsum + 8);   // + the zero slack behind the stage (flow.hip: stage_weights)
       h->act_off_s = fp.act_units;
       fp.act_units += h->s.sum_hidden + h->s.n_out;
       h->act_off_t = fp.act_units;
