@@ -97,13 +97,15 @@ def test_oracle_follows_published_first_steps():
     vo, eo = O.VarStateOracle(spec, th), O.EvolutionEquationOracle(DIM, "diffusion")
     to = O.TDVPOracle(frozen=frozen)
     g = torch.Generator().manual_seed(11)
-    stages = []
+    stages, means, spectra = [], [], []
 
     def f(y, t, k=None):
         z = O.latent_from_normals(spec, y, torch.randn(N, DIM, generator=g, dtype=torch.float64))
         u, aux = to.rhs(y, t, vo, eo, z)
         x = aux["x"][0]
         stages.append((float(-aux["logp_sample"].mean()), float(x.var(0, unbiased=False).mean()), float(to.solverResidual), float(to.tdvp_error)))
+        means.append(x.mean(0).numpy())
+        spectra.append(to.ev.numpy().copy())
         return u, aux
 
     t, dt, y, n_steps, times = 0.0, 5e-8, th.clone(), 22, []
@@ -127,6 +129,14 @@ def test_oracle_follows_published_first_steps():
     res, err = np.concatenate([first[:, 2], second[:, 2]]), np.concatenate([first[:, 3], second[:, 3]])
     assert np.all(res > 0.4 * ref["solver_res"][:n_steps].min()) and np.all(res < 2.5 * ref["solver_res"][:n_steps].max())
     assert 0.1 < np.median(err) / np.median(ref["tdvp_error"][:n_steps]) < 10 and err.max() < 5e-3
+    # sample means (published `x1`): zero within the sampling error sigma / sqrt(N) ~ 0.01, like the published record
+    m_or, m_pub = np.asarray(means[0::2]), ref["x1"][:n_steps]
+    assert np.abs(m_or).max() < 5.5 * np.sqrt((1 + 2 * times.max()) / N) and 0.5 < m_or.std() / m_pub.std() < 2.0
+    # the spectrum after 20 steps (published `ev` record 20, t = 0.0105): same numerical rank, lambda_max in the Monte-Carlo band
+    ev_or, ev_pub = np.sort(spectra[2 * 20])[::-1], np.sort(ref["ev_step20"])[::-1]
+    rank = lambda ev: int((ev > 1e-9 * ev[0]).sum())
+    assert rank(ev_or) == rank(ev_pub) == 144
+    assert 0.9 < ev_or[0] / ev_pub[0] < 1.1 and np.abs(np.log(ev_or[:8] / ev_pub[:8])).max() < 0.15
     # the frozen latent covariance stayed at the identity (A = 0 is a fixed point of the pseudo-inverse flow)
     assert float(y[list(frozen)].abs().max()) == 0.0
 
