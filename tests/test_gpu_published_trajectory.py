@@ -37,6 +37,10 @@ def _run(latent, n_steps, seed=1, dts=None, on_device=True):
         vs.set_parameters(dp)
         if n == 0:
             out["ev0"], out["res0"], out["err0"] = tdvp.ev.cpu().numpy(), float(tdvp.solverResidual), float(tdvp.tdvp_error)
+        if n == 20:
+            out["ev20"] = tdvp.ev.cpu().numpy()
+        if n == n_steps - 1:
+            out["ev_end"] = tdvp.ev.cpu().numpy()
         out["times"].append(t)
         out["entropy"].append(float(info["entropy"]))
         out["covar"].append(torch.diagonal(info["covar"]).cpu().numpy())
@@ -57,6 +61,12 @@ def test_gaussian_diffusion_d8_matches_published_trajectory():
     # the product's first spectrum, residual and TDVP error against the reference's own step-0 record (lambda_max 873.4, numerical
     # rank 144, 161 eigenvalues above 1e-11 lambda_max, residual 6e-11) -- the same checks that pin the oracle on the CPU
     check_against_published_step0(spectrum_with_A_columns(run["ev0"], int(run["n_frozen"])), float(run["res0"]), float(run["err0"]), ref)
+    # ... and the published spectra after 20 steps and at the last step: numerical rank 144 both times, leading eigenvalue in the
+    # Monte-Carlo band (this run's spectra belong to the second stage of the step, a state dt later: same rank, lambda_max within 10 %)
+    for mine, pub in ((run["ev20"], ref["ev_step20"]), (run["ev_end"], ref["ev_last"])):
+        mine, pub = spectrum_with_A_columns(mine, int(run["n_frozen"])), np.sort(pub)[::-1]
+        assert int((mine > 1e-9 * mine[0]).sum()) == int((pub > 1e-9 * pub[0]).sum()) == 144
+        assert 0.9 < mine[0] / pub[0] < 1.1
     # stepper.py:137 hands the driver the info of the second stage (the Euler predictor at times[n] + dt); the published record is
     # of the state at times[n] (tests/test_oracle_published_run.py), so record n of this run is compared with record n + 1
     assert np.abs(run["entropy"][:-1] - ref["entropy"][1:]).max() < 0.12
