@@ -23,6 +23,7 @@ CONFIGS = [
     (2, 2, (9, 9, 9), "Gauss", "different_add"),
     (3, 3, (4,), "Gauss", "no_add+global"),              # global_change (net.py:72,80-82,115-116,150-151), odd d
     (6, 11, (3,), "Student_t", "different_add+global"),  # ... with t-networks; 11 blocks: 'blocks_10' sorts before 'blocks_2'
+    (16, 2, (5, 4, 3), "Student_t", "different_add"),    # the ABI's maxima: d = VMCPDE_MAX_DIM (136 Hessian directions), three hidden layers
 ]
 
 
@@ -257,3 +258,22 @@ def test_ka3_density_is_normalised_on_the_reference_grid():
         vs = make_varstate(spec, th)
         grid = G.Grid(np.array([30.0, 30.0]), 600, sym=True)     # the multiplicative variants spread mass beyond +-10
         assert abs(float(vs.integrate(grid)) - 1.0) < 1e-5, coupling
+
+
+@pytest.mark.parametrize("kw,msg", [(dict(dim=17), "dim 17"), (dict(depth=17), "depth 17"), (dict(hidden=(3, 3, 3, 3)), "n_hidden 4"),
+                                    (dict(overlap=True), "bad ind_down")])
+def test_model_descriptor_limits_fail_loudly(kw, msg):
+    """vmcpde_create rejects what the ABI cannot represent (VMCPDE_MAX_DIM / _DEPTH / _HIDDEN_LAYERS) and partitions that are not a
+    split of the coordinates (var_state.py:116-117) with an error naming the field -- no silent truncation."""
+    import vmc_pde_amd as V
+    dim, depth, hidden = kw.get("dim", 4), kw.get("depth", 2), kw.get("hidden", (3,))
+    ups = [list(range(dim // 2)) for _ in range(depth)]
+    dns = [list(range(dim // 2, dim)) for _ in range(depth)]
+    if kw.get("overlap"):
+        dns[0][0] = ups[0][0]
+    off = np.zeros(dim)
+    sampler = V.Sampler(key=1, dim=dim, name="Gauss", mcmc_info={"offset": off, "bound": 0.25})
+    with pytest.raises((RuntimeError, ValueError, AssertionError)) as err:
+        V.VarState(sampler, dim, 1, depth, network_args=dict(intmediate=hidden, offset=off, latentSpaceName="Gauss", dim=dim),
+                   inds_up=ups, inds_down=dns)
+    assert msg in str(err.value), str(err.value)

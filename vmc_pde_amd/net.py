@@ -53,6 +53,8 @@ class INNwProb:
             dn=(C.c_int32 * (self.depth * (self.dim - n_up)))(*[v for u in self.inds_down for v in u]),
             off=(C.c_double * self.dim)(*self.offset.tolist()))
         desc = nat.ModelDesc()
+        if len(self.intmediate) > len(desc.hidden):
+            raise ValueError(f"n_hidden {len(self.intmediate)} outside [0,{len(desc.hidden)}] (VMCPDE_MAX_HIDDEN_LAYERS)")
         desc.dim, desc.depth, desc.n_hidden = self.dim, self.depth, len(self.intmediate)
         for k, w in enumerate(self.intmediate):
             desc.hidden[k] = w
