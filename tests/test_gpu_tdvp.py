@@ -459,3 +459,60 @@ def test_observables_kernel_against_numpy(n, d):
         assert np.allclose(o[d + d * d + k * d:d + d * d + (k + 1) * d], ref, rtol=1e-11, atol=1e-11 * np.abs(ref).max()), pw
     assert abs(o[d * d + 5 * d] + lp.mean()) < 1e-13 and o[d * d + 5 * d + 1] == el.max()
     assert float(ws.abs().max()) == 0.0 or int(ws[-2:].view(torch.int64)[0]) == 0
+
+
+def _small_cholesky_setup(**tdvp_kw):
+    import vmc_pde_amd as V
+    dim, depth, hidden, latent, coupling, eq, N = CASES[2]
+    spec, th, nrm, chi2, eo, ep = _problem(dim, depth, hidden, latent, coupling, eq, N, lam=0.1)
+    z = O.latent_from_normals(spec, th, nrm, chi2)
+    vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()))
+    return vs, th.cuda(), ep, V.TDVP(solver="cholesky", **tdvp_kw), dict(nSamplesTDVP=N, nSamplesObs=N, timings=None)
+
+
+def test_failed_cholesky_raises_instead_of_integrating_on():
+    """tdvp.py:136-141 stops the run on a NaN update.  The on-device Cholesky replaces NaN / non-positive pivots by unit rows and
+    would hand back a finite but meaningless update: the health record (pinned pivots, solver residual) must turn that into an
+    exception -- at the NaN check of the same call when observables are on, at the start of the next call when they are off."""
+    vs, th, ep, tp, kw = _small_cholesky_setup(diagonalShift=1e-4, svdTol=1e-8)
+    upd, _ = tp(th, 0.1, vs, ep, **kw)                       # a healthy call first
+    assert bool(torch.isfinite(upd).all()) and int(tp.cholInfo.item()) == 0
+    bad = th.clone()
+    bad[vs.numParameters // 2] = float("nan")
+    with pytest.raises(FloatingPointError, match="Cholesky failed"):
+        tp(bad, 0.1, vs, ep, **kw)
+    # observables off: the call itself returns (no host synchronisation), the next call raises
+    vs, th, ep, tp, kw = _small_cholesky_setup(diagonalShift=1e-4, svdTol=1e-8)
+    tp(bad, 0.1, vs, ep, observables=False, **kw)
+    with pytest.raises(FloatingPointError, match="previous step"):
+        tp(th, 0.1, vs, ep, observables=False, **kw)
+
+
+def test_pinned_pivots_warn_once_and_freeze_those_parameters():
+    """Parameters whose row of S is exactly zero (frozen here; dead units in practice) meet a zero pivot when there is no absolute
+    floor (svdTol = 0): the factorisation pins them (unit row, update 0), counts them in cholInfo and TDVP warns once; the other
+    parameters get the solution of the remaining system."""
+    frozen = [0, 5, 17]
+    vs, th, ep, tp, kw = _small_cholesky_setup(diagonalShift=1e-3, svdTol=0.0, frozenParameters=frozen)
+    with pytest.warns(RuntimeWarning, match="pinned 3 parameter"):
+        upd, _ = tp(th, 0.1, vs, ep, **kw)
+    assert int(tp.cholInfo.item()) == 3 and float(upd[frozen].abs().max()) == 0.0
+    assert float(tp.solverResidual) < 1e-9 and bool(torch.isfinite(upd).all())
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                        # second call: no second warning
+        tp(th, 0.1, vs, ep, **kw)
+
+
+def test_nan_update_stops_the_run_on_the_spectral_path():
+    """tdvp.py:136-141: a NaN in the update ends the run (the reference prints S0, F0 and exits; here an exception).  With NaN
+    parameters the host eigensolver may already refuse the matrix -- either way the call must not return."""
+    import vmc_pde_amd as V
+    dim, depth, hidden, latent, coupling, eq, N = CASES[0]
+    spec, th, nrm, chi2, eo, ep = _problem(dim, depth, hidden, latent, coupling, eq, N)
+    z = O.latent_from_normals(spec, th, nrm, chi2)
+    vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()))
+    bad = th.clone().cuda()
+    bad[3] = float("nan")
+    with pytest.raises((FloatingPointError, np.linalg.LinAlgError)):
+        V.TDVP()(bad, 0.0, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None)
