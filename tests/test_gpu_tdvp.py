@@ -516,3 +516,27 @@ def test_nan_update_stops_the_run_on_the_spectral_path():
     bad[3] = float("nan")
     with pytest.raises((FloatingPointError, np.linalg.LinAlgError)):
         V.TDVP()(bad, 0.0, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None)
+
+
+def test_lazy_SExp_refuses_a_jacobian_that_was_overwritten():
+    """SExp / rhoVar / snr are evaluated lazily from the Jacobian of the last TDVP call, which lives in the VarState's per-N
+    workspace (2 GB at C2: not copied).  Another evaluation of the same batch size overwrites it -- the lazy properties must
+    notice (workspace generation) instead of returning a weighted Gram of mismatched data."""
+    import vmc_pde_amd as V
+    dim, depth, hidden, latent, coupling, eq, N = CASES[1]
+    spec, th, nrm, chi2, eo, ep = _problem(dim, depth, hidden, latent, coupling, eq, N, lam=0.1)
+    z = O.latent_from_normals(spec, th, nrm, chi2)
+    vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()))
+    tp = V.TDVP()
+    kw = dict(nSamplesTDVP=N, nSamplesObs=N, timings=None)
+    tp(th.cuda(), 0.1, vs, ep, **kw)
+    S1 = tp.SExp.clone()                                      # read in time: fine, and cached
+    x, _ = vs.flow_sample(z.cuda())
+    vs(x, mode="eval_coordgrads")                            # same N: the workspace is rewritten
+    assert torch.equal(tp.SExp, S1)                          # the cached value is still the right one
+    tp(th.cuda(), 0.1, vs, ep, **kw)
+    vs(x, mode="eval_coordgrads")
+    with pytest.raises(RuntimeError, match="overwritten"):
+        tp.SExp
+    with pytest.raises(RuntimeError, match="overwritten"):
+        tp.snr
