@@ -328,3 +328,41 @@ def test_full_size_config4_shard_tdvp_call():
     for upd, resid, info, err in out:
         assert torch.isfinite(upd).all() and info == 0 and resid < 1e-8 and 0.0 <= err < 1.0
     assert tp._uncentred_ok
+
+
+def test_two_host_threads_on_their_own_streams():
+    """include/vmcpde.h: thread-compatible, no process-wide mutable state.  Two host threads factor different matrices and build
+    different Gram matrices at the same time, each on its own stream with its own workspaces; results must equal the serial ones
+    bit for bit (the per-GPU context -- permutation table, attribute flags -- is created under a lock and read-only afterwards)."""
+    import threading
+    P, N = 1500, 4096
+    mats = [_spd_gpu(P, 100 + k) for k in range(2)]
+    g = torch.Generator(device=DEV).manual_seed(5)
+    jts = [torch.randn((_pad(P, 128), N), generator=g, dtype=torch.float64, device=DEV) for _ in range(2)]
+    for jt in jts:
+        jt[P:] = 0.0
+
+    def work(k, stream, out):
+        with torch.cuda.stream(stream):
+            for _ in range(3):
+                Ap, *_ = _factor(mats[k], P)
+                npk = nat.lib().vmcpde_gram_packed_doubles(P)
+                packed = torch.empty(npk, dtype=torch.float64, device=DEV)
+                need = nat.lib().vmcpde_gram_workspace_bytes(P, N)
+                ws = torch.empty(need // 8, dtype=torch.float64, device=DEV)
+                nat.call("vmcpde_gram", nat.ptr(jts[k]), N, 0, P, N, None, None, nat.ptr(packed), nat.ptr(ws), need, nat.stream())
+            stream.synchronize()
+            out[k] = (Ap[:P, :P].tril().clone(), packed.clone())
+
+    serial, threaded = {}, {}
+    for k in range(2):
+        work(k, torch.cuda.current_stream(), serial)
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    ts = [threading.Thread(target=work, args=(k, streams[k], threaded)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for k in range(2):
+        assert torch.equal(serial[k][0], threaded[k][0]) and torch.equal(serial[k][1], threaded[k][1])
