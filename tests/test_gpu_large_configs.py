@@ -330,6 +330,16 @@ def test_full_size_config4_shard_tdvp_call():
     assert tp._uncentred_ok
 
 
+def test_full_size_step_is_bitwise_reproducible():
+    """The whole step at the C4 shard size and at C2 (sample, flow, Gram with split reduction, Cholesky, substitution): a second,
+    independent run from the same seeds gives the same update bit for bit -- no atomics or arrival-order dependent sums anywhere
+    (the replicated solve of the multi-GPU scheme relies on it: theta is never broadcast after step 0)."""
+    for dim, hidden, N, lam in ((6, (19, 19), 32768, 0.0), (2, (21, 21), 65536, 0.1)):
+        runs = [_full_size_call(dim, hidden, N, "advection_hamiltonian_wDiss", lam)[2] for _ in range(2)]
+        for (u0, r0, i0, e0), (u1, r1, i1, e1) in zip(*runs):
+            assert torch.equal(u0, u1) and r0 == r1 and e0 == e1 and i0 == i1 == 0
+
+
 def test_two_host_threads_on_their_own_streams():
     """include/vmcpde.h: thread-compatible, no process-wide mutable state.  Two host threads factor different matrices and build
     different Gram matrices at the same time, each on its own stream with its own workspaces; results must equal the serial ones
