@@ -80,6 +80,8 @@ def main():
         vState.set_parameters(st["theta"])
         t, myStepper.dt, smp._calls = st["t"], st["dt"], st["sampler_calls"]
         infos = st.get("infos", infos)          # the run record continues where the interrupted run stopped
+        if "tdvp" in st:
+            tdvpEq.load_state_dict(st["tdvp"])  # the lagged means of the moments / Gram: the resumed run repeats the uninterrupted one
         print(f"resumed at t = {t} with {len(infos['times'])} recorded steps")
 
     def host(v):
@@ -112,7 +114,8 @@ def main():
         # checkpoint (parameters, clock, sampler stream position AND the run record) -- written next to the target and renamed,
         # so a kill in the middle of the write leaves the previous checkpoint intact
         tmp = ckpt + ".tmp"
-        torch.save({"theta": vState.get_parameters().cpu(), "t": t, "dt": myStepper.dt, "sampler_calls": smp._calls, "infos": infos}, tmp)
+        torch.save({"theta": vState.get_parameters().cpu(), "t": t, "dt": myStepper.dt, "sampler_calls": smp._calls, "infos": infos,
+                    "tdvp": tdvpEq.state_dict()}, tmp)
         os.replace(tmp, ckpt)
         if len(infos["times"]) % args.save_every == 0:
             util.store_infos(wdir, infos)

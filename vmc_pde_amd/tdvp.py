@@ -428,6 +428,24 @@ class TDVP:
                 self._record_guard(out)
         return update, out[0], out[1]
 
+    # ---- state carried from call to call (not in the reference, whose calls are independent) ---------------------
+    def state_dict(self):
+        """What a call inherits from the previous one: the global means used as the shift of the one-pass moments and the Gram
+        (centering / gramShift "auto").  With it a resumed run repeats the uninterrupted one bit for bit (examples/main.py)."""
+        if self._ratio_event is not None:
+            self._ratio_event.synchronize()
+            self._uncentred_ok = bool(self._ratio_host[0] < 1e3)
+        return {"c_prev": None if self._c_prev is None else self._c_prev.detach().cpu().clone(),
+                "cE_prev": None if self._c_prev is None else self._cE_prev.detach().cpu().clone(),
+                "uncentred_ok": bool(self._uncentred_ok)}
+
+    def load_state_dict(self, st, device=None):
+        device = global_defs.my_device() if device is None else device
+        self._c_prev = None if st.get("c_prev") is None else st["c_prev"].to(device)
+        self._cE_prev = None if st.get("cE_prev") is None else st["cE_prev"].to(device)
+        self._uncentred_ok = bool(st.get("uncentred_ok", False))
+        self._ratio_host = self._ratio_event = None      # the restored flag stands until the next call's own check lands
+
     # ---- tdvp.py:143-162 -----------------------------------------------------------------------------------------
     def _observables(self, sampleConfigs, logProbs, Eloc):
         """mean, covariance (1/n), entropy, central moments 3-6 of the samples and the largest Eloc: `vmcpde_observables` (two
