@@ -459,9 +459,13 @@ __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const 
       mma_kstep_sym<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff, alias);
     }
     VMC_STAMP(1)
+#ifndef VMC_GRAM_DIAG_NO_WAIT        // timing diagnostics only (results are wrong): what the DMA wait / the K-step barrier cost
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     VMC_STAMP(2)
+#ifndef VMC_GRAM_DIAG_NO_BARRIER
     __syncthreads();
+#endif
     VMC_STAMP(3)
     cur ^= 1;
   }
