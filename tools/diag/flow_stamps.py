@@ -7,8 +7,16 @@ import torch, bench
 from vmc_pde_amd import _native as nat
 wl = sys.argv[1] if len(sys.argv) > 1 else "C2"
 dev = torch.device("cuda", 0)
-vs, eq, tdvp, theta = bench.build_problem(dev, wl)
-N = bench.WORKLOADS[wl]["n_samp"]
+if wl == "small":      # the reference's phase-space model: d = 6, 4 blocks x hidden (3,), different_add, P = 411, N = 10 000
+    import numpy as np, vmc_pde_amd as V
+    off = np.array([1.0, 0.0, 1.0, 0.0, 1.0, 0.0])
+    sampler = V.Sampler(key=1, dim=6, name="Gauss", mcmc_info={"offset": off, "bound": 0.25})
+    vs = V.VarState(sampler, 6, 1, 4, network_args={"intmediate": (3,), "offset": off, "latentSpaceName": "Gauss", "dim": 6, "different_add": True})
+    eq = V.EvolutionEquation(dim=6, name="advection_hamiltonian_wDiss")
+    N = 10000
+else:
+    vs, eq, tdvp, theta = bench.build_problem(dev, wl)
+    N = bench.WORKLOADS[wl]["n_samp"]
 x, _ = vs.sample(N)
 lib = nat.lib()
 out = (C.c_ulonglong * 10)()

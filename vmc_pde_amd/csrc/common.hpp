@@ -39,12 +39,15 @@ struct DenseLayer {
   int32_t off_bias, off_kernel;  // kernel is (in,out) row-major
 };
 
+constexpr int STAGE_ALL_MAX_DOUBLES = 1536;   // networks whose weights (all of them, with slack) fit 12 KB of LDS are staged once per kernel
+
 // One SingleTrafo (net.py:44-62): n_layers-1 tanh hidden layers + alpha*tanh output layer.
 struct Trafo {
   int32_t n_layers;
   int32_t n_in, n_out;
   int32_t sum_hidden;   // sum of hidden widths
   int32_t max_width;    // max over all layer widths incl. input/output
+  int32_t wbase;        // first double of this network in the all-networks weight stage (FlowProgram::stage_all)
   DenseLayer layer[MAX_LAYERS];
 };
 
@@ -66,6 +69,10 @@ struct FlowProgram {
   int32_t max_width;     // widest MLP layer (incl. inputs/outputs)
   int32_t max_sum_act;   // max over trafos of (n_in + sum_hidden)
   int32_t max_mlp_weights; // max over the MLPs of the doubles of all its layers' kernels and biases (the LDS weight stage)
+  int32_t all_mlp_weights; // the same summed over every MLP (each with its zero slack), and
+  int32_t stage_all;       //   whether the flow kernels stage ALL networks once at their start (small networks: one round trip to
+                           //   theta per kernel instead of one per network pass -- a 64-sample group of the reference's d = 6, hidden (3,)
+                           //   model makes 48 passes whose latency, not work, is the kernel's time)
   int32_t act_units;     // activation workspace: sum over all MLPs of (hidden widths + outputs) doubles per sample
   double alpha;          // SingleTrafo.alpha = 10 (net.py:50)
   int32_t global_change; // net.py:72: block b ends with y -> th[off_gscale[b]] * y + th[off_goffset[b] + i]

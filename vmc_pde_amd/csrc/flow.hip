@@ -75,7 +75,7 @@ Regions make_regions_values(const FlowProgram& fp) {
   r.SOUT = u; u += d;
   r.LAT = u; u += d;
   r.total = u;
-  r.wgt = fp.max_mlp_weights;
+  r.wgt = fp.stage_all ? fp.all_mlp_weights : fp.max_mlp_weights;
   return r;
 }
 
@@ -106,7 +106,7 @@ Regions make_regions(const FlowProgram& fp) {
   r.Y = u; u += d;
   r.Q = u; u += d;
   r.total = (u > end_taylor) ? u : end_taylor;
-  r.wgt = fp.max_mlp_weights;
+  r.wgt = fp.stage_all ? fp.all_mlp_weights : fp.max_mlp_weights;
   return r;
 }
 
@@ -241,8 +241,7 @@ __device__ __forceinline__ int layer_woff(const Trafo& T, int k) {
   for (int q = 0; q < k; ++q) off += T.layer[q].n_in * T.layer[q].n_out + T.layer[q].n_out;
   return off;
 }
-__device__ __forceinline__ void stage_weights(const Ctx& c, const Trafo& T) {
-  int off = 0;
+__device__ __forceinline__ void stage_weights_at(const Ctx& c, const Trafo& T, int off) {
   for (int k = 0; k < T.n_layers; ++k) {
     const DenseLayer& L = T.layer[k];
     const int nk = L.n_in * L.n_out;
@@ -253,6 +252,18 @@ __device__ __forceinline__ void stage_weights(const Ctx& c, const Trafo& T) {
   // JB doubles of zeros behind the last layer: the dense loops read whole output blocks of JB weights unconditionally (a block
   // that sticks out of its row reads the next row, the bias row or this slack -- finite values whose products are dropped)
   if (threadIdx.x < JB) c.wl[off + threadIdx.x] = 0.0;
+}
+// the stage of one network pass: nothing to do when the kernel staged every network at its start (FlowProgram::stage_all)
+__device__ __forceinline__ void stage_weights(const Ctx& c, const Trafo& T) {
+  if (!c.fp->stage_all) stage_weights_at(c, T, 0);
+}
+__device__ __forceinline__ int stage_base(const Ctx& c, const Trafo& T) { return c.fp->stage_all ? T.wbase : 0; }
+__device__ __forceinline__ void stage_all_networks(const Ctx& c) {
+  const FlowProgram& fp = *c.fp;
+  for (int h = 0; h < fp.n_half; ++h) {
+    stage_weights_at(c, fp.hs[h].s, fp.hs[h].s.wbase);
+    if (fp.hs[h].has_t) stage_weights_at(c, fp.hs[h].t, fp.hs[h].t.wbase);
+  }
 }
 
 // y = tanh-layer(x): z_j = b_j + sum_i W[i][j] a_i (net.py:55-61), with NC Taylor components.
@@ -310,7 +321,7 @@ __device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, i
 template <int NC>
 __device__ __forceinline__ int mlp_forward(const Ctx& c, const Trafo& T, int uA, int uB, int cs, int wofs = -1) {
   int cur = uA, nxt = uB;
-  int wl = wofs, woff = 0;
+  int wl = wofs, woff = stage_base(c, T);
   stage_weights(c, T);
   SYNC();                                   // (also orders the previous user's reads of the stage before this write: every pass ends with a barrier)
   FSTAMP(3);
@@ -529,7 +540,7 @@ __device__ __forceinline__ void latent_forward(const Ctx& c, const LatentCache* 
 
 // SingleTrafo forward keeping every layer input in ACT (input already in ACT[0..n_in)); outputs go to uOUT.
 __device__ __forceinline__ void mlp_forward_store(const Ctx& c, const Trafo& T, int uACT, int uOUT) {
-  int in = uACT, woff = 0;
+  int in = uACT, woff = stage_base(c, T);
   stage_weights(c, T);
   SYNC();
   for (int k = 0; k < T.n_layers; ++k) {
@@ -581,7 +592,7 @@ __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const
     const int uin = r.ACT + in_off;
     if (k == nl - 1) SYNC();                  // publishes wave 0's DEL0 (and the weights if they were staged here); later layers
                                               // start behind the barrier that closed the previous one
-    const double* __restrict__ W = c.wl + layer_woff(T, k);
+    const double* __restrict__ W = c.wl + stage_base(c, T) + layer_woff(T, k);
     for (int i = c.wave; i < n_in; i += c.nw) LD(r.EPS + i) = 0.0;
     for (int j0 = 0, blk = 0; j0 < n_out; j0 += JB, ++blk) {
       double dl[JB];
@@ -756,6 +767,8 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 1) void flow_eval_kernel(const Flow
   c.st = (c.wave == 0) ? &stamps : nullptr;
 #endif
 
+  if (fp->stage_all) stage_all_networks(c);   // (the first network pass starts with a barrier)
+
   // wave 0 owns the per-sample state and the scalar results; all waves walk the same sequence of stages
   double lp_val = 0.0;
   if (n_dirs > 0 && hv != nullptr) {
@@ -861,6 +874,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 4) void flow_sample_kernel(const Fl
   const int64_t n = (int64_t)blockIdx.x * lanes + c.lane;
   const bool active = lane_ok && n < N && W0;
   const int64_t nn = (n < N) ? n : (N - 1);
+  if (fp->stage_all) stage_all_networks(c);   // (the first network pass starts with a barrier)
   double lp[1] = {0.0};
   if (W0) {
     for (int i = 0; i < d; ++i) LD(r.X + i) = zin[nn * d + i];

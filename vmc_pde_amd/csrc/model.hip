@@ -187,6 +187,12 @@ extern "C" int vmcpde_create(const vmcpde_model_desc* desc, vmcpde_model** out) 
       int wsum = 0;
       for (int k = 0; k < h->s.n_layers; ++k) wsum += h->s.layer[k].n_in * h->s.layer[k].n_out + h->s.layer[k].n_out;
       fp.max_mlp_weights = std::max(fp.max_mlp_weights, wsum + 8);   // + the zero slack behind the stage (flow.hip: stage_weights)
+      h->s.wbase = fp.all_mlp_weights;
+      fp.all_mlp_weights += wsum + 8;
+      if (has_t) {
+        h->t.wbase = fp.all_mlp_weights;
+        fp.all_mlp_weights += wsum + 8;
+      }
       h->act_off_s = fp.act_units;
       fp.act_units += h->s.sum_hidden + h->s.n_out;
       h->act_off_t = fp.act_units;
@@ -194,6 +200,7 @@ extern "C" int vmcpde_create(const vmcpde_model_desc* desc, vmcpde_model** out) 
     }
   }
 
+  fp.stage_all = (fp.all_mlp_weights <= STAGE_ALL_MAX_DOUBLES) ? 1 : 0;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e == hipSuccess) e = hipMalloc(&m->dev, sizeof(FlowProgram));
