@@ -79,19 +79,21 @@ Regions make_regions_values(const FlowProgram& fp) {
   return r;
 }
 
-Regions make_regions(const FlowProgram& fp) {
+// kdirs: Hessian directions carried by one forward Taylor pass (1 + 2 kdirs components: value, then first and second derivative
+// along each direction)
+Regions make_regions(const FlowProgram& fp, int kdirs = 1) {
   Regions r;
-  const int d = fp.dim, W = fp.max_width;
+  const int d = fp.dim, W = fp.max_width, nc = 1 + 2 * kdirs;
   r.cs = W;
   int u = 0;
-  r.X = u; u += 3 * d;
+  r.X = u; u += nc * d;
   r.G = u; u += d;
   const int base = u;
   // Taylor phase
-  r.A = u; u += 3 * W;
-  r.B = u; u += 3 * W;
-  r.SOUT = u; u += 3 * d;
-  r.LAT = u; u += 3 * d;
+  r.A = u; u += nc * W;
+  r.B = u; u += nc * W;
+  r.SOUT = u; u += nc * d;
+  r.LAT = u; u += nc * d;
   const int end_taylor = u;
   // reverse phase
   u = base;
@@ -304,11 +306,14 @@ __device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, i
 #endif
         LD(uout + j0 + jj) = scale * h;
         if (wofs >= 0 && c.act_store) c.actw[(int64_t)(wofs + j0 + jj) * c.ldw + c.samp_st] = scale * h;
-        if (NC == 3) {
+        if (NC > 1) {
           const double hp = 1.0 - h * h;
-          const double z1 = acc[1][jj], z2 = acc[2][jj];
-          LD(uout + cs + j0 + jj) = scale * hp * z1;
-          LD(uout + 2 * cs + j0 + jj) = scale * hp * (z2 - 2.0 * h * z1 * z1);
+#pragma unroll
+          for (int kd = 0; kd < (NC - 1) / 2; ++kd) {           // first / second derivative along direction kd
+            const double z1 = acc[2 * kd + 1][jj], z2 = acc[2 * kd + 2][jj];
+            LD(uout + (2 * kd + 1) * cs + j0 + jj) = scale * hp * z1;
+            LD(uout + (2 * kd + 2) * cs + j0 + jj) = scale * hp * (z2 - 2.0 * h * z1 * z1);
+          }
         }
       }
     }
@@ -369,7 +374,9 @@ __device__ __forceinline__ void halfstep_forward(const Ctx& c, const HalfStep& h
   }
   if (!W0) return;     // (the next stage starts with a barrier that wave 0 reaches after the update below)
   for (int k = 0; k < h.n_c; ++k) {
-    double s[3] = {0, 0, 0}, t[3] = {0, 0, 0}, cv[3] = {0, 0, 0}, y[3] = {0, 0, 0};
+    double s[NC], t[NC], cv[NC], y[NC];
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) s[cc] = t[cc] = cv[cc] = y[cc] = 0.0;
     const int ix = h.idx_c[k];
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) {
@@ -387,11 +394,13 @@ __device__ __forceinline__ void halfstep_forward(const Ctx& c, const HalfStep& h
     } else {
       const double E = exp(s[0]);
       y[0] = cv[0] * E;
-      if (NC == 3) {
-        const double E1 = E * s[1];
-        const double E2 = E * (s[2] + s[1] * s[1]);
-        y[1] = cv[1] * E + cv[0] * E1;
-        y[2] = cv[2] * E + 2.0 * cv[1] * E1 + cv[0] * E2;
+#pragma unroll
+      for (int kd = 0; kd < (NC - 1) / 2; ++kd) {
+        const int c1 = 2 * kd + 1, c2 = 2 * kd + 2;
+        const double E1 = E * s[c1];
+        const double E2 = E * (s[c2] + s[c1] * s[c1]);
+        y[c1] = cv[c1] * E + cv[0] * E1;
+        y[c2] = cv[c2] * E + 2.0 * cv[c1] * E1 + cv[0] * E2;
       }
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) {
@@ -497,9 +506,11 @@ __device__ __forceinline__ void halfstep_inverse(const Ctx& c, const HalfStep& h
 template <int NC>
 __device__ __forceinline__ void latent_forward(const Ctx& c, const LatentCache* __restrict__ lc, const Regions& r, int ux, double* lp) {
   const int d = c.fp->dim;
-  double Q[3] = {0, 0, 0};
+  double Q[NC];
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) Q[cc] = 0.0;
   for (int i = d - 1; i >= 0; --i) {
-    double y[3];
+    double y[NC];
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) {
       y[cc] = LD(ux + cc * d + i);
@@ -517,23 +528,28 @@ __device__ __forceinline__ void latent_forward(const Ctx& c, const LatentCache* 
       LD(r.LAT + cc * d + i) = y[cc];
     }
     Q[0] += y[0] * y[0];
-    if (NC == 3) {
-      Q[1] += 2.0 * y[0] * y[1];
-      Q[2] += 2.0 * (y[1] * y[1] + y[0] * y[2]);
+#pragma unroll
+    for (int kd = 0; kd < (NC - 1) / 2; ++kd) {
+      Q[2 * kd + 1] += 2.0 * y[0] * y[2 * kd + 1];
+      Q[2 * kd + 2] += 2.0 * (y[2 * kd + 1] * y[2 * kd + 1] + y[0] * y[2 * kd + 2]);
     }
   }
   if (c.fp->latent == VMCPDE_LATENT_GAUSS) {
     lp[0] = lc->lognorm - 0.5 * Q[0];   // net.py:18-20
-    if (NC == 3) { lp[1] = -0.5 * Q[1]; lp[2] = -0.5 * Q[2]; }
+#pragma unroll
+    for (int cc = 1; cc < NC; ++cc) lp[cc] = -0.5 * Q[cc];
   } else {
     const double nu = lc->nu, p = (double)d;   // net.py:32-36
     const double hnp = 0.5 * (nu + p);
     lp[0] = lc->lognorm - hnp * log1p(Q[0] / nu);
-    if (NC == 3) {
+    if (NC > 1) {
       const double f1 = -hnp / (nu + Q[0]);
       const double f2 = hnp / ((nu + Q[0]) * (nu + Q[0]));
-      lp[1] = f1 * Q[1];
-      lp[2] = f1 * Q[2] + f2 * Q[1] * Q[1];
+#pragma unroll
+      for (int kd = 0; kd < (NC - 1) / 2; ++kd) {
+        lp[2 * kd + 1] = f1 * Q[2 * kd + 1];
+        lp[2 * kd + 2] = f1 * Q[2 * kd + 2] + f2 * Q[2 * kd + 1] * Q[2 * kd + 1];
+      }
     }
   }
 }
@@ -727,6 +743,10 @@ __device__ __forceinline__ void latent_backward(const Ctx& c, const LatentCache*
   }
 }
 
+// KD: Hessian directions per forward Taylor pass (1 + 2 KD components).  One direction per pass needs the least LDS (every
+// configuration of BASELINE); narrow networks take KD = 2 or 4, which shares the value component and the weight reads of a
+// pass among the directions (d = 8 diffusion: 2 passes instead of 8) -- chosen by vmcpde_flow_eval.
+template <int KD>
 __global__ __launch_bounds__(64 * MAX_WAVES, 1) void flow_eval_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
                                                       const double* __restrict__ th, const double* __restrict__ x,
                                                       int64_t N, const double* __restrict__ dirs, int n_dirs,
@@ -772,24 +792,32 @@ __global__ __launch_bounds__(64 * MAX_WAVES, 1) void flow_eval_kernel(const Flow
   // wave 0 owns the per-sample state and the scalar results; all waves walk the same sequence of stages
   double lp_val = 0.0;
   if (n_dirs > 0 && hv != nullptr) {
-    for (int k = 0; k < n_dirs; ++k) {
+    constexpr int NCT = 1 + 2 * KD;
+    for (int k = 0; k < n_dirs; k += KD) {
       c.act_store = active && c.actw != nullptr && k == 0;       // the value component is the same for every direction
       if (W0)
         for (int i = 0; i < d; ++i) {
           LD(r.X + i) = x[nn * d + i];
-          LD(r.X + d + i) = dirs[k * d + i];
-          LD(r.X + 2 * d + i) = 0.0;
+#pragma unroll
+          for (int kd = 0; kd < KD; ++kd) {                       // (a group that sticks out of n_dirs carries zero directions)
+            LD(r.X + (2 * kd + 1) * d + i) = (k + kd < n_dirs) ? dirs[(k + kd) * d + i] : 0.0;
+            LD(r.X + (2 * kd + 2) * d + i) = 0.0;
+          }
         }
-      double lj[3] = {0, 0, 0}, lp[3];
+      double lj[NCT], lp[NCT];
+#pragma unroll
+      for (int cc = 0; cc < NCT; ++cc) lj[cc] = 0.0;
       for (int s = 0; s < fp->n_half; ++s) {
-        halfstep_forward<3>(c, fp->hs[s], r, lj);
-        if ((s & 1) && fp->global_change) global_forward<3>(c, s >> 1, r, lj);
+        halfstep_forward<NCT>(c, fp->hs[s], r, lj);
+        if ((s & 1) && fp->global_change) global_forward<NCT>(c, s >> 1, r, lj);
       }
       if (W0) {
         FSTAMP(8);
-        latent_forward<3>(c, lc, r, r.X, lp);
+        latent_forward<NCT>(c, lc, r, r.X, lp);
         lp_val = lp[0] + lj[0];
-        if (active) hv[n * n_dirs + k] = lp[2] + lj[2];
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd)
+          if (active && k + kd < n_dirs) hv[n * n_dirs + k + kd] = lp[2 * kd + 2] + lj[2 * kd + 2];
         FSTAMP(3);
       }
     }
@@ -1090,25 +1118,49 @@ extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const doub
   if (n_samples == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (int rc = vmcpde_prepare_latent_internal(m, theta, st)) return rc;
-  Regions r = make_regions(m->host);
+  // Hessian directions per forward pass: 4 or 2 when every workgroup of the launch is still resident at once with the larger
+  // per-sample LDS footprint (narrow networks, moderate batches -- the reference's own problem sizes), else 1
+  int kd = 1;
+  Regions r = make_regions(m->host, 1);
   int bytes = 0;
-  const int lanes = pick_lanes(r.total, r.wgt, pick_waves(m->host), &bytes);
+  int lanes = pick_lanes(r.total, r.wgt, pick_waves(m->host), &bytes);
   VMC_REQUIRE(bytes <= 160 * 1024, "network too wide for the LDS-resident flow kernel (%d B per sample lane)", r.total * 8);
+  if (hv != nullptr && n_dirs >= 2 && env_int("VMCPDE_FLOW_MULTIDIR", 1)) {
+    for (int cand : {4, 2}) {
+      if (cand == 4 && n_dirs < 3) continue;
+      const Regions rc = make_regions(m->host, cand);
+      int bc = 0;
+      const int lc_ = pick_lanes(rc.total, rc.wgt, pick_waves(m->host), &bc);
+      if (bc > 160 * 1024 || lc_ != lanes) continue;              // (same samples per workgroup as the one-direction plan)
+      const int64_t resident = 256 * (int64_t)((160 * 1024) / bc);
+      if ((n_samples + lc_ - 1) / lc_ <= resident) {
+        kd = cand; r = rc; bytes = bc; lanes = lc_;
+        break;
+      }
+    }
+  }
+  const void* kern = (kd == 4) ? (const void*)flow_eval_kernel<4> : (kd == 2) ? (const void*)flow_eval_kernel<2> : (const void*)flow_eval_kernel<1>;
   if (bytes > 64 * 1024) {
     DeviceCtx* ctx = device_ctx();
     if (!ctx) return -2;
     DeviceCtxLock lock;
-    if (bytes > ctx->flow_eval_lds) {
-      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)flow_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-      ctx->flow_eval_lds = bytes;
+    int& have = (kd == 4) ? ctx->flow_eval_lds4 : (kd == 2) ? ctx->flow_eval_lds2 : ctx->flow_eval_lds;
+    if (bytes > have) {
+      VMC_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      have = bytes;
     }
   }
   const int64_t grid = (n_samples + lanes - 1) / lanes;
   VMC_REQUIRE(workspace == nullptr || workspace_bytes >= vmcpde_flow_eval_workspace_bytes(m, n_samples),
               "flow_eval workspace too small: need %lld bytes", (long long)vmcpde_flow_eval_workspace_bytes(m, n_samples));
-  hipLaunchKernelGGL(flow_eval_kernel, dim3((unsigned)grid), dim3(64 * pick_waves(m->host)), bytes, st, m->dev, m->cache, theta, x, n_samples,
-                     dirs, (hv ? n_dirs : 0), logp, g, hv, JT, ldj, (int)jt_f32, static_cast<double*>(workspace),
-                     (int64_t)((n_samples + 63) / 64 * 64), lanes, r);
+#define VMC_LAUNCH_FLOW_EVAL(K)                                                                                                          \
+  hipLaunchKernelGGL(flow_eval_kernel<K>, dim3((unsigned)grid), dim3(64 * pick_waves(m->host)), bytes, st, m->dev, m->cache, theta, x, \
+                     n_samples, dirs, (hv ? n_dirs : 0), logp, g, hv, JT, ldj, (int)jt_f32, static_cast<double*>(workspace),             \
+                     (int64_t)((n_samples + 63) / 64 * 64), lanes, r)
+  if (kd == 4) VMC_LAUNCH_FLOW_EVAL(4);
+  else if (kd == 2) VMC_LAUNCH_FLOW_EVAL(2);
+  else VMC_LAUNCH_FLOW_EVAL(1);
+#undef VMC_LAUNCH_FLOW_EVAL
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }
