@@ -75,6 +75,11 @@ def test_tdvp_rhs_parity_eigh_path(case):
 
     (uw_p, err_p), (uw_o, err_o) = restricted(upd_p.cpu()), restricted(upd_o)
     assert float(torch.linalg.norm(to.S0 @ (uw_p - uw_o)) / nF) < 1e-9
+    # measured 2e-14 .. 8e-12 on most boxes, once 2e-10 for the Student-t case (373 of its 393 modes pass the 1e-9 threshold and the
+    # oracle's own host eigh differs between CPUs): asserted at 1e-10 on the modes above 1e-7 lambda_max, at 1e-9 on all of `well`
+    assert abs(err_p - err_o) < 1e-9
+    W = to.V[:, to.ev > 1e-7 * to.ev[-1]]
+    (_, err_p), (_, err_o) = restricted(upd_p.cpu()), restricted(upd_o)
     assert abs(err_p - err_o) < 1e-10
     # the solve in isolation: the reference's formulae (tdvp.py:61-64, 82-91) in numpy on the PRODUCT's (S, F)
     Sp, Fp = tp.S.cpu(), tp.F0.cpu()
