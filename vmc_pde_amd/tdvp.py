@@ -35,12 +35,19 @@ _BORDER_PIVOT = 1e200    # corner of the bordered matrix: any value above F^T A^
 def _lapack_threads(P):
     """Thread cap for the host eigh: OpenBLAS' default (one thread per hardware thread, 64+) makes a 411 x 411 eigh take 94 ms
     instead of 9 ms with one thread, and a 4213 x 4213 one 5.3 s instead of 1.3 s with 16 (measured on the GPU box's host)."""
+    global _THREADPOOLS
+    limit = 1 if P < 600 else (8 if P < 2000 else 16)
     try:
-        from threadpoolctl import threadpool_limits
+        if _THREADPOOLS is None:     # (threadpool_limits() re-scans the loaded libraries on every call: 0.45 ms; the controller is made once)
+            from threadpoolctl import ThreadpoolController
+            _THREADPOOLS = ThreadpoolController()
+        return _THREADPOOLS.limit(limits=limit)
     except ImportError:          # no cap available: plain LAPACK call
         import contextlib
         return contextlib.nullcontext()
-    return threadpool_limits(limits=1 if P < 600 else (8 if P < 2000 else 16))
+
+
+_THREADPOOLS = None
 
 
 DEVICE_EIGH_MIN_P = 640     # diagonalizeOnDevice=None: rocSOLVER's syevd overtakes thread-capped host LAPACK between P = 411 and 1024
