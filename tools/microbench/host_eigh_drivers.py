@@ -14,3 +14,13 @@ for n in (392, 411, 1024):
                 for _ in range(5): f()
                 res.append(f"{name} {(time.perf_counter() - t) / 5 * 1e3:7.2f} ms")
             print(f"n={n} threads={thr}: " + " | ".join(res), flush=True)
+
+import torch
+print("torch CPU eigh:", torch.__config__.parallel_info().splitlines()[0] if hasattr(torch.__config__, "parallel_info") else "")
+for n in (392, 411, 1024):
+    X = rng.standard_normal((n, int(0.4 * n))); S = torch.from_numpy(X @ X.T / X.shape[1])
+    for thr in (1, 4, 8, 16):
+        torch.set_num_threads(thr)
+        torch.linalg.eigh(S); t = time.perf_counter()
+        for _ in range(5): torch.linalg.eigh(S)
+        print(f"n={n} torch threads={thr}: {(time.perf_counter() - t) / 5 * 1e3:7.2f} ms", flush=True)
