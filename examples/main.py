@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--save-every", type=int, default=1, help="write infos.npz every this many steps (and at the end)")
     ap.add_argument("--svd-tol", type=float, default=1e-11,
                     help="spectral cut-off / absolute floor; wide networks (P in the thousands) need ~1e-6 with --diagonal-shift 1e-4")
+    ap.add_argument("--no-integrals", action="store_true",
+                    help="skip the three small-ball integrals (tdvp.py:152-162; the reference evaluates them on every call and its "
+                         "published records hold them, so they are on by default)")
     args = ap.parse_args()
     m = mode_dict[args.mode]
     dim, offset = m["dim"], m["offset"]
@@ -89,7 +92,7 @@ def main():
     while t < args.t_end + dt:                                                                                                             # main.py:159
         t1 = time.perf_counter()
         dp, dt, info = myStepper.step(0, tdvpEq, vState.get_parameters(), evolutionEq=evolutionEq, psi=vState, nSamplesTDVP=nSamplesTDVP,
-                                      nSamplesObs=nSamplesObs, normFunction=norm_fun, timings=timings, integrals=False)
+                                      nSamplesObs=nSamplesObs, normFunction=norm_fun, timings=timings, integrals=not args.no_integrals)
         vState.set_parameters(dp)
         infos["times"].append(t)
         print(f"t = {t:.3f}, dt = {dt:e}")
@@ -113,6 +116,7 @@ def main():
         t = t + dt
         # checkpoint (parameters, clock, sampler stream position AND the run record) -- written next to the target and renamed,
         # so a kill in the middle of the write leaves the previous checkpoint intact
+        tdvpEq.check("before the checkpoint")      # a failed solve must not reach the checkpoint (the stepper checked already)
         tmp = ckpt + ".tmp"
         torch.save({"theta": vState.get_parameters().cpu(), "t": t, "dt": myStepper.dt, "sampler_calls": smp._calls, "infos": infos,
                     "tdvp": tdvpEq.state_dict()}, tmp)

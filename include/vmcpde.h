@@ -192,10 +192,12 @@ int vmcpde_tdvp_diagnostics(const double* u, const double* S0u, const double* F,
 /* tdvp.py:143-150, the observables of one sample set x[n][dim] (row-major, dim <= 16) in two launches:
  *   out = mean[dim] (x1) | covar[dim*dim] (1/n, about the mean) | x3[dim] x4[dim] x5[dim] x6[dim] (central moments) |
  *         entropy = -mean(logp) | max(eloc)          ([dev] dim*dim + 5*dim + 2; logp / eloc NULL: 0 / -inf)
+ * eloc has its OWN length n_eloc (ABI 3): with nSamplesObs > nSamplesTDVP the reference re-draws x and logp at nSamplesObs
+ * (tdvp.py:130-134) while jnp.max(Eloc) (tdvp.py:150) still runs over the nSamplesTDVP entries of the solve.
  * workspace: vmcpde_observables_workspace_bytes(), zero-initialised once by the caller (the kernels leave it zeroed). */
 int64_t vmcpde_observables_workspace_bytes(void);
-int vmcpde_observables(const double* x, int64_t n_samples, int32_t dim, const double* logp, const double* eloc, double* out,
-                       void* workspace, int64_t workspace_bytes, void* stream);
+int vmcpde_observables(const double* x, int64_t n_samples, int32_t dim, const double* logp, const double* eloc, int64_t n_eloc,
+                       double* out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- mpi_wrapper.py:129-163 (global_sum) ---------------------------------------------------------------------- */
 /* The single collective of a TDVP step: packed[0..count) <- sum over the ranks of `comm`, in place, fp64, on `stream`

@@ -560,6 +560,28 @@ class TDVPOracle:
         info["max_grad"] = Eloc.max()
         return info
 
+    @staticmethod
+    def ball_points(normals, uniforms):
+        """tdvp.py:154-155 with the draws injected: directions normals / |normals| (1,n,d), radii uniforms^(1/d) (1,n) -- uniform
+        points in the unit ball.  (The reference draws both arrays from the SAME key `psi.sampler.key`; threefry streams are not
+        reproducible here (H4), so the two arrays are inputs.)"""
+        dim = normals.shape[-1]
+        return normals / torch.linalg.norm(normals, dim=-1, keepdim=True) * uniforms[..., None] ** (1 / dim)
+
+    @staticmethod
+    def small_ball_integrals(psi, samples):
+        """tdvp.py:157-162: Monte-Carlo integral of exp(logp) over balls of radius lim * sqrt(T), T = 10, lim in (1, 0.5, 0.1),
+        from uniform unit-ball points `samples` (1,n,d): mean(p(lim * samples)) * volume of the ball."""
+        info = {}
+        dim = samples.shape[-1]
+        for lim in [1, 0.5, 0.1]:
+            lim_normal = lim
+            T = 10
+            lim = lim * math.sqrt(T)                                                             # :160
+            sphere_volume = math.pi ** (dim / 2) / math.gamma(dim / 2 + 1) * lim ** dim          # :161
+            info[f"integral_{lim_normal}sigma"] = torch.mean(torch.exp(psi(lim * samples))) * sphere_volume   # :162
+        return info
+
 
 # --------------------------------------------------------------------------------------------
 # stepper.py (value semantics: every `y +=` of the reference rebinds an immutable jnp array)

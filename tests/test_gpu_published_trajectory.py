@@ -28,13 +28,20 @@ def _run(latent, n_steps, seed=1, dts=None, on_device=True):
     stepper = V.FixedStepper(timeStep=5e-8, mode="Heun", maxStep=1e-2, increase_fac=2.0)   # first step 1e-7, doubling (published `times`)
     tdvp = V.TDVP(diagonalizeOnDevice=on_device, frozenParameters=frozen)
     eq = V.EvolutionEquation(dim=dim, name="diffusion")
-    t, out = 0.0, dict(times=[], entropy=[], covar=[], tdvp_error=[], solver_res=[], nu=[])
+    t, out = 0.0, dict(times=[], entropy=[], covar=[], tdvp_error=[], solver_res=[], nu=[], dt=[], max_grad=[], x4=[], x6=[],
+                       integral_1sigma=[], integral_05sigma=[], integral_01sigma=[])
     for n in range(n_steps):
         if dts is not None:      # replay a recorded (partly adaptive) step-size sequence
             stepper.dt, stepper.increase_fac, stepper.maxStep = float(dts[n]), 1.0, 1.0
         dp, dt, info = stepper.step(0, tdvp, vs.get_parameters(), evolutionEq=eq, psi=vs, nSamplesTDVP=10000, nSamplesObs=10000,
-                                    normFunction=lambda v, S: v @ S @ v, timings=None, integrals=None)
+                                    normFunction=lambda v, S: v @ S @ v, timings=None)      # (small-ball integrals on, as in the reference)
         vs.set_parameters(dp)
+        out["dt"].append(dt)
+        out["max_grad"].append(float(info["max_grad"]))
+        out["x4"].append(info["x4"].cpu().numpy())
+        out["x6"].append(info["x6"].cpu().numpy())
+        for key, lim in (("integral_1sigma", 1), ("integral_05sigma", 0.5), ("integral_01sigma", 0.1)):
+            out[key].append(float(info[f"integral_{lim}sigma"]))
         if n == 0:
             out["ev0"], out["res0"], out["err0"] = tdvp.ev.cpu().numpy(), float(tdvp.solverResidual), float(tdvp.tdvp_error)
         if n == 20:
@@ -80,6 +87,23 @@ def test_gaussian_diffusion_d8_matches_published_trajectory():
     # solver diagnostics in the published range (tdvp_error median 5.1e-5 / max 8.8e-4; residual max 6.5e-11)
     assert np.median(run["tdvp_error"]) < 5e-4 and run["tdvp_error"].max() < 5e-3
     assert np.median(run["solver_res"]) < 1e-9
+    # the rest of the info record (tdvp.py:143-162).  Small-ball integrals: the exact solution N(0, (1 + 2t) I_8) has
+    # integral_{lim}sigma = chi^2_8-CDF(10 lim^2 / (1 + 2t)); the published record follows that curve to 2.4e-2 / 3.9e-3 / 1.5e-4
+    # (tests/test_oracle_published_run.py).  This run's record n belongs to the predictor state at times[n] + dt (see above).
+    from scipy.stats import chi2
+    t2 = run["times"] + run["dt"]
+    for lim, key, tol in ((1.0, "integral_1sigma", 0.08), (0.5, "integral_05sigma", 0.04), (0.1, "integral_01sigma", 0.03)):
+        exact = chi2.cdf(10.0 * lim ** 2 / (1 + 2 * t2), 8)
+        dev = run[key] / exact - 1
+        assert np.abs(dev).max() < tol and np.abs(dev[:30]).max() < tol / 4, (key, np.abs(dev).max(), np.abs(dev[:30]).max())
+        assert np.abs(run[key][:-1] / ref[key][1:] - 1).max() < 1.5 * tol, key          # record n here ~ published record n + 1
+    # central moments of a Gaussian of variance s^2 = 1 + 2t: x4 = 3 s^4, x6 = 15 s^6 (10^4 samples: ~3 % / ~10 % standard error)
+    s2 = 1 + 2 * t2
+    assert np.abs(run["x4"].mean(1) / (3 * s2 ** 2) - 1).max() < 0.08 and np.abs(ref["x4"].mean(1) / (3 * (1 + 2 * ref["times"]) ** 2) - 1).max() < 0.08
+    assert np.abs(run["x6"].mean(1) / (15 * s2 ** 3) - 1).max() < 0.25 and np.abs(ref["x6"].mean(1) / (15 * (1 + 2 * ref["times"]) ** 3) - 1).max() < 0.25
+    # largest Eloc = max_i (r_i^2 / s^2 - d) / s^2: the published record falls from 18.6 .. 38.2 in the first steps to 1.8 .. 2.7 at t = 5
+    assert 0.7 < np.median(run["max_grad"][:50]) / np.median(ref["max_grad"][:50]) < 1.4
+    assert 0.7 < np.median(run["max_grad"][-50:]) / np.median(ref["max_grad"][-50:]) < 1.4
 
 
 def test_student_t_diffusion_d8_follows_published_nu():
@@ -164,11 +188,12 @@ def test_phase_space_three_oscillators_matches_exact_moments_and_published_ensem
     tdvp = V.TDVP(diagonalizeOnDevice=True)
     eq = V.EvolutionEquation(dim=dim, name="advection_hamiltonian_wDiss")                     # T = 10, gamma = m = omega = 1, lam = 0
     n_steps = len(ref["inn_times"])
-    t, times, x1, cov, terr = 0.0, [], [], [], []
+    t, times, x1, cov, terr, ints = 0.0, [], [], [], [], []
     for n in range(n_steps):
         dp, dt, info = stepper.step(0, tdvp, vs.get_parameters(), evolutionEq=eq, psi=vs, nSamplesTDVP=10000, nSamplesObs=10000,
-                                    normFunction=lambda v, S: v @ S @ v, timings=None, integrals=None)
+                                    normFunction=lambda v, S: v @ S @ v, timings=None)
         vs.set_parameters(dp)
+        ints.append([float(info[f"integral_{lim}sigma"]) for lim in (1, 0.5, 0.1)])
         times.append(t)
         x1.append(info["x1"].cpu().numpy())
         cov.append(info["covar"].cpu().numpy())
@@ -194,6 +219,31 @@ def test_phase_space_three_oscillators_matches_exact_moments_and_published_ensem
     dw = np.abs(np.diagonal(cov[idx], axis1=1, axis2=2) - np.diagonal(ref["covar"], axis1=1, axis2=2))
     assert (dw / np.diagonal(ref["covar"], axis1=1, axis2=2)).max() < 0.15
     assert np.abs(x1[idx] - ref["x1"]).max() < 0.2
+    # small-ball integrals (tdvp.py:152-162): (i) against the ball probabilities of the exact Gaussian N(m(t), C(t)) -- 2^22 host
+    # samples per checked time; record n belongs to the predictor state at times[n] + dt --, (ii) against the fraction of the
+    # reference's 10 000 published Langevin walkers inside the balls, (iii) against the steady-state constants the reference's plot
+    # script holds (paper_plot_phaseSpaceTempDifference.py:129-133: chi^2_6-CDF at 1, 0.25, 0.01), which t = 5 has almost reached
+    ints = np.asarray(ints)
+    rng = np.random.default_rng(0)
+    t_next = np.append(times[1:], t)
+    import math
+    from scipy.stats import multivariate_normal
+    u = rng.standard_normal((1 << 20, dim))
+    u = u / np.linalg.norm(u, axis=1, keepdims=True) * rng.uniform(size=(1 << 20, 1)) ** (1 / dim)       # uniform in the unit ball
+    for n in (0, 100, 250, 400, n_steps - 1):
+        m1, c1 = _oscillator_moments([t_next[n]], T=10.0)
+        mean6, cov6 = np.tile(m1[0], 3), np.kron(np.eye(3), c1[0])
+        for k, lim in enumerate((1, 0.5, 0.1)):
+            R = lim * math.sqrt(10.0)
+            exact = multivariate_normal(mean6, cov6).pdf(R * u).mean() * math.pi ** 3 / math.gamma(4.0) * R ** dim
+            assert abs(ints[n, k] / exact - 1) < 0.2, (n, lim, ints[n, k], exact)        # flow-vs-exact covariance agreement is ~10 %
+    iw = [int(np.argmin(np.abs(t_next - tw))) for tw in (1.0, 2.0, 3.0, 4.0, 5.0)]
+    jw = [int(np.argmin(np.abs(ref["wiener_times_all"] - tw))) for tw in (1.0, 2.0, 3.0, 4.0, 5.0)]
+    assert np.abs(ints[iw, 0] / ref["wiener_integral_1sigma"][jw] - 1).max() < 0.25      # walker fractions of ~2 %: +-8 % counting error
+    steady = np.array([0.0143877, 0.000296478, 2.07554e-8])
+    assert np.all(np.abs(ints[-1] / steady - 1) < 0.25), ints[-1] / steady
+    late = ref["wiener_times_all"] > 8.0
+    assert abs(ref["wiener_integral_1sigma"][late].mean() / steady[0] - 1) < 0.1          # the published ensemble sits on the constant
 
 
 def test_headline_configuration_evolves_the_kramers_equation_correctly():

@@ -49,6 +49,10 @@ def test_tdvp_rhs_parity_eigh_path(case):
     # product
     vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()))
     tp = V.TDVP(solver="eigh")
+    # the small-ball integrals (tdvp.py:152-162) with the ball points injected into oracle and product (H4)
+    gb = torch.Generator().manual_seed(11)
+    ball = O.TDVPOracle.ball_points(torch.randn(1, N, dim, generator=gb, dtype=torch.float64), torch.rand(1, N, generator=gb, dtype=torch.float64))
+    tp._ball_samples = lambda psi, n, d: ball.to(psi.device)
     upd_p, info = tp(th.cuda(), 0.2, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None)
     P = vs.numParameters
     assert rel_err(tp.S0, to.S0) < 1e-11 and tp.S0.shape == (P, P)
@@ -100,7 +104,9 @@ def test_tdvp_rhs_parity_eigh_path(case):
     obs = to.observables(aux["x"], aux["logp"], aux["Eloc"])
     for k in ("x1", "covar", "entropy", "x3", "x4", "x5", "x6", "max_grad"):
         assert rel_err(info[k], obs[k]) < 1e-10, k
-    assert {"integral_1sigma", "integral_0.5sigma", "integral_0.1sigma"} <= set(info)
+    ints = O.TDVPOracle.small_ball_integrals(vo, ball)
+    for k in ("integral_1sigma", "integral_0.5sigma", "integral_0.1sigma"):
+        assert float(ints[k]) > 0 and abs(float(info[k]) / float(ints[k]) - 1) < 1e-10, k
     assert mpi.globNumSamples == N
 
 
@@ -468,7 +474,7 @@ def test_observables_kernel_against_numpy(n, d):
     ws = torch.zeros(nat.lib().vmcpde_observables_workspace_bytes() // 8, dtype=torch.float64, device=dev)
     out = torch.full((d * d + 5 * d + 2,), float("nan"), dtype=torch.float64, device=dev)
     for _ in range(2):      # twice: the workspace counter must be left at zero
-        nat.call("vmcpde_observables", nat.ptr(xd), n, d, nat.ptr(lpd), nat.ptr(eld), nat.ptr(out), nat.ptr(ws), ws.numel() * 8, nat.stream())
+        nat.call("vmcpde_observables", nat.ptr(xd), n, d, nat.ptr(lpd), nat.ptr(eld), n, nat.ptr(out), nat.ptr(ws), ws.numel() * 8, nat.stream())
     o = out.cpu().numpy()
     m = x.mean(0)
     X = x - m

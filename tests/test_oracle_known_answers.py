@@ -143,3 +143,33 @@ def test_distribute_sampling_matches_reference_formula():
     # chains variant (mpi_wrapper.py:94-110)
     spc, glob = O.distribute_sampling(10000, 1, 0, localDevices=1, numChainsPerDevice=30)
     assert spc == 334 and glob == 334 * 30
+
+
+@pytest.mark.parametrize("dim,sigma", [(2, math.sqrt(10.0)), (3, 1.5), (6, 1.0)])
+def test_small_ball_integrals_known_answer(dim, sigma):
+    """tdvp.py:152-162 on a density whose ball probabilities are known: identity flow (output kernels 0), latent covariance
+    sigma^2 I (L = 0, L_diag = log sigma, util.py:21-26), mu = offset = 0  ->  p = N(0, sigma^2 I) and
+    integral_{lim}sigma = P(|x| < lim sqrt(10)) = chi^2_d-CDF(10 lim^2 / sigma^2).  d = 6, sigma = 1 at lim = 1 is the first
+    entry of the steady-state constants the reference's plot script holds (paper_plot_phaseSpaceTempDifference.py:129-133:
+    0.0143877 / 2.96478e-4 / 2.07554e-8 are the chi^2_6-CDF at 1, 0.25, 0.01 -- the T = 10 steady state has variance 10)."""
+    from scipy.stats import chi2
+    spec = make_spec(dim, 2, (3,))
+    th = O.init_parameters(spec, 5, out_scale=0.0)
+    p = O.unflatten(spec, th)
+    p["L_diag"] = torch.full_like(p["L_diag"], math.log(sigma))
+    th = O.flatten(spec, p)
+    vs = O.VarStateOracle(spec, th)
+    g = torch.Generator().manual_seed(dim)
+    n = 40000
+    ball = O.TDVPOracle.ball_points(torch.randn(1, n, dim, generator=g, dtype=torch.float64), torch.rand(1, n, generator=g, dtype=torch.float64))
+    r = torch.linalg.norm(ball[0], dim=-1)
+    assert float(r.max()) <= 1.0 and abs(float((r ** dim).mean()) - 0.5) < 0.01          # uniform in the unit ball: r^d ~ U(0,1)
+    ints = O.TDVPOracle.small_ball_integrals(vs, ball)
+    for lim in (1, 0.5, 0.1):
+        exact = chi2.cdf(10.0 * lim ** 2 / sigma ** 2, dim)
+        # Monte-Carlo error of the mean of p over the ball, from the sample itself
+        R = lim * math.sqrt(10.0)
+        pv = torch.exp(vs(R * ball))[0]
+        se = float(pv.std() / pv.mean()) / math.sqrt(n)
+        assert abs(float(ints[f"integral_{lim}sigma"]) / exact - 1) < 5 * se + 1e-12, (lim, se)
+    assert abs(chi2.cdf(1.0, 6) - 0.0143877) < 1e-7 and abs(chi2.cdf(0.25, 6) - 2.96478e-4) < 1e-9 and abs(chi2.cdf(0.01, 6) - 2.07554e-8) < 1e-13

@@ -75,7 +75,7 @@ _PROTOS = {
     "vmcpde_tdvp_moments": (_int, [_vp, _i32, _i32, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _f64, _vp]),
     "vmcpde_tdvp_diagnostics": (_int, [_vp, _vp, _vp, _vp, _i32, _f64, _vp, _vp, _vp, _vp, _vp]),
     "vmcpde_observables_workspace_bytes": (_i64, []),
-    "vmcpde_observables": (_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "vmcpde_observables": (_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     "vmcpde_allreduce": (_int, [_vp, _i64, _vp, _vp]),
     "vmcpde_comm_unique_id": (_int, [_vp]),
     "vmcpde_comm_init_rank": (_int, [C.POINTER(_vp), _i32, _vp, _i32]),

@@ -178,12 +178,14 @@ constexpr int OBS_QMAX = OBS_DMAX * OBS_DMAX + 4 * OBS_DMAX;            // 320
 
 template <int PHASE>
 __global__ __launch_bounds__(OBS_THREADS) void observables_kernel(const double* __restrict__ x, int64_t n, int d, const double* __restrict__ logp,
-                                                                  const double* __restrict__ eloc, double* __restrict__ out, double* __restrict__ ws) {
-  __shared__ double xs[OBS_CHUNK * (OBS_DMAX + 2)];     // per sample: d coordinates (centred in phase 1), then log p, Eloc (phase 0)
+                                                                  const double* __restrict__ eloc, int64_t n_eloc, double* __restrict__ out,
+                                                                  double* __restrict__ ws) {
+  __shared__ double xs[OBS_CHUNK * (OBS_DMAX + 1)];     // per sample: d coordinates (centred in phase 1), then log p (phase 0)
   __shared__ double mean[OBS_DMAX];
+  __shared__ double emax[OBS_THREADS / 64];
   __shared__ bool last;
   const int t = threadIdx.x, nb = gridDim.x;
-  const int w = d + (PHASE == 0 ? 2 : 0);                // doubles per staged sample
+  const int w = d + (PHASE == 0 ? 1 : 0);                // doubles per staged sample
   const int nq = (PHASE == 0) ? d + 2 : d * d + 4 * d;
   if (PHASE == 1) {
     if (t < d) mean[t] = out[t];
@@ -192,7 +194,22 @@ __global__ __launch_bounds__(OBS_THREADS) void observables_kernel(const double* 
   const int64_t per = (n + nb - 1) / nb;
   const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < n) ? (lo + per) : n;
   double acc[2] = {0.0, 0.0};
-  if (PHASE == 0) { if (t == d + 1) acc[0] = -INFINITY; if (t + OBS_THREADS == d + 1) acc[1] = -INFINITY; }
+  if (PHASE == 0) {
+    // max Eloc (tdvp.py:150) over ITS OWN n_eloc entries: with nSamplesObs > nSamplesTDVP (tdvp.py:130-134) the samples and log p are
+    // re-drawn at nSamplesObs while Eloc keeps the nSamplesTDVP entries of the solve
+    double mx = -INFINITY;
+    if (eloc) {
+      const int64_t per_e = (n_eloc + nb - 1) / nb;
+      const int64_t lo_e = (int64_t)blockIdx.x * per_e, hi_e = (lo_e + per_e < n_eloc) ? (lo_e + per_e) : n_eloc;
+      for (int64_t i = lo_e + t; i < hi_e; i += OBS_THREADS) mx = fmax(mx, eloc[i]);
+    }
+    mx = wave_max(mx);
+    if ((t & 63) == 0) emax[t >> 6] = mx;
+    __syncthreads();
+    mx = emax[0];
+    for (int k = 1; k < OBS_THREADS / 64; ++k) mx = fmax(mx, emax[k]);
+    if (t == d + 1) acc[0] = mx;           // (d <= 16: quantity d + 1 always belongs to the first pass of thread d + 1)
+  }
   for (int64_t c0 = lo; c0 < hi; c0 += OBS_CHUNK) {
     const int m = (int)((hi - c0 < OBS_CHUNK) ? (hi - c0) : OBS_CHUNK);
     for (int e = t; e < m * d; e += OBS_THREADS) {
@@ -201,10 +218,7 @@ __global__ __launch_bounds__(OBS_THREADS) void observables_kernel(const double* 
       xs[sidx * w + j] = (PHASE == 1) ? v - mean[j] : v;
     }
     if (PHASE == 0)
-      for (int sidx = t; sidx < m; sidx += OBS_THREADS) {
-        xs[sidx * w + d] = logp ? logp[c0 + sidx] : 0.0;
-        xs[sidx * w + d + 1] = eloc ? eloc[c0 + sidx] : -INFINITY;
-      }
+      for (int sidx = t; sidx < m; sidx += OBS_THREADS) xs[sidx * w + d] = logp ? logp[c0 + sidx] : 0.0;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -212,8 +226,7 @@ __global__ __launch_bounds__(OBS_THREADS) void observables_kernel(const double* 
       if (q >= nq) break;
       double a = acc[k];
       if (PHASE == 0) {
-        if (q == d + 1) for (int sidx = 0; sidx < m; ++sidx) a = fmax(a, xs[sidx * w + q]);
-        else for (int sidx = 0; sidx < m; ++sidx) a += xs[sidx * w + q];
+        if (q <= d) for (int sidx = 0; sidx < m; ++sidx) a += xs[sidx * w + q];
       } else if (q < d * d) {
         const int i = q / d, j = q - i * d;
         for (int sidx = 0; sidx < m; ++sidx) a = fma(xs[sidx * w + i], xs[sidx * w + j], a);
@@ -306,17 +319,18 @@ extern "C" int vmcpde_tdvp_diagnostics(const double* u, const double* S0u, const
 
 extern "C" int64_t vmcpde_observables_workspace_bytes(void) { return ((int64_t)OBS_BLOCKS_MAX * OBS_QMAX + 2) * (int64_t)sizeof(double); }
 
-extern "C" int vmcpde_observables(const double* x, int64_t n_samples, int32_t dim, const double* logp, const double* eloc, double* out,
-                                  void* workspace, int64_t workspace_bytes, void* stream) {
+extern "C" int vmcpde_observables(const double* x, int64_t n_samples, int32_t dim, const double* logp, const double* eloc, int64_t n_eloc,
+                                  double* out, void* workspace, int64_t workspace_bytes, void* stream) {
   VMC_REQUIRE(x && out && workspace, "vmcpde_observables: null argument");
   VMC_REQUIRE(n_samples >= 1, "empty sample set");
+  VMC_REQUIRE(eloc == nullptr || n_eloc >= 1, "vmcpde_observables: eloc given with n_eloc < 1");
   VMC_REQUIRE(dim >= 1 && dim <= OBS_DMAX, "vmcpde_observables: 1 <= dim <= 16");
   VMC_REQUIRE(workspace_bytes >= vmcpde_observables_workspace_bytes(), "observables workspace too small");
   int blocks = (int)((n_samples + 4 * OBS_CHUNK - 1) / (4 * OBS_CHUNK));
   if (blocks > OBS_BLOCKS_MAX) blocks = OBS_BLOCKS_MAX;
-  hipLaunchKernelGGL(observables_kernel<0>, dim3(blocks), dim3(OBS_THREADS), 0, (hipStream_t)stream, x, n_samples, dim, logp, eloc, out,
+  hipLaunchKernelGGL(observables_kernel<0>, dim3(blocks), dim3(OBS_THREADS), 0, (hipStream_t)stream, x, n_samples, dim, logp, eloc, n_eloc, out,
                      static_cast<double*>(workspace));
-  hipLaunchKernelGGL(observables_kernel<1>, dim3(blocks), dim3(OBS_THREADS), 0, (hipStream_t)stream, x, n_samples, dim, logp, eloc, out,
+  hipLaunchKernelGGL(observables_kernel<1>, dim3(blocks), dim3(OBS_THREADS), 0, (hipStream_t)stream, x, n_samples, dim, logp, eloc, n_eloc, out,
                      static_cast<double*>(workspace));
   VMC_CHECK_HIP(hipGetLastError());
   return 0;

@@ -24,6 +24,15 @@ class _Stages:
         return k, info
 
 
+def _accept(f):
+    """Before a step is handed back: let the right-hand side report a failed solve (`TDVP.check`: NaN update, Cholesky that was
+    not positive definite).  The reference stops inside every call (tdvp.py:136-141); with `observables=False` the calls here do
+    not synchronise with the host, so this is the one place per step that does."""
+    check = getattr(f, "check", None)
+    if check is not None:
+        check("stepper: before accepting the step")
+
+
 def _heun_increment(rhs, y0, t, h, k_first=None):
     """Heun (explicit trapezoid) increment over [t, t+h] from y0; reuses a known first slope.  Returns (dy, k_first, infos)."""
     infos = []
@@ -65,6 +74,7 @@ class AdaptiveHeun:
             if ratio >= 1.0:
                 break
         self.dt = dt
+        _accept(f)
         return y_start + fine, used, info
 
 
@@ -86,6 +96,8 @@ class FixedStepper:
         rhs = _Stages(f, rhsArgs)
         if self.mode == 'Euler':
             k0, info = rhs(y_start, t)
+            _accept(f)
             return y_start + self.dt * k0, self.dt, info
         dy, _, infos = _heun_increment(rhs, y_start, t, self.dt)
+        _accept(f)
         return y_start + dy, self.dt, infos[-1]

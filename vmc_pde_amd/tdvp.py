@@ -95,6 +95,7 @@ class TDVP:
             # tdvp.py:87-89: the SNR soft cut-off lives in the eigenbasis of S; a Cholesky factor has none
             raise ValueError("useSNR=True needs the spectral solver (solver='eigh' or 'auto'); the Cholesky path has no eigenbasis")
         self._guard_host = self._guard_event = None
+        self._guard_pending = self._guard_chol = False
         self.cholInfo = None
         self._buf = {}
         self._c_prev = None
@@ -337,9 +338,11 @@ class TDVP:
         return "eigh" if self.solver == "auto" else self.solver
 
     # ---- Cholesky health: pinned pivots and the solver residual ------------------------------------------------------
-    def _record_guard(self, out):
+    def _record_guard(self, out, chol):
         """Queue (residual, pinned-pivot count) of this solve for the host without synchronising: checked by `_check_guard` at
-        the next host-side guard (the NaN check of `__call__`, or the start of the next right-hand side when observables are off)."""
+        the next host-side guard (the NaN check of `__call__`, `check()` -- called by the steppers before a step is accepted --, or
+        the start of the next right-hand side)."""
+        self._guard_chol = chol
         if self._guard_host is None:
             self._guard_host = torch.empty(4, dtype=global_defs.tReal).pin_memory()
             self._guard_event = torch.cuda.Event()
@@ -347,14 +350,27 @@ class TDVP:
         self._guard_event.record()
         self._guard_pending = True
 
+    def check(self, when="this step"):
+        """Wait for the health record of the last solve and raise if it failed (the reference's NaN exit, tdvp.py:136-141, and the
+        Cholesky guard).  `__call__` runs it itself when observables are on; with `observables=False` nothing synchronises with the
+        host inside a call, so the steppers call it before they hand a step back and a driver should call it before writing a
+        checkpoint -- otherwise a failed solve would only be noticed at the start of the next right-hand side (or never, for the
+        last call of a run)."""
+        self._check_guard(when)
+
     def _check_guard(self, when):
         """factor_inverse_32 (csrc/solve.hip) replaces every non-positive / NaN pivot by a unit row and only counts it, so an
-        indefinite or NaN-contaminated S gives a finite but wrong update: fail loudly instead of integrating on."""
+        indefinite or NaN-contaminated S gives a finite but wrong update: fail loudly instead of integrating on.  On the spectral
+        path the record holds the residual |S u - F| / |F|, which is NaN exactly when the update (or S, F) is."""
         if not getattr(self, "_guard_pending", False):
             return
         self._guard_event.synchronize()
         self._guard_pending = False
         resid, pinned = float(self._guard_host[0]), int(self._guard_host[2])
+        if not self._guard_chol:
+            if math.isnan(resid):
+                raise FloatingPointError(f"nan encountered in the TDVP update ({when})")
+            return
         if not (resid <= self.residualBound):      # also catches NaN
             raise FloatingPointError(f"on-device Cholesky failed ({when}): solver residual {resid:.3e} > {self.residualBound:g} with "
                                      f"{pinned} pinned pivot(s); S + shift is not positive definite -- raise diagonalShift / svdTol "
@@ -431,8 +447,7 @@ class TDVP:
                      float(self.diagonalShift) if self.diagonalShift > 1e-10 else 0.0,
                      nat.ptr(self._floor) if (chol and self._floor is not None) else None, nat.ptr(self._scal),
                      nat.ptr(b["info"]) if chol else None, nat.ptr(out), nat.stream())
-            if chol:
-                self._record_guard(out)
+            self._record_guard(out, chol)
         return update, out[0], out[1]
 
     # ---- state carried from call to call (not in the reference, whose calls are independent) ---------------------
@@ -468,8 +483,9 @@ class TDVP:
                 ws = self._obs_ws = torch.zeros(nat.lib().vmcpde_observables_workspace_bytes() // 8, dtype=global_defs.tReal, device=x.device)
             out = torch.empty(d * d + 5 * d + 2, dtype=global_defs.tReal, device=x.device)
             with torch.cuda.device(x.device):
-                nat.call("vmcpde_observables", nat.ptr(x), x.shape[0], d, nat.ptr(lp), nat.ptr(el), nat.ptr(out), nat.ptr(ws), ws.numel() * 8,
-                         nat.stream())
+                # (Eloc keeps the nSamplesTDVP entries of the solve when the samples were re-drawn at nSamplesObs, tdvp.py:130-134,150)
+                nat.call("vmcpde_observables", nat.ptr(x), x.shape[0], d, nat.ptr(lp), nat.ptr(el), el.numel(), nat.ptr(out), nat.ptr(ws),
+                         ws.numel() * 8, nat.stream())
             info["x1"] = out[:d]
             info["covar"] = out[d:d + d * d].reshape(d, d)
             info["entropy"] = out[d * d + 5 * d]
@@ -490,9 +506,11 @@ class TDVP:
         return info
 
     def _ball_samples(self, psi, n, dim):
-        """Uniform points in the unit ball for the small-ball integrals (tdvp.py:152-157).  The reference draws them from
+        """Uniform points in the unit ball (1,n,dim) for the small-ball integrals (tdvp.py:152-157).  The reference draws them from
         `sampler.key`, which every sampler call advances (sampler.py:73): fresh points per call, here from the sampler's key and
-        call count."""
+        call count.  Departure, on purpose: the reference passes the SAME key to `normal` and `uniform` (tdvp.py:154-155), which
+        correlates direction and radius of a point through the shared threefry bits; here the two are independent draws, so the
+        points are exactly uniform in the ball.  Tests inject points by replacing this method on the instance."""
         g = torch.Generator(device=psi.device).manual_seed(int(psi.sampler.key) + 104729 + 7919 * int(getattr(psi.sampler, "_calls", 0)))
         samples = torch.randn((1, n, dim), generator=g, dtype=global_defs.tReal, device=psi.device)
         radius = torch.rand((1, n), generator=g, dtype=global_defs.tReal, device=psi.device)
@@ -544,7 +562,10 @@ class TDVP:
 
         info = self._observables(sampleConfigs, logProbs, Eloc)               # tdvp.py:143-150
 
-        if rhsArgs.get("integrals", True) is not None:                        # tdvp.py:152-162: always evaluated by the reference
+        # tdvp.py:152-162.  The reference evaluates them on every call and ignores the `integrals` keyword its driver passes
+        # (main.py:111,161 -- the published records hold them although `comp_integrals = False`); here they are on by default and
+        # `integrals=False` (or None) switches the three extra flow evaluations off.
+        if rhsArgs.get("integrals", True) not in (None, False):
             dim = sampleConfigs.shape[-1]
             samples = self._ball_samples(psi, nSamplesObs, dim)
             for lim_normal in [1, 0.5, 0.1]:
