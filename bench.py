@@ -28,7 +28,6 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # multi-process GPU
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np
 import torch
@@ -107,11 +106,16 @@ def _timed(fn, reps=2):
     return float(np.median(ts)), float(np.min(ts)), ts
 
 
-def cpu_baseline(theta_cpu, inds_up, inds_down):
+def cpu_baseline(theta_cpu, inds_up, inds_down, workload="C2"):
     """The reference algorithm as written (oracle), timed piecewise on bounded samples -- one warm-up and two timed repetitions
-    per part -- and scaled linearly in N; the autodiff part is timed at two sample counts to show that the
-    scaling it relies on holds."""
+    per part -- and extrapolated to the full step: the autodiff part (vmap(grad) + the Hessian pass) is timed at
+    THREE sample counts and extrapolated along the fitted line t = a + b N (its cost per sample still falls between N = 2048 and
+    4096, so a plain x16 of one point overstates it), the GEMM parts are scaled linearly in N, eigh is timed at the full P for C2.
+    C3 (P = 16 181): autodiff and GEMMs as above; the host eigh of a 16 181 x 16 181 matrix does not fit a benchmark run (SURVEY 8d:
+    "hours"), so it is timed at P/4 and scaled by 4^3 -- labelled as such."""
     from oracle import vmc_oracle as O
+    w = WORKLOADS[workload]
+    dim, hidden, n_full = w["dim"], w["hidden"], w["n_samp"]
     # threads actually used: the cores this process may run on, capped at the GPU box's 16-core share per GPU
     # (an OpenMP pool as wide as the host's 256 hardware threads makes the oracle's many small ops far slower)
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
@@ -121,25 +125,31 @@ def cpu_baseline(theta_cpu, inds_up, inds_down):
         blas_cap = threadpool_limits(limits=cores)
     except ImportError:
         blas_cap = None
-    spec = O.NetSpec(dim=DIM, inds_up=inds_up, inds_down=inds_down, intmediate=HIDDEN, offset=[1.0] * DIM)
+    spec = O.NetSpec(dim=dim, inds_up=inds_up, inds_down=inds_down, intmediate=hidden, offset=list(w["offset"]))
     P = O.num_parameters(spec)
     vo = O.VarStateOracle(spec, theta_cpu)
-    eo = O.EvolutionEquationOracle(DIM, EQ)
-    eo.eqParams[EQ]["params"]["lam"] = LAM
+    eo = O.EvolutionEquationOracle(dim, EQ)
+    eo.eqParams[EQ]["params"]["lam"] = w.get("lam", LAM)
     g = torch.Generator().manual_seed(0)
-    n_gemm = 4096
+    big = P > 8000
+    n_gemm = 2048 if big else 4096
+    ad_counts = (512, 1024, 2048) if big else (1024, 2048, 4096)
 
     # (1) sampling + Eloc + Jacobian: vmap(grad) + the jacrev(jacfwd) Hessian pass (var_state.py:31-32, evolutionEq.py:107-119)
     ad = {}
-    for n_ad in (2048, 4096):
-        z = O.latent_from_normals(spec, theta_cpu, torch.randn(n_ad, DIM, generator=g, dtype=torch.float64))
+    for n_ad in ad_counts:
+        z = O.latent_from_normals(spec, theta_cpu, torch.randn(n_ad, dim, generator=g, dtype=torch.float64))
 
         def autodiff():
             x, _ = vo.flow_sample(z)
             return eo(vo, x, 0.0)
         ad[n_ad] = _timed(autodiff)
-    t_ad, n_ad = ad[4096][0], 4096
-    linearity = ad[4096][0] / (2.0 * ad[2048][0])          # 1.0 = exactly linear in N
+    ns = np.asarray(ad_counts, dtype=np.float64)
+    slope, icpt = np.polyfit(ns, [ad[n][0] for n in ad_counts], 1)
+    slope_min, icpt_min = np.polyfit(ns, [ad[n][1] for n in ad_counts], 1)
+    t_ad_full, t_ad_full_min = icpt + slope * n_full, icpt_min + slope_min * n_full
+    t_ad_naive = ad[ad_counts[-1]][0] * n_full / ad_counts[-1]          # what scaling the largest point alone would give
+    linearity = ad[ad_counts[-1]][0] / (2.0 * ad[ad_counts[-2]][0])      # 1.0 = exactly proportional to N
 
     # (2) tdvp.py:40-47: centred copies, F0, the two un-symmetrised Gram GEMMs (S0, SExp)
     Jg = torch.randn(n_gemm, P, generator=g, dtype=torch.float64)
@@ -155,42 +165,50 @@ def cpu_baseline(theta_cpu, inds_up, inds_down):
     def gram_sexp():
         Ow = Eg[:, None] * keep["Oc"]
         keep["SExp"] = Ow.T @ Ow / n_gemm              # tdvp.py:47
-    t_gram1 = _timed(gram_s0)
-    t_gram2 = _timed(gram_sexp)
+    reps = 1 if big else 2
+    t_gram1 = _timed(gram_s0, reps)
+    t_gram2 = _timed(gram_sexp, reps)
+    keep.pop("SExp", None)
 
-    # (3) tdvp.py:61-64: host eigh at the full P
-    S0np = keep["S0"].numpy()
+    # (3) tdvp.py:61-64: host eigh -- at the full P (C2 / C4), at P/4 scaled by 4^3 for C3
+    p_eigh = P // 4 if big else P
+    S0np = np.ascontiguousarray(keep["S0"].numpy()[:p_eigh, :p_eigh])
 
     def eigh():
         keep["ev"], keep["V"] = np.linalg.eigh(S0np)
-    t_eigh = _timed(eigh)
+    t_eigh_meas = _timed(eigh, reps)
+    eigh_scale = (P / p_eigh) ** 3
+    t_eigh = tuple(v * eigh_scale for v in t_eigh_meas[:2])
 
-    # (4) tdvp.py:68-70: EO @ V and its variance
-    Vt = torch.from_numpy(keep["V"])
+    # (4) tdvp.py:68-70: EO @ V and its variance (C3: a random orthogonal-sized V stands in for the eigenvectors of the full matrix)
+    Vt = torch.from_numpy(keep["V"]) if not big else torch.randn(P, P, generator=g, dtype=torch.float64)
 
     def eov():
         keep["rho"] = (keep["EO"] @ Vt).var(0)
-    t_eov = _timed(eov)
+    t_eov = _timed(eov, reps)
     if blas_cap is not None:
         blas_cap.restore_original_limits()
 
-    scale_ad, scale_gemm = N_SAMP / n_ad, N_SAMP / n_gemm
-    total = t_ad * scale_ad + (t_gram1[0] + t_gram2[0] + t_eov[0]) * scale_gemm + t_eigh[0]
-    total_min = ad[4096][1] * scale_ad + (t_gram1[1] + t_gram2[1] + t_eov[1]) * scale_gemm + t_eigh[1]
-    fair = t_ad * scale_ad + t_gram1[0] * scale_gemm + t_eigh[0]     # one Gram, no SExp, no EO@V
-    return {"value": 1.0 / total, "unit": "TDVP steps/s", "cores": cores, "kind": "port",
-            "sample": (f"reference algorithm as written on torch/numpy fp64 CPU, each part 1 warm-up + 2 timed repetitions (median): "
-                       f"autodiff J + Hessian at N={n_ad} (x{int(scale_ad)}; N=2048 -> 4096 scales by {2 * linearity:.2f}), S0 and SExp Gram GEMMs "
-                       f"+ EO@V at N={n_gemm} (x{int(scale_gemm)}), eigh at the full P={P}; parts {t_ad:.2f}s / {t_gram1[0] + t_gram2[0]:.2f}s / "
-                       f"{t_eov[0]:.2f}s / {t_eigh[0]:.2f}s -> {total:.1f}s per 65536-sample step (extrapolated)"),
+    scale_gemm = n_full / n_gemm
+    total = t_ad_full + (t_gram1[0] + t_gram2[0] + t_eov[0]) * scale_gemm + t_eigh[0]
+    total_min = t_ad_full_min + (t_gram1[1] + t_gram2[1] + t_eov[1]) * scale_gemm + t_eigh[1]
+    fair = t_ad_full + t_gram1[0] * scale_gemm + t_eigh[0]     # one Gram, no SExp, no EO@V
+    eigh_note = (f"eigh at the full P={P}" if not big else
+                 f"eigh NOT RUN at P={P}: timed at P/4={p_eigh} ({t_eigh_meas[0]:.1f}s) and scaled by (P/{p_eigh})^3 = {eigh_scale:.0f}")
+    return {"value": 1.0 / total, "unit": "TDVP steps/s", "cores": cores, "kind": "port", "workload": workload,
+            "sample": (f"reference algorithm as written on torch/numpy fp64 CPU, each part 1 warm-up + {reps} timed repetition(s) (median): "
+                       f"autodiff J + Hessian at N={list(ad_counts)} -> fitted line {icpt:.2f}s + {slope * 1e3:.3f}ms/sample -> {t_ad_full:.1f}s at "
+                       f"N={n_full} (scaling the largest point alone would give {t_ad_naive:.1f}s), S0 and SExp Gram GEMMs + EO@V at N={n_gemm} "
+                       f"(x{int(scale_gemm)}), {eigh_note}; parts {t_ad_full:.1f}s / {(t_gram1[0] + t_gram2[0]) * scale_gemm:.1f}s / "
+                       f"{t_eov[0] * scale_gemm:.1f}s / {t_eigh[0]:.1f}s -> {total:.1f}s per {n_full}-sample step (extrapolated)"),
             "seconds_per_step_extrapolated": total, "seconds_per_step_extrapolated_min": total_min,
-            "parts_seconds": {"autodiff_N2048": {"median": ad[2048][0], "min": ad[2048][1]},
-                              "autodiff_N4096": {"median": ad[4096][0], "min": ad[4096][1]},
-                              "gram_S0_N4096": {"median": t_gram1[0], "min": t_gram1[1]},
-                              "gram_SExp_N4096": {"median": t_gram2[0], "min": t_gram2[1]},
-                              "eigh_full_P": {"median": t_eigh[0], "min": t_eigh[1]},
-                              "EO_at_V_N4096": {"median": t_eov[0], "min": t_eov[1]}},
-            "autodiff_linearity_2048_to_4096": linearity,
+            "parts_seconds": {**{f"autodiff_N{n}": {"median": ad[n][0], "min": ad[n][1]} for n in ad_counts},
+                              f"gram_S0_N{n_gemm}": {"median": t_gram1[0], "min": t_gram1[1]},
+                              f"gram_SExp_N{n_gemm}": {"median": t_gram2[0], "min": t_gram2[1]},
+                              f"eigh_P{p_eigh}": {"median": t_eigh_meas[0], "min": t_eigh_meas[1]},
+                              f"EO_at_V_N{n_gemm}": {"median": t_eov[0], "min": t_eov[1]}},
+            "autodiff_fit": {"intercept_s": float(icpt), "slope_s_per_sample": float(slope), "full_step_s": float(t_ad_full),
+                             "largest_point_scaled_s": float(t_ad_naive), "ratio_last_two_points_over_2": float(linearity)},
             "fair_variant": {"value": 1.0 / fair, "unit": "TDVP steps/s",
                              "what": "same port without the reference's redundant work (one centred Gram GEMM, no SExp, no EO@V)"},
             "note": "an eager torch.func port of the reference's algorithm, not XLA-jitted JAX-CPU (jax is not installable here): "
@@ -240,8 +258,8 @@ def main():
     n_total = args.samples * world
     kwargs = dict(evolutionEq=eq, psi=vs, nSamplesTDVP=n_total, nSamplesObs=n_total, timings=None, observables=False)
 
-    gram_events = []
-    tdvp._event_hook = lambda a, b: gram_events.append((a, b))
+    stage_events = {}
+    tdvp._event_hook = lambda name, a, b: stage_events.setdefault(name, []).append((a, b))
 
     def barrier():
         if world > 1:
@@ -251,7 +269,7 @@ def main():
     for _ in range(args.warmup):
         tdvp(theta, 0.0, **kwargs)
     barrier()
-    gram_events.clear()
+    stage_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         update, _ = tdvp(theta, 0.0, **kwargs)
@@ -264,7 +282,21 @@ def main():
     assert torch.isfinite(update).all(), "non-finite TDVP update"
     resid = float(tdvp.solverResidual)
 
-    gram_ms = float(np.mean([a.elapsed_time(b) for a, b in gram_events])) if gram_events else float("nan")
+    # HIP-event brackets on the launch stream inside the timed steps, averaged over the steps: what this rank spent in its shard's
+    # flow kernels and Gram, in the step's one collective (waiting for the slowest rank included) and in the replicated part
+    # (finalize + Cholesky + substitution + diagnostics)
+    mine = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in stage_events.items()}
+    gram_ms = mine.get("gram", float("nan"))
+    order = ["sample+flow", "gram", "allreduce", "replicated"]
+    per_rank = [[mine.get(k, float("nan")) for k in order]]
+    if world > 1:
+        t_st = torch.tensor(per_rank[0], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        gathered = [torch.empty_like(t_st) for _ in range(world)]
+        dist.all_gather(gathered, t_st)
+        per_rank = [[float(v) for v in g.cpu()] for g in gathered]
+    from vmc_pde_amd import _native as nat
+    npk = nat.lib().vmcpde_gram_packed_doubles(P)
+    payload_bytes = int((npk + 2 * P + 4) * 8)
 
     # outside the timed region: per-stage wall times with a device sync at each section boundary (the reference's
     # timing sections, tdvp.py:116-128), and one Heun integrator step = 2 TDVP steps (stepper.py:135-137)
@@ -323,9 +355,12 @@ def main():
                          "algorithmic_flops_per_launch": flops, "measured_mfma_f64_peak": peak_meas,
                          "frac_of_measured_peak": achieved / peak_meas if peak_meas > 0 else None},
             "stages_ms": stage_ms, "heun_step_ms": heun_ms,
+            # per-rank HIP-event averages over the timed steps (ms): the Amdahl terms of the multi-GPU step
+            "rank_stage_ms": [dict(zip(order, r)) for r in per_rank],
+            "allreduce_payload_bytes": payload_bytes,
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload == "C2" and args.samples == N_SAMP:
-            line["cpu_baseline"] = cpu_baseline(theta.cpu(), vs.net.inds_up, vs.net.inds_down)
+        if world == 1 and not args.no_cpu_baseline and args.samples == WORKLOADS[args.workload]["n_samp"]:
+            line["cpu_baseline"] = cpu_baseline(theta.cpu(), vs.net.inds_up, vs.net.inds_down, args.workload)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -114,18 +114,22 @@ def main():
     vo = O.VarStateOracle(spec, th0)
     eo = make_eq(dim, "diffusion")
     to = O.TDVPOracle()
-    zs = []
+    zs, stage_in, stage_out, stage_F = [], [], [], []
 
     def f(y, t, k):
         z = O.latent_from_normals(spec, y, nrm[k])       # the latent draw depends on theta (mu, L) -- sampler.py:86
         zs.append(z.numpy())
         u, _ = to.rhs(y, t, vo, eo, z)
+        stage_in.append(y.numpy().copy())                # the state each stage is evaluated at, its update and its force
+        stage_out.append(u.numpy().copy())
+        stage_F.append(to.F0.numpy().copy())
         return u, None
 
     dt = O.fixed_stepper_dt(1e-5, 1.3, 1e-4)       # FixedStepper(timeStep=1e-5, increase_fac=1.3, maxStep=1e-4)
     th1, _ = O.heun_step(f, th0, 0.0, dt)
     np.savez_compressed(os.path.join(HERE, "oracle_heun_step.npz"), theta0=th0.numpy(), theta1=th1.numpy(), dt=np.float64(dt),
                         normals0=nrm[0].numpy(), normals1=nrm[1].numpy(), z0=zs[0], z1=zs[1],
+                        stage_theta=np.stack(stage_in), stage_update=np.stack(stage_out), stage_F=np.stack(stage_F),
                         inds_up=np.asarray(spec.inds_up, dtype=np.int32), inds_down=np.asarray(spec.inds_down, dtype=np.int32),
                         offset=np.asarray(spec.offset))
     print("oracle_heun_step.npz: |theta1-theta0| =", float(torch.linalg.norm(th1 - th0)))

@@ -92,11 +92,19 @@ def test_gaussian_diffusion_d8_matches_published_trajectory():
     # (tests/test_oracle_published_run.py).  This run's record n belongs to the predictor state at times[n] + dt (see above).
     from scipy.stats import chi2
     t2 = run["times"] + run["dt"]
-    for lim, key, tol in ((1.0, "integral_1sigma", 0.08), (0.5, "integral_05sigma", 0.04), (0.1, "integral_01sigma", 0.03)):
-        exact = chi2.cdf(10.0 * lim ** 2 / (1 + 2 * t2), 8)
-        dev = run[key] / exact - 1
-        assert np.abs(dev).max() < tol and np.abs(dev[:30]).max() < tol / 4, (key, np.abs(dev).max(), np.abs(dev[:30]).max())
-        assert np.abs(run[key][:-1] / ref[key][1:] - 1).max() < 1.5 * tol, key          # record n here ~ published record n + 1
+    # Yardstick, as for the entropy above: the published run's own largest deviation from the exact curve (2.4e-2 / 3.9e-3 / 1.5e-4:
+    # Monte-Carlo error of 10^4 ball points plus that run's model error) -- this run must stay within 3x of it, plus what the Euler
+    # predictor itself is off by: its state is first-order accurate over the step, log p(0) = -(d/2) log(2 pi s^2) moves by
+    # (d/2) eps with eps = 2 dt / s^2 and the predictor misses the curvature term (d/2) eps^2 / 2 -- 8e-4 at dt = 1e-2, s^2 ~ 1,
+    # which is what the 0.1-sigma integral (~ p(0) x volume) shows (measured 7.5e-4 against 1.5e-4 for the published first-stage
+    # record; the larger balls are dominated by the Monte-Carlo error: 2.3e-2 / 4.4e-3 against 2.4e-2 / 3.9e-3).
+    predictor = 0.5 * 8 * (2 * run["dt"] / (1 + 2 * run["times"])) ** 2          # twice the curvature term
+    for lim, key in ((1.0, "integral_1sigma"), (0.5, "integral_05sigma"), (0.1, "integral_01sigma")):
+        dev_pub = np.abs(ref[key] / chi2.cdf(10.0 * lim ** 2 / (1 + 2 * ref["times"]), 8) - 1).max()
+        dev = np.abs(run[key] / chi2.cdf(10.0 * lim ** 2 / (1 + 2 * t2), 8) - 1)
+        print(f"{key}: largest deviation from the exact curve {dev.max():.2e} (published run {dev_pub:.2e}), mean {dev.mean():.2e}")
+        assert np.all(dev < 3.0 * dev_pub + predictor), (key, dev.max(), dev_pub)
+        assert np.all(np.abs(run[key][:-1] / ref[key][1:] - 1) < 4.0 * dev_pub + predictor[:-1]), key   # record n here ~ published record n + 1
     # central moments of a Gaussian of variance s^2 = 1 + 2t: x4 = 3 s^4, x6 = 15 s^6 (10^4 samples: ~3 % / ~10 % standard error)
     s2 = 1 + 2 * t2
     assert np.abs(run["x4"].mean(1) / (3 * s2 ** 2) - 1).max() < 0.08 and np.abs(ref["x4"].mean(1) / (3 * (1 + 2 * ref["times"]) ** 2) - 1).max() < 0.08
@@ -129,7 +137,7 @@ def test_student_t_diffusion_d8_follows_published_nu():
     assert abs(float(run["err0"]) - ref["tdvp_error"][0]) < 0.03
     nu_ref = np.exp(ref["dist_params"][:n]) + 1                                      # recorded after each step (main.py:162,190), as in _run
     assert np.abs(run["nu"] / nu_ref - 1).max() < 0.015, np.abs(run["nu"] / nu_ref - 1).max()
-    assert run["nu"][-1] > 2.4                                                       # 2.00 -> 2.52 over these steps in the published run
+    assert abs(nu_ref[-1] - 2.52) < 0.005 and abs(run["nu"][-1] / 2.52 - 1) < 0.02   # 2.00 -> 2.52 over these steps in the published run: two-sided band
     # the ansatz cannot follow this flow exactly: the published TDVP error is 0.22 -> 0.11 over these steps
     assert np.all(run["tdvp_error"] < 2 * ref["tdvp_error"][:n] + 0.02) and np.all(run["tdvp_error"] > 0.4 * ref["tdvp_error"][:n])
 

@@ -136,3 +136,72 @@ def test_world_size_2_gloo_sharding_and_single_allreduce():
     assert (rk0, rk1, cs0, cs1) == (0, 1, 2, 2) and ok0 and ok1
     for r in range(2):
         assert O.distribute_sampling(10001, 2, r)[0] == (per0, per1)[r]
+
+
+def _worker8(rank, world, port, q):
+    """One of eight ranks of a ragged sample count: shard sizes / offsets (mpi_wrapper.py:68-126) and the packed-buffer algebra of a
+    TDVP step -- every rank contributes shifted partial sums about a COMMON lagged shift, ONE all-reduce, and the replicated
+    finalize recovers the exactly centred (S0, F0, Eloc statistics) of tdvp.py:37-46."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vmc_pde_amd import mpi_wrapper as mpi
+    n, P = 10003, 9                                   # 10003 = 8 * 1250 + 3: three ranks hold one sample more
+    per = mpi.distribute_sampling(n)
+    first = mpi.first_sample_id(n)
+    rng = np.random.default_rng(11)                    # every rank generates the same global batch and takes its shard
+    J = rng.standard_normal((n, P)) * 2 + 5 * rng.standard_normal(P)
+    E = rng.standard_normal(n) + 3
+    c, cE = J[:50].mean(0), E[:50].mean()              # the previous call's means: any common shift works
+    Jm, Em = J[first:first + per] - c, E[first:first + per]
+    pack = torch.as_tensor(np.concatenate([(Jm.T @ Jm).reshape(-1), Jm.sum(0), (Jm * (Em - cE)[:, None]).sum(0),
+                                           [Em.sum(), (Em ** 2).sum(), np.abs(Em).sum()], [float(per)]]))
+    n_payload = pack.numel()
+    mpi.allreduce_sum_(pack)                           # the step's single collective
+    p = pack.numpy()
+    G, rs, rd = p[:P * P].reshape(P, P), p[P * P:P * P + P], p[P * P + P:P * P + 2 * P]
+    sE, sE2, sAbs, cnt = p[P * P + 2 * P:]
+    delta, dE = rs / cnt, sE / cnt - cE
+    S0, F0 = G / cnt - np.outer(delta, delta), rd / cnt - delta * dE
+    Oc, Ec = J - J.mean(0), E - E.mean()
+    ok = (cnt == n and np.allclose(S0, Oc.T @ Oc / n, rtol=1e-12, atol=1e-12) and np.allclose(F0, (Ec[:, None] * Oc).mean(0), rtol=1e-11, atol=1e-12)
+          and np.allclose(c + delta, J.mean(0), rtol=1e-13) and abs(sE / cnt - E.mean()) < 1e-13
+          and abs(sE2 / cnt - (sE / cnt) ** 2 - E.var()) < 1e-12 and abs(sAbs / cnt - np.abs(E).mean()) < 1e-13)
+    # MCMC branch: whole sweeps of localDevices * chains on every rank (mpi_wrapper.py:87-110)
+    sweeps = mpi.distribute_sampling(n, localDevices=1, numChainsPerDevice=30)
+    q.put((rank, per, first, sweeps, mpi.globNumSamples, n_payload, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_world_size_8_gloo_ragged_shards_and_packed_buffer_algebra():
+    """The eight-rank layout of BASELINE config C4 (samples sharded over 8 GPUs, one all-reduce per step), rehearsed over gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 8
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    pers, firsts = [r[1] for r in res], [r[2] for r in res]
+    assert pers == [1251, 1251, 1251, 1250, 1250, 1250, 1250, 1250] and sum(pers) == 10003
+    assert firsts == [int(v) for v in np.concatenate([[0], np.cumsum(pers)[:-1]])]
+    for r in range(world):
+        n_or, glob_or = O.distribute_sampling(10003, world, r)[0], O.distribute_sampling(10003, world, r, 1, 30)
+        assert n_or == pers[r] and res[r][3] == glob_or[0] and res[r][4] == glob_or[1]
+        assert res[r][6], f"rank {r}: packed-buffer algebra failed"
+    assert res[0][5] == 9 * 9 + 2 * 9 + 4
+
+
+def test_allreduce_payload_of_a_c4_step(lib_built):
+    """The one collective of a step moves [Gram tiles | sum O | sum E~O | sum E, E^2, |E| | n]: 73.6 MB at
+    P = 4155 / 4213 (both 33 tile rows), 1.05 GB at P = 16181 -- the sizes bench.py reports as `allreduce_payload_bytes`."""
+    from vmc_pde_amd import _native as nat
+    for P, nb in ((4155, 33), (4213, 33), (16181, 127)):
+        npk = nat.lib().vmcpde_gram_packed_doubles(P)
+        assert npk == nb * (nb + 1) // 2 * 128 * 128
+        payload = (npk + 2 * P + 4) * 8
+        assert payload == {4155: 73_597_904, 4213: 73_598_832, 16181: 1_065_612_144}[P]

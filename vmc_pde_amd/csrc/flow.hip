@@ -40,6 +40,12 @@ namespace {
 #define VMC_FLOW_UNROLL 1            // input units per trip of the dense-layer loops.  Measured (tools/diag/flow_unroll_ab.sh): unrolling by 2 / 3,
                                      // i.e. the LDS reads of several units in flight together, is 3-5 % SLOWER on C2 / C3 / C4
 #endif
+#ifndef VMC_FLOW_EPS_REGS
+#define VMC_FLOW_EPS_REGS 1          // reverse sweep: eps of a wave's input units in registers (0: an LDS line, the round-2 form)
+#endif
+#ifndef VMC_FLOW_MIN_BLOCKS
+#define VMC_FLOW_MIN_BLOCKS 1        // __launch_bounds__ second argument of flow_eval_kernel (2 caps the kernel at 128 VGPRs)
+#endif
 constexpr int JB = VMC_FLOW_JB;  // output block held in registers by the dense-layer loops (measured: 6 x up-to-8 waves is the best compromise over C2/C3/C4)
 constexpr int MAX_WAVES = VMC_FLOW_MAX_WAVES;
 
@@ -59,6 +65,8 @@ struct Regions {
   int GAM;  // input gradient of the MLPs (d)
   int Y, Q; // whitened residual y = U^-1 r and q = U^-T y (d each)
   int cs;   // component stride of A/B = widest layer
+  int inplace;  // Taylor / value MLP passes write a layer's outputs over its inputs (one output block per wave: registers hold
+                // the block across the barrier that separates the last read from the first write) -- no second buffer B
   int total;
   int wgt;  // doubles of the workgroup-shared weight stage behind the per-lane vectors (kernels + biases of ALL layers of one MLP)
 };
@@ -74,6 +82,7 @@ Regions make_regions_values(const FlowProgram& fp) {
   r.B = u; u += W;
   r.SOUT = u; u += d;
   r.LAT = u; u += d;
+  r.inplace = 0;
   r.total = u;
   r.wgt = fp.stage_all ? fp.all_mlp_weights : fp.max_mlp_weights;
   return r;
@@ -82,31 +91,40 @@ Regions make_regions_values(const FlowProgram& fp) {
 // kdirs: Hessian directions carried by one forward Taylor pass (1 + 2 kdirs components: value, then first and second derivative
 // along each direction)
 Regions make_regions(const FlowProgram& fp, int kdirs = 1) {
+  // Round 3 plan: what bounds flow_eval is how many workgroups are resident per CU, i.e. this footprint (C2: 146 units = 75 KB per 64
+  // samples -> two workgroups per CU; now 82 units = 42 KB -> three).  (i) Taylor phase: in-place layer buffers (no B) whenever
+  // every wave owns at most one output block; the latent line aliases the then idle MLP buffer; the s stash exists only for
+  // different_add.  (ii) reverse phase: the cotangent of a layer's inputs overwrites those inputs in ACT (its owner is the only
+  // reader of both), so the delta ping-pong is gone; Y / Q of the latent adjoint alias DEL0 / GAM, which are written later.
   Regions r;
   const int d = fp.dim, W = fp.max_width, nc = 1 + 2 * kdirs;
+  const bool diff_add = (fp.coupling == VMCPDE_COUPLING_DIFFERENT_ADD);
   r.cs = W;
+  r.inplace = ((W + JB - 1) / JB <= MAX_WAVES && env_int("VMCPDE_FLOW_INPLACE", 1)) ? 1 : 0;
   int u = 0;
   r.X = u; u += nc * d;
   r.G = u; u += d;
   const int base = u;
   // Taylor phase
   r.A = u; u += nc * W;
-  r.B = u; u += nc * W;
-  r.SOUT = u; u += nc * d;
-  r.LAT = u; u += nc * d;
+  if (r.inplace) r.B = r.A;
+  else { r.B = u; u += nc * W; }
+  r.SOUT = u; if (diff_add) u += nc * d;
+  if (W >= d) r.LAT = r.A;                 // (latent_forward runs after the last MLP pass)
+  else { r.LAT = u; u += nc * d; }
   const int end_taylor = u;
   // reverse phase
   u = base;
   r.ACT = u; u += fp.max_sum_act;
   r.OUTS = u; u += d;
-  r.OUTT = u; u += d;
+  r.OUTT = u; if (diff_add) u += d;
   r.DW = u; u += d;
-  r.DEL0 = u; u += W;
-  r.DEL1 = u; u += W;
-  r.EPS = u; u += W;
+  r.DEL0 = u; u += d;                      // cotangent of the MLP's output pre-activations (n_out <= d)
+  r.DEL1 = r.DEL0;                         // (unused since round 3: deltas of hidden layers live in ACT)
+  r.EPS = u; if (!(VMC_FLOW_EPS_REGS && r.inplace)) u += W;       // (inplace plans keep eps in registers, see mlp_backward)
   r.GAM = u; u += d;
-  r.Y = u; u += d;
-  r.Q = u; u += d;
+  r.Y = r.DEL0;
+  r.Q = r.GAM;
   r.total = (u > end_taylor) ? u : end_taylor;
   r.wgt = fp.stage_all ? fp.all_mlp_weights : fp.max_mlp_weights;
   return r;
@@ -271,49 +289,65 @@ __device__ __forceinline__ void stage_all_networks(const Ctx& c) {
 // y = tanh-layer(x): z_j = b_j + sum_i W[i][j] a_i (net.py:55-61), with NC Taylor components.
 // Cooperative: the input must be visible to all waves on entry; the caller synchronises before the output is read.
 template <int NC>
-__device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, int woff, int uin, int uout, int cs, double scale, int wofs = -1) {
+__device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, int woff, int uin, int uout, int cs, double scale, int wofs = -1,
+                                            bool inplace = false) {
+  // inplace (uout == uin; every wave owns at most ONE output block): the block is finished in registers, a barrier waits for the
+  // last reader of the inputs, then the outputs overwrite them.  Every wave makes exactly one trip so that all reach the barrier.
   const int n_in = L.n_in, n_out = L.n_out;
   const double* __restrict__ W = c.wl + woff;           // staged by the caller (stage_weights + barrier)
   const double* __restrict__ Bv = W + n_in * n_out;
-  for (int j0 = c.wave * JB; j0 < n_out; j0 += c.nw * JB) {     // output blocks round-robin over the waves
+  for (int j0 = c.wave * JB; inplace ? (j0 == c.wave * JB) : (j0 < n_out); j0 += c.nw * JB) {     // output blocks round-robin over the waves
     double acc[NC][JB];
-#pragma unroll
-    for (int jj = 0; jj < JB; ++jj) {
-      acc[0][jj] = (j0 + jj < n_out) ? Bv[j0 + jj] : 0.0;
-#pragma unroll
-      for (int cc = 1; cc < NC; ++cc) acc[cc][jj] = 0.0;
-    }
-#pragma unroll VMC_FLOW_UNROLL
-    for (int i = 0; i < n_in; ++i) {
-      double a[NC];
-#pragma unroll
-      for (int cc = 0; cc < NC; ++cc) a[cc] = LD(uin + cc * cs + i);
-      const double* __restrict__ wr = W + i * n_out + j0;
+    const bool has = j0 < n_out;
+    if (has) {
 #pragma unroll
       for (int jj = 0; jj < JB; ++jj) {
-        const double w = wr[jj];                              // (unconditional: see stage_weights)
+        acc[0][jj] = (j0 + jj < n_out) ? Bv[j0 + jj] : 0.0;
 #pragma unroll
-        for (int cc = 0; cc < NC; ++cc) acc[cc][jj] = fma(w, a[cc], acc[cc][jj]);
+        for (int cc = 1; cc < NC; ++cc) acc[cc][jj] = 0.0;
       }
-    }
+#pragma unroll VMC_FLOW_UNROLL
+      for (int i = 0; i < n_in; ++i) {
+        double a[NC];
 #pragma unroll
-    for (int jj = 0; jj < JB; ++jj) {
-      if (j0 + jj < n_out) {
-        #ifdef VMC_FLOW_OCML_TANH
+        for (int cc = 0; cc < NC; ++cc) a[cc] = LD(uin + cc * cs + i);
+        const double* __restrict__ wr = W + i * n_out + j0;
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+          const double w = wr[jj];                              // (unconditional: see stage_weights)
+#pragma unroll
+          for (int cc = 0; cc < NC; ++cc) acc[cc][jj] = fma(w, a[cc], acc[cc][jj]);
+        }
+      }
+      // activation and its Taylor coefficients, in registers
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) {
+#ifdef VMC_FLOW_OCML_TANH
         const double h = tanh(acc[0][jj]);
 #else
         const double h = fast_tanh(acc[0][jj]);
 #endif
-        LD(uout + j0 + jj) = scale * h;
-        if (wofs >= 0 && c.act_store) c.actw[(int64_t)(wofs + j0 + jj) * c.ldw + c.samp_st] = scale * h;
+        acc[0][jj] = scale * h;
         if (NC > 1) {
           const double hp = 1.0 - h * h;
 #pragma unroll
           for (int kd = 0; kd < (NC - 1) / 2; ++kd) {           // first / second derivative along direction kd
             const double z1 = acc[2 * kd + 1][jj], z2 = acc[2 * kd + 2][jj];
-            LD(uout + (2 * kd + 1) * cs + j0 + jj) = scale * hp * z1;
-            LD(uout + (2 * kd + 2) * cs + j0 + jj) = scale * hp * (z2 - 2.0 * h * z1 * z1);
+            acc[2 * kd + 1][jj] = scale * hp * z1;
+            acc[2 * kd + 2][jj] = scale * hp * (z2 - 2.0 * h * z1 * z1);
           }
+        }
+      }
+    }
+    if (inplace) SYNC();
+    if (has) {
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) {
+        if (j0 + jj < n_out) {
+          LD(uout + j0 + jj) = acc[0][jj];
+          if (wofs >= 0 && c.act_store) c.actw[(int64_t)(wofs + j0 + jj) * c.ldw + c.samp_st] = acc[0][jj];
+#pragma unroll
+          for (int cc = 1; cc < NC; ++cc) LD(uout + cc * cs + j0 + jj) = acc[cc][jj];
         }
       }
     }
@@ -325,13 +359,14 @@ __device__ __forceinline__ void dense_layer(const Ctx& c, const DenseLayer& L, i
 // order), then the outputs -- the order mlp_load_activations reads them back in.
 template <int NC>
 __device__ __forceinline__ int mlp_forward(const Ctx& c, const Trafo& T, int uA, int uB, int cs, int wofs = -1) {
+  const bool inplace = (uA == uB);          // Regions::inplace: no second buffer
   int cur = uA, nxt = uB;
   int wl = wofs, woff = stage_base(c, T);
   stage_weights(c, T);
   SYNC();                                   // (also orders the previous user's reads of the stage before this write: every pass ends with a barrier)
   FSTAMP(3);
   for (int k = 0; k < T.n_layers; ++k) {
-    dense_layer<NC>(c, T.layer[k], woff, cur, nxt, cs, (k == T.n_layers - 1) ? c.fp->alpha : 1.0, wl);
+    dense_layer<NC>(c, T.layer[k], woff, cur, nxt, cs, (k == T.n_layers - 1) ? c.fp->alpha : 1.0, wl, inplace);
     FSTAMP(1);
     SYNC();
     FSTAMP(4);
@@ -600,7 +635,8 @@ __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const
     }
   }
   int in_off = T.n_in + T.sum_hidden;  // one past the last layer input
-  int cur = r.DEL0, nxt = r.DEL1;
+  int cur = r.DEL0;                    // cotangent of this layer's output pre-activations: DEL0 for the output layer, then the ACT
+                                       // segment of the layer above (overwritten in place by its owner waves, see below)
   for (int k = nl - 1; k >= 0; --k) {
     const DenseLayer& L = T.layer[k];
     const int n_in = L.n_in, n_out = L.n_out;
@@ -609,35 +645,75 @@ __device__ __forceinline__ void mlp_backward(const Ctx& c, const Trafo& T, const
     if (k == nl - 1) SYNC();                  // publishes wave 0's DEL0 (and the weights if they were staged here); later layers
                                               // start behind the barrier that closed the previous one
     const double* __restrict__ W = c.wl + stage_base(c, T) + layer_woff(T, k);
-    for (int i = c.wave; i < n_in; i += c.nw) LD(r.EPS + i) = 0.0;
-    for (int j0 = 0, blk = 0; j0 < n_out; j0 += JB, ++blk) {
-      double dl[JB];
+    if (VMC_FLOW_EPS_REGS && r.inplace) {
+      // eps_i = sum_j W[i][j] delta_j of this wave's input units i = wave + m * nw in REGISTERS: n_in <= JB * nw whenever the plan
+      // is "inplace" (one output block per wave), so m < JB -- no EPS line in LDS and no read-modify-write through it
+      double e[JB];
 #pragma unroll
-      for (int jj = 0; jj < JB; ++jj) dl[jj] = (j0 + jj < n_out) ? LD(cur + j0 + jj) : 0.0;
-      const int nj = (n_out - j0 < JB) ? (n_out - j0) : JB;
-      if (JT != nullptr && active && (blk % c.nw) == c.wave) jt_store_block(c, JT, L.off_bias + j0, nj, dl, 1.0);
-      for (int i = c.wave; i < n_in; i += c.nw) {
-        const double a = LD(uin + i);
-        const double* __restrict__ wr = W + i * n_out + j0;
-        double e = 0.0;
+      for (int m = 0; m < JB; ++m) e[m] = 0.0;
+      for (int j0 = 0, blk = 0; j0 < n_out; j0 += JB, ++blk) {
+        double dl[JB];
 #pragma unroll
-        for (int jj = 0; jj < JB; ++jj) {
-          const double w = (j0 + jj < n_out) ? wr[jj] : 0.0;
-          e = fma(w, dl[jj], e);
+        for (int jj = 0; jj < JB; ++jj) dl[jj] = (j0 + jj < n_out) ? LD(cur + j0 + jj) : 0.0;
+        const int nj = (n_out - j0 < JB) ? (n_out - j0) : JB;
+        if (JT != nullptr && active && (blk % c.nw) == c.wave) jt_store_block(c, JT, L.off_bias + j0, nj, dl, 1.0);
+#pragma unroll
+        for (int m = 0; m < JB; ++m) {
+          const int i = c.wave + m * c.nw;
+          if (i < n_in) {
+            const double a = LD(uin + i);
+            const double* __restrict__ wr = W + i * n_out + j0;
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) e[m] = fma(wr[jj], dl[jj], e[m]);      // (dl is 0 beyond n_out; the stage has JB doubles of slack)
+            if (JT != nullptr && active) jt_store_block(c, JT, L.off_kernel + i * n_out + j0, nj, dl, a);
+          }
         }
-        LD(r.EPS + i) += e;
-        if (JT != nullptr && active) jt_store_block(c, JT, L.off_kernel + i * n_out + j0, nj, dl, a);
       }
-    }
-    if (k > 0) {
-      for (int i = c.wave; i < n_in; i += c.nw) {
-        const double a = LD(uin + i);
-        LD(nxt + i) = (1.0 - a * a) * LD(r.EPS + i);
+#pragma unroll
+      for (int m = 0; m < JB; ++m) {
+        const int i = c.wave + m * c.nw;
+        if (i < n_in) {
+          if (k > 0) {
+            // delta of the layer below = tanh'(its output) * eps, written OVER that output a_i: wave w is the only reader of a_i
+            // for its i = w, w + nw, ..., and the layer below reads this segment only as its output cotangent
+            const double a = LD(uin + i);
+            LD(uin + i) = (1.0 - a * a) * e[m];
+          } else {
+            LD(r.GAM + i) += e[m];
+          }
+        }
       }
-      const int t = cur; cur = nxt; nxt = t;
     } else {
-      for (int i = c.wave; i < n_in; i += c.nw) LD(r.GAM + i) += LD(r.EPS + i);
+      for (int i = c.wave; i < n_in; i += c.nw) LD(r.EPS + i) = 0.0;
+      for (int j0 = 0, blk = 0; j0 < n_out; j0 += JB, ++blk) {
+        double dl[JB];
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) dl[jj] = (j0 + jj < n_out) ? LD(cur + j0 + jj) : 0.0;
+        const int nj = (n_out - j0 < JB) ? (n_out - j0) : JB;
+        if (JT != nullptr && active && (blk % c.nw) == c.wave) jt_store_block(c, JT, L.off_bias + j0, nj, dl, 1.0);
+        for (int i = c.wave; i < n_in; i += c.nw) {
+          const double a = LD(uin + i);
+          const double* __restrict__ wr = W + i * n_out + j0;
+          double e = 0.0;
+#pragma unroll
+          for (int jj = 0; jj < JB; ++jj) {
+            const double w = (j0 + jj < n_out) ? wr[jj] : 0.0;
+            e = fma(w, dl[jj], e);
+          }
+          LD(r.EPS + i) += e;
+          if (JT != nullptr && active) jt_store_block(c, JT, L.off_kernel + i * n_out + j0, nj, dl, a);
+        }
+      }
+      if (k > 0) {
+        for (int i = c.wave; i < n_in; i += c.nw) {
+          const double a = LD(uin + i);
+          LD(uin + i) = (1.0 - a * a) * LD(r.EPS + i);
+        }
+      } else {
+        for (int i = c.wave; i < n_in; i += c.nw) LD(r.GAM + i) += LD(r.EPS + i);
+      }
     }
+    if (k > 0) cur = uin;
     SYNC();
   }
 }
@@ -747,7 +823,7 @@ __device__ __forceinline__ void latent_backward(const Ctx& c, const LatentCache*
 // configuration of BASELINE); narrow networks take KD = 2 or 4, which shares the value component and the weight reads of a
 // pass among the directions (d = 8 diffusion: 2 passes instead of 8) -- chosen by vmcpde_flow_eval.
 template <int KD>
-__global__ __launch_bounds__(64 * MAX_WAVES, 1) void flow_eval_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
+__global__ __launch_bounds__(64 * MAX_WAVES, VMC_FLOW_MIN_BLOCKS) void flow_eval_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
                                                       const double* __restrict__ th, const double* __restrict__ x,
                                                       int64_t N, const double* __restrict__ dirs, int n_dirs,
                                                       double* __restrict__ logp, double* __restrict__ g,

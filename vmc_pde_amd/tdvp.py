@@ -125,25 +125,38 @@ class TDVP:
             self._buf = {(P, str(device)): b}
         return b
 
+    class _Section:
+        """HIP events on the launch stream around one stage of a call, handed to `TDVP._event_hook(name, e0, e1)` when bench.py
+        has set one (no cost otherwise)."""
+
+        def __init__(self, owner, name):
+            self.hook, self.name = getattr(owner, "_event_hook", None), name
+
+        def __enter__(self):
+            if self.hook is not None:
+                self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+            return self
+
+        def __exit__(self, *exc):
+            if self.hook is not None and exc[0] is None:
+                self.e1.record()
+                self.hook(self.name, self.e0, self.e1)
+            return False
+
     def _gram(self, b, JT, ldj, P, n, c, w, out):
         need = nat.lib().vmcpde_gram_workspace_bytes(P, n)
         if b["gram_ws"] is None or b["gram_ws"].numel() * 8 < need:
             b["gram_ws"] = torch.empty(max(need // 8, 1), dtype=global_defs.tReal, device=JT.device)
-        hook = getattr(self, "_event_hook", None)     # bench.py: HIP events on the launch stream around the S-build
-        if hook is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         f32 = 0 if JT.dtype != torch.float32 else (2 if (self.f32BlockGram and c is None and w is None and ldj % 4 == 0) else 1)
         if f32 == 2 and self._solver() == "cholesky" and self.diagonalShift < F32_BLOCK_MIN_SHIFT:
             # fp32 block sums perturb the scaled Gram by ~2e-8 per entry, i.e. ~2e-8 * 2 sqrt(P) in norm: the sum is no longer
             # exactly positive semi-definite, and a smaller shift cannot make the (rank-deficient) S + shift*diag(S) definite
             raise ValueError(f"f32BlockGram needs diagonalShift >= {F32_BLOCK_MIN_SHIFT:g} with the Cholesky solver "
                              f"(got {self.diagonalShift:g}); use the widening fp32 path (f32BlockGram=False) for smaller shifts")
-        nat.call("vmcpde_gram", nat.ptr(JT), ldj, f32, P, n, nat.ptr(c), nat.ptr(w), nat.ptr(out),
-                 nat.ptr(b["gram_ws"]), b["gram_ws"].numel() * 8, nat.stream())
-        if hook is not None:
-            e1.record()
-            hook(e0, e1)
+        with self._Section(self, "gram"):             # bench.py: HIP events on the launch stream around the S-build
+            nat.call("vmcpde_gram", nat.ptr(JT), ldj, f32, P, n, nat.ptr(c), nat.ptr(w), nat.ptr(out),
+                     nat.ptr(b["gram_ws"]), b["gram_ws"].numel() * 8, nat.stream())
 
     # ---- tdvp.py:36-52 -------------------------------------------------------------------------------------------
     def get_tdvp_equation(self, Eloc, gradients, logProbs, psi=None):
@@ -215,7 +228,10 @@ class TDVP:
                 nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, f32, P, n, nat.ptr(e), nat.ptr(c), nat.ptr(cE), nat.ptr(b["rowsum"]),
                          nat.ptr(b["rowdot"]), nat.stream())
             self._gram(b, JT, ldj, P + 2 if bordered else P, n, c_gram, None, b["packed"])
-            mpi.allreduce_sum_(b["pack"])            # the one collective of the step (no-op on a single rank)
+            with self._Section(self, "allreduce"):
+                mpi.allreduce_sum_(b["pack"])        # the one collective of the step (no-op on a single rank)
+            self._replicated = self._Section(self, "replicated")      # finalize + factorisation + substitution + diagnostics: closed in solve()
+            self._replicated.__enter__()
             if use_chol and b["A"] is None:
                 b["A"] = torch.zeros((b["Ppad"], b["Ppad"]), dtype=global_defs.tReal, device=device)
             # the bordered Cholesky (row P of A = F, corner = a huge pivot) gets its border row from the same kernel
@@ -447,6 +463,7 @@ class TDVP:
                      float(self.diagonalShift) if self.diagonalShift > 1e-10 else 0.0,
                      nat.ptr(self._floor) if (chol and self._floor is not None) else None, nat.ptr(self._scal),
                      nat.ptr(b["info"]) if chol else None, nat.ptr(out), nat.stream())
+            self._replicated.__exit__(None, None, None)
             self._record_guard(out, chol)
         return update, out[0], out[1]
 
@@ -534,13 +551,14 @@ class TDVP:
                 torch.cuda.synchronize(psi.device)
                 timings.stop_timing(name)
 
-        start_timing("sampling")
-        sampleConfigs, logProbs = psi.sample(numSamples=nSamplesTDVP)         # tdvp.py:117
-        stop_timing("sampling")
+        with self._Section(self, "sample+flow"):
+            start_timing("sampling")
+            sampleConfigs, logProbs = psi.sample(numSamples=nSamplesTDVP)         # tdvp.py:117
+            stop_timing("sampling")
 
-        start_timing("compute Eloc")
-        Eloc, sampleGradients, logProbs = evolutionEq(psi, sampleConfigs, t)  # tdvp.py:122
-        stop_timing("compute Eloc")
+            start_timing("compute Eloc")
+            Eloc, sampleGradients, logProbs = evolutionEq(psi, sampleConfigs, t)  # tdvp.py:122
+            stop_timing("compute Eloc")
 
         start_timing("solve TDVP eqn.")
         update, self.solverResidual, self.tdvp_error = self.solve(Eloc, sampleGradients, logProbs, psi=psi)   # tdvp.py:127
