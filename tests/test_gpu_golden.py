@@ -160,7 +160,7 @@ def test_heun_step_against_committed_vector():
         assert float(torch.linalg.norm(S0 @ du)) < 1e-9 * nF, (k, float(torch.linalg.norm(S0 @ du)) / nF)
         ev, Vv = tp.ev.cpu(), tp.V.cpu()
         W = Vv[:, ev > 1e-9 * ev[-1]]
-        assert float(torch.linalg.norm(W.T @ du)) < 1e-9 * float(torch.linalg.norm(W.T @ u.cpu())), k
+        assert float(torch.linalg.norm(S0 @ (W @ (W.T @ du)))) < 1e-9 * nF, k
     # and the step itself is the explicit trapezoid of the two slopes the product computed (stepper.py:135-139), to rounding
     assert len(slopes) == 2
     assert float((y - (th0 + 0.5 * dt * (slopes[0] + slopes[1]))).abs().max()) <= 4e-16 * float(th0.abs().max() + dt * slopes[0].abs().max())

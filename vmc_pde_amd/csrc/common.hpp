@@ -100,7 +100,7 @@ struct DeviceCtx {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool attr_chol = false, attr_gram = false, attr_gram_f32 = false, attr_gram_dma = false, attr_solve = false;
-  int flow_eval_lds = 0, flow_eval_lds2 = 0, flow_eval_lds4 = 0, flow_sample_lds = 0;   // largest dynamic-LDS size the flow kernels (per directions-per-pass variant) were raised to
+  int flow_eval_lds = 0, flow_eval_lds_cap = 0, flow_eval_lds2 = 0, flow_eval_lds4 = 0, flow_sample_lds = 0;   // largest dynamic-LDS size the flow kernels (per directions-per-pass variant) were raised to
   int* gram_perm = nullptr;                     // [dev] Gram tile order (position -> lower-triangle tile index) for gram_perm_nb row blocks
   int gram_perm_nb = 0;
 };

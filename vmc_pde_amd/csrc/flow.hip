@@ -43,9 +43,6 @@ namespace {
 #ifndef VMC_FLOW_EPS_REGS
 #define VMC_FLOW_EPS_REGS 1          // reverse sweep: eps of a wave's input units in registers (0: an LDS line, the round-2 form)
 #endif
-#ifndef VMC_FLOW_MIN_BLOCKS
-#define VMC_FLOW_MIN_BLOCKS 1        // __launch_bounds__ second argument of flow_eval_kernel (2 caps the kernel at 128 VGPRs)
-#endif
 constexpr int JB = VMC_FLOW_JB;  // output block held in registers by the dense-layer loops (measured: 6 x up-to-8 waves is the best compromise over C2/C3/C4)
 constexpr int MAX_WAVES = VMC_FLOW_MAX_WAVES;
 
@@ -822,8 +819,12 @@ __device__ __forceinline__ void latent_backward(const Ctx& c, const LatentCache*
 // KD: Hessian directions per forward Taylor pass (1 + 2 KD components).  One direction per pass needs the least LDS (every
 // configuration of BASELINE); narrow networks take KD = 2 or 4, which shares the value component and the weight reads of a
 // pass among the directions (d = 8 diffusion: 2 passes instead of 8) -- chosen by vmcpde_flow_eval.
-template <int KD>
-__global__ __launch_bounds__(64 * MAX_WAVES, VMC_FLOW_MIN_BLOCKS) void flow_eval_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
+// CAP: the register allocation is held to 128 VGPRs (four waves per SIMD; 52 B of scratch per lane) -- chosen by vmcpde_flow_eval
+// when the LDS plan lets more than twelve waves be resident per CU, which the uncapped kernel's 148 VGPRs would not (C2: four
+// 4-wave workgroups per CU, Eloc + J 0.645 -> 0.595 ms; where LDS allows no more than twelve waves anyway the uncapped kernel is
+// faster -- C3 2.14 against 2.39 ms; tools/diag/flow_plan_ab.sh).  (HIP's second launch-bound is waves per SIMD, not blocks per CU.)
+template <int KD, bool CAP = false>
+__global__ __launch_bounds__(64 * MAX_WAVES, CAP ? 4 : 1) void flow_eval_kernel(const FlowProgram* __restrict__ fp, const LatentCache* __restrict__ lc,
                                                       const double* __restrict__ th, const double* __restrict__ x,
                                                       int64_t N, const double* __restrict__ dirs, int n_dirs,
                                                       double* __restrict__ logp, double* __restrict__ g,
@@ -1215,12 +1216,17 @@ extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const doub
       }
     }
   }
-  const void* kern = (kd == 4) ? (const void*)flow_eval_kernel<4> : (kd == 2) ? (const void*)flow_eval_kernel<2> : (const void*)flow_eval_kernel<1>;
+  const int waves = pick_waves(m->host);
+  // more than twelve waves per CU possible by LDS and by the 16-wave budget of a 128-VGPR kernel -> the capped instantiation
+  const int wg_lds = (160 * 1024) / bytes, wg_cap = 16 / waves;
+  const bool cap = (kd == 1) && ((wg_lds < wg_cap ? wg_lds : wg_cap) * waves > 12) && env_int("VMCPDE_FLOW_CAP", 1);
+  const void* kern = (kd == 4) ? (const void*)flow_eval_kernel<4> : (kd == 2) ? (const void*)flow_eval_kernel<2>
+                     : cap ? (const void*)flow_eval_kernel<1, true> : (const void*)flow_eval_kernel<1>;
   if (bytes > 64 * 1024) {
     DeviceCtx* ctx = device_ctx();
     if (!ctx) return -2;
     DeviceCtxLock lock;
-    int& have = (kd == 4) ? ctx->flow_eval_lds4 : (kd == 2) ? ctx->flow_eval_lds2 : ctx->flow_eval_lds;
+    int& have = (kd == 4) ? ctx->flow_eval_lds4 : (kd == 2) ? ctx->flow_eval_lds2 : cap ? ctx->flow_eval_lds_cap : ctx->flow_eval_lds;
     if (bytes > have) {
       VMC_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       have = bytes;
@@ -1229,12 +1235,13 @@ extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const doub
   const int64_t grid = (n_samples + lanes - 1) / lanes;
   VMC_REQUIRE(workspace == nullptr || workspace_bytes >= vmcpde_flow_eval_workspace_bytes(m, n_samples),
               "flow_eval workspace too small: need %lld bytes", (long long)vmcpde_flow_eval_workspace_bytes(m, n_samples));
-#define VMC_LAUNCH_FLOW_EVAL(K)                                                                                                          \
-  hipLaunchKernelGGL(flow_eval_kernel<K>, dim3((unsigned)grid), dim3(64 * pick_waves(m->host)), bytes, st, m->dev, m->cache, theta, x, \
+#define VMC_LAUNCH_FLOW_EVAL(...)                                                                                                        \
+  hipLaunchKernelGGL((flow_eval_kernel<__VA_ARGS__>), dim3((unsigned)grid), dim3(64 * waves), bytes, st, m->dev, m->cache, theta, x, \
                      n_samples, dirs, (hv ? n_dirs : 0), logp, g, hv, JT, ldj, (int)jt_f32, static_cast<double*>(workspace),             \
                      (int64_t)((n_samples + 63) / 64 * 64), lanes, r)
   if (kd == 4) VMC_LAUNCH_FLOW_EVAL(4);
   else if (kd == 2) VMC_LAUNCH_FLOW_EVAL(2);
+  else if (cap) VMC_LAUNCH_FLOW_EVAL(1, true);
   else VMC_LAUNCH_FLOW_EVAL(1);
 #undef VMC_LAUNCH_FLOW_EVAL
   VMC_CHECK_HIP(hipGetLastError());
