@@ -188,3 +188,65 @@ def test_row_moments_eloc_stats_and_finalize():
              0.0, None, nat.ptr(S2), Pp, None, 0, None, None, nat.stream())
     S2g = S2.cpu().numpy()[:P, :P]
     assert np.linalg.norm(S2g - S_ref) / np.linalg.norm(S_ref) < 1e-11
+
+
+# ---- the INT8 experiment (csrc/gram_i8.hip): error-free sliced Gram, same packed sums as the uncentred fp64 kernel ------------------------
+def _gram_i8(JT, ldj, P, N, slices=6, bits=8):
+    npk = nat.lib().vmcpde_gram_packed_doubles(P)
+    packed = torch.full((npk,), float("nan"), dtype=torch.float64, device=DEV)
+    need = nat.lib().vmcpde_gram_i8_workspace_bytes(P, N, slices, bits)
+    ws = torch.empty(need // 8 + 1, dtype=torch.float64, device=DEV)
+    nat.call("vmcpde_gram_i8", nat.ptr(JT), ldj, P, N, slices, bits, nat.ptr(packed), nat.ptr(ws), ws.numel() * 8, nat.stream())
+    return packed
+
+
+@pytest.mark.parametrize("slices,bits", [(6, 8), (6, 7), (7, 7)])
+def test_gram_i8_lane_maps_with_asymmetric_integer_operand(slices, bits):
+    # exact small integers with an asymmetric pattern: a wrong A/B lane map, C/D map, slice order or digit weight shows up bit for bit
+    P, N = 300, 200          # ragged in both directions: padded rows, a partial K-block, three tile rows
+    J = (np.arange(N)[:, None] * 3 + np.arange(P)[None, :] * 7 + (np.arange(P)[None, :] ** 2) % 5) % 11 - 5.0
+    JT = torch.zeros((384, 208), dtype=torch.float64, device=DEV)
+    JT[:P, :N] = torch.as_tensor(J.T)
+    assert np.array_equal(_unpack(_gram_i8(JT, 208, P, N, slices, bits), P), J.T @ J)
+    # wider integers need several digits: still exact (every kept digit-pair sum is an exact integer; nothing is dropped below 2^40)
+    rng = np.random.default_rng(3)
+    J = rng.integers(-(1 << 19), 1 << 19, (N, P)).astype(np.float64)
+    JT[:P, :N] = torch.as_tensor(J.T)
+    assert np.array_equal(_unpack(_gram_i8(JT, 208, P, N, slices, bits), P), J.T @ J)
+
+
+@pytest.mark.parametrize("P,N", [(37, 1024), (129, 17), (411, 1000), (640, 4099), (4213, 2048), (1030, 40000)])
+def test_gram_i8_matches_fp64_kernel(P, N):
+    """Random Jacobians with row scales over six decades and non-zero means: the sliced sums against the fp64 MFMA kernel (itself
+    1e-13 from numpy, test_gram_parity_with_centring).  Six balanced 8-bit digits: rel-Frobenius <= 1e-12 (SURVEY 8d asks 1e-12 of the
+    Gram kernels; measured 1e-13 at 4096 x 65536, profiles/r03_gram_i8_microbench.json); seven 7-bit digits 1e-13."""
+    rng = np.random.default_rng(P + N)
+    J, JT, ldj = _jt(P, N, seed=P * 3 + N, mean=0.7)
+    scale = 10.0 ** rng.uniform(-3, 3, P)
+    JT[:P] *= torch.as_tensor(scale, device=DEV)[:, None]
+    ref = _unpack(_gram(JT, ldj, P, N), P)
+    d = np.sqrt(np.diag(ref))
+    for slices, bits, tol in ((6, 8, 1e-12), (7, 7, 1e-13)):
+        got = _unpack(_gram_i8(JT, ldj, P, N, slices, bits), P)
+        # scale-free (correlation form): the rows span six decades, so the plain Frobenius norm would only see the largest
+        err = np.linalg.norm((got - ref) / np.outer(d, d)) / np.linalg.norm(ref / np.outer(d, d))
+        assert err < tol, (slices, bits, err)
+        assert np.array_equal(got, got.T)
+
+
+def test_gram_i8_is_deterministic_and_handles_zero_and_constant_rows():
+    P, N = 200, 3000
+    J, JT, ldj = _jt(P, N, seed=5)
+    JT[7] = 0.0                      # a dead parameter: exponent 0, all digits 0
+    JT[11, :N] = 1.0                 # the appended "ones" row of the fused-moments Gram: one non-zero digit
+    JT[13, :N] = -2.5e-150           # tiny values: 2^shift alone would overflow the exponent range
+    a = _gram_i8(JT, ldj, P, N)
+    b = _gram_i8(JT, ldj, P, N)
+    assert torch.equal(a, b)         # integer atomics and fixed-order reductions: bitwise reproducible
+    S = _unpack(a, P)
+    ref = _unpack(_gram(JT, ldj, P, N), P)
+    assert np.all(S[7] == 0.0) and S[11, 11] == float(N) and np.isfinite(S).all()
+    assert abs(S[11, 3] - ref[11, 3]) <= 1e-12 * np.sqrt(ref[11, 11] * ref[3, 3])
+    assert abs(S[13, 13] / ref[13, 13] - 1) < 1e-12
+    with pytest.raises(nat.VmcpdeError, match="supported"):
+        _gram_i8(JT, ldj, P, N, slices=5, bits=8)

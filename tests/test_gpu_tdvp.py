@@ -650,3 +650,25 @@ def test_lazy_SExp_refuses_a_jacobian_that_was_overwritten():
         tp.SExp
     with pytest.raises(RuntimeError, match="overwritten"):
         tp.snr
+
+
+def test_int8_gram_option_reproduces_the_fp64_step():
+    """TDVP(int8Gram=True) (experiment, opt-in): the S-build on the INT8 matrix pipe -- same S0, F0 and Cholesky update as the fp64 path
+    on the same samples (uncentred fast path with the appended moment rows, second call of a run)."""
+    import vmc_pde_amd as V
+    dim, depth, hidden, latent, coupling, eq, N = 2, 3, (4, 4), "Gauss", "no_add", "advection_hamiltonian_wDiss", 3000
+    spec, th, nrm, chi2, eo, ep = _problem(dim, depth, hidden, latent, coupling, eq, N, lam=0.1)
+    z = O.latent_from_normals(spec, th, nrm, chi2)
+    res = {}
+    for flag in (False, True):
+        vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()))
+        tp = V.TDVP(diagonalShift=1e-4, svdTol=1e-8, solver="cholesky", int8Gram=flag)
+        kw = dict(nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+        tp(th.cuda(), 0.1, vs, ep, **kw)                      # first call: exact centring, sets up the lagged means
+        upd, _ = tp(th.cuda(), 0.1, vs, ep, **kw)             # second call: uncentred Gram with the appended rows
+        tp.check()
+        assert tp._uncentred_ok
+        res[flag] = (tp.S0.clone(), tp.F0.clone(), upd.clone(), float(tp.solverResidual))
+    (S_a, F_a, u_a, r_a), (S_b, F_b, u_b, r_b) = res[False], res[True]
+    assert rel_err(S_b, S_a) < 1e-11 and rel_err(F_b, F_a) < 1e-10
+    assert float(torch.linalg.norm(S_a @ (u_b - u_a)) / torch.linalg.norm(F_a)) < 1e-8 and r_b < 1e-8

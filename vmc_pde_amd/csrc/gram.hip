@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "mfma_tile.hpp"
+#include "gram_order.hpp"
 
 using namespace vmcpde;
 
@@ -81,49 +82,6 @@ GramPlan make_plan(int P, int64_t N, int slots /* resident workgroups: 256 CUs x
   g.nsplit = (int)((N + g.chunk - 1) / g.chunk);
   if (g.nsplit < 1) g.nsplit = 1;
   return g;
-}
-
-// XCD-aware mapping of a workgroup to its (sample split, tile) unit.  Workgroups are dealt round-robin over the 8 XCDs
-// (blockIdx % 8 share an L2) and started in blockIdx order, so slot = blockIdx / 8 is "time".  order 1 (default): all XCDs
-// sweep the SAME sample chunk at the same time -- slot -> (split, local tile), XCD x owns a contiguous run of that split's
-// tiles -- which keeps the chip-wide working set at one or two chunks of J (Infinity-Cache sized) and neighbouring tiles
-// (shared operand panels) on one L2.  order 0: one sample chunk per XCD (eight chunks in flight).
-// order 2: the tiles are laid along a Z-order (Morton) curve through the lower triangle (perm: position -> tile index) and every
-// XCD owns a contiguous piece of the curve in every sample split, so the 64 workgroups resident on an XCD work on a compact
-// 2-D patch of tiles and share ~16 operand panels per K-step in that XCD's L2 instead of ~26 for two or three whole tile rows.
-// The pieces are balanced: with ntiles = 8 q + r every XCD gets q tiles per split and the r left-over tiles rotate over the
-// XCDs from split to split (XCDs (s r + i) mod 8, i < r), so the per-XCD totals differ by at most one unit (order 1 gives
-// seven XCDs ceil(ntiles/8) tiles and the last one the rest: 71 against 64 at C2, i.e. 1.2 % more rounds than necessary).
-__device__ __forceinline__ int xcd_extra(int xcd, int split, int r) { return (((xcd - split * r) % 8) + 8) % 8 < r ? 1 : 0; }
-
-__device__ __forceinline__ bool gram_unit(int ntiles, int nsplit, int total_units, int units_per_xcd, int order, const int* __restrict__ perm,
-                                          int& split, int& tile) {
-  if (order == 2) {
-    const int xcd = (int)(blockIdx.x & 7), q = ntiles >> 3, r = ntiles & 7;
-    int rem = (int)(blockIdx.x >> 3), s = 0;
-    for (; s < nsplit; ++s) {
-      const int cnt = q + xcd_extra(xcd, s, r);
-      if (rem < cnt) break;
-      rem -= cnt;
-    }
-    if (s == nsplit) return false;
-    int start = q * xcd;
-    for (int x = 0; x < xcd; ++x) start += xcd_extra(x, s, r);
-    split = s;
-    tile = perm[start + rem];
-    return true;
-  }
-  if (order == 1) {
-    const int slot = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
-    split = slot / units_per_xcd;                      // units_per_xcd = tiles per XCD per split here
-    tile = xcd * units_per_xcd + (slot - split * units_per_xcd);
-    return tile < ntiles && split < nsplit;
-  }
-  const int unit = (int)(blockIdx.x & 7) * units_per_xcd + (int)(blockIdx.x >> 3);
-  if (unit >= total_units) return false;
-  split = unit / ntiles;
-  tile = unit - split * ntiles;
-  return true;
 }
 
 // centred / weighted / fp32-operand variants: register-staged main loop, two workgroups per CU
@@ -414,15 +372,8 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
   int per_xcd = (order == 1) ? (g.ntiles + 7) / 8 : (total + 7) / 8;
   int grid = (order == 1) ? per_xcd * 8 * g.nsplit : per_xcd * 8;
   if (order == 2) {        // slots of the busiest XCD (gram_unit's balanced deal)
-    const int q = g.ntiles / 8, r = g.ntiles % 8;
-    int most = 0;
-    for (int x = 0; x < 8; ++x) {
-      int cnt = 0;
-      for (int sp = 0; sp < g.nsplit; ++sp) cnt += q + (((((x - sp * r) % 8) + 8) % 8 < r) ? 1 : 0);
-      most = cnt > most ? cnt : most;
-    }
-    per_xcd = most;
-    grid = most * 8;
+    per_xcd = order2_slots_per_xcd(g.ntiles, g.nsplit);
+    grid = per_xcd * 8;
   }
   // tuning knob: extra dynamic LDS forces one workgroup per CU (to measure what the co-resident partner is worth)
   const size_t lds_pad = (size_t)env_int("VMCPDE_GRAM_LDSPAD", 0);
@@ -432,25 +383,7 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
   DeviceCtxLock lock;      // first-use attribute changes; held over the (asynchronous) launches below, which is harmless
   const int* perm = nullptr;
   if (order == 2) {
-    if (ctx->gram_perm_nb != g.nb) {       // (re)build the Z-order tile list for this matrix size: once per size and GPU
-      std::vector<std::pair<uint64_t, int>> keyed;
-      keyed.reserve(g.ntiles);
-      auto spread = [](uint32_t v) { uint64_t x = v; x = (x | (x << 16)) & 0x0000FFFF0000FFFFull; x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-                                     x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full; x = (x | (x << 2)) & 0x3333333333333333ull;
-                                     x = (x | (x << 1)) & 0x5555555555555555ull; return x; };
-      for (int ti = 0; ti < g.nb; ++ti)
-        for (int tj = 0; tj <= ti; ++tj) keyed.push_back({(spread((uint32_t)ti) << 1) | spread((uint32_t)tj), ti * (ti + 1) / 2 + tj});
-      std::sort(keyed.begin(), keyed.end());
-      std::vector<int> host(g.ntiles);
-      for (int i = 0; i < g.ntiles; ++i) host[i] = keyed[i].second;
-      if (ctx->gram_perm) (void)hipFree(ctx->gram_perm);
-      ctx->gram_perm = nullptr;
-      ctx->gram_perm_nb = 0;
-      VMC_CHECK_HIP(hipMalloc(&ctx->gram_perm, (size_t)g.ntiles * sizeof(int)));
-      VMC_CHECK_HIP(hipMemcpy(ctx->gram_perm, host.data(), (size_t)g.ntiles * sizeof(int), hipMemcpyHostToDevice));
-      ctx->gram_perm_nb = g.nb;
-    }
-    perm = ctx->gram_perm;
+    if (int rc = ensure_gram_perm(ctx, g.nb, &perm)) return rc;
   }
   if (!ctx->attr_gram || lds_pad) {
 #define VMC_ATTR(CEN, SCA, T) VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_kernel<CEN, SCA, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes))

@@ -1,0 +1,431 @@
+// EXPERIMENT (opt-in, never the default): the Gram matrix on the INT8 matrix pipe by error-free slicing of the fp64 Jacobian.
+//
+// Reference: tdvp.py:46 / mpi_wrapper.py:21-25 -- the same S0 = <O O^T> (uncentred packed sums, as the DMA variant of gram.hip).
+// MI355X runs v_mfma_i32_32x32x32_i8 at 64x the rate of v_mfma_f64_16x16x4_f64; an fp64 product can be recovered EXACTLY from
+// integer products of slices (Ozaki scheme, integer form):
+//     J[p][n] = 2^e_p * sum_{s<NS} d_s[p][n] 2^(-6-7s),   d_s int8, |d_s| <= 64   (per-row power-of-two scale, residuals rounded to nearest)
+//     S[p][q] = 2^(e_p+e_q-12) sum_k 2^(-7k) T_k[p][q],   T_k = sum_{s+t=k} D_s D_t^T   (int32 accumulators: exact, k <= NS-1 kept)
+// Every pair product is <= 2^12 and a diagonal k holds k+1 <= 7 pairs, so one int32 accumulator per diagonal is exact over up to
+// 74 898 samples -- a sample split (<= 65 536) never overflows.  What is dropped: the slices behind 2^-48 of the row maximum and the
+// pair products with s+t >= NS (2^-46 of max_p max_q per sample, signs random) -- ~1e-14 (max/rms)^2 / sqrt(N) of |S|_F.
+// NS = 7: 28 MFMAs replace one fp64 multiply-add per 32x32x32 block, i.e. 28/64 = 0.44 of the fp64 matrix-pipe time at equal
+// utilisation (measured loop rate with LDS-fed operands: 3.7 POP/s, tools/microbench/i8_sliced_gram.hip).
+//
+// Pipeline (vmcpde_gram_i8):
+//   1. row_expo_kernel      e_p from the row maxima (one pass over J)
+//   2. slice_kernel         J -> int8 planes in the BLOCKED layout planes[kb][s][p][32]: the 32 samples of K-block kb of slice s of
+//                           128 consecutive rows are 4 KB contiguous -- exactly the LDS image of an operand, so staging is plain DMA
+//   3. gram_i8_kernel       lower-triangle 128 x 128 tiles x sample splits; 8 waves, wave tile 64 x 32, NS int32 diagonals
+//                           (2 x 16 x NS accumulator VGPRs), operands global -> LDS by global_load_lds (double-buffered, 112 KB),
+//                           fragments by ds_read_b128; epilogue: Horner sum of the diagonals in fp64, scale by 2^(e_p+e_q-12),
+//                           fp64 slab in the layout of gram.hip (reduce_splits / finalize are shared)
+#include <algorithm>
+#include <vector>
+
+#include "mfma_tile.hpp"
+#include "gram_order.hpp"
+
+using namespace vmcpde;
+
+namespace {
+
+typedef int int4_t __attribute__((ext_vector_type(4)));
+typedef int int16v_t __attribute__((ext_vector_type(16)));
+
+constexpr int KB = 32;                 // samples per K-block = bytes per fragment row
+
+// e_p: |J[p][n]| / 2^e_p < 1 for every n (0 for an all-zero row)
+__global__ __launch_bounds__(256) void row_expo_kernel(const double* __restrict__ JT, int64_t ldj, int64_t N, int P, int headroom, int* __restrict__ expo) {
+  __shared__ double red[4];
+  const int t = threadIdx.x, p = blockIdx.x;
+  double mx = 0.0;
+  if (p < P) {
+    const double* __restrict__ row = JT + (int64_t)p * ldj;
+    const int64_t N2 = N & ~(int64_t)1;
+    for (int64_t n = 2 * t; n < N2; n += 512) {
+      const double2_t v = *reinterpret_cast<const double2_t*>(row + n);
+      mx = fmax(mx, fmax(fabs(v.x), fabs(v.y)));
+    }
+    if (t == 0 && N2 < N) mx = fmax(mx, fabs(row[N2]));
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+  if ((t & 63) == 0) red[t >> 6] = mx;
+  __syncthreads();
+  if (t == 0) {
+    mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    int e = 0;
+    if (mx > 0.0 && isfinite(mx)) frexp(mx, &e);       // mx = f 2^e, f in [0.5, 1)
+    expo[p] = e + headroom;
+  }
+}
+
+// planes[((kb * NS + s) * Ppad + p) * 32 + j] = digit s of sample 32 kb + j of row p.  One workgroup: 32 rows x KB_PER_WG K-blocks;
+// a thread converts 8 consecutive samples, so the four threads of a row cover one K-block and the 128 threads of a K-block write
+// 1 KB contiguous per slice.
+//   BITS = 7: x = J / 2^e in (-1, 1); d_0 = rint(64 x), then residuals x 128 rounded to nearest: |d_s| <= 64, x = sum d_s 2^(-6-7s).
+//   BITS = 8: x = J / 2^e with one more bit of head room (|x| < 1/2); M = rint(x 2^(8 NS - 1)) is split from the least significant end
+//             into BALANCED base-256 digits d = ((M + 128) mod 256) - 128 in [-128, 127] (the carry goes up; the top digit is
+//             <= 65 in magnitude): x = sum d_s 2^(-7-8s) exactly to 2^(-8 NS + 1) -- 47 bits from six slices, no offsets, digits of
+//             either sign, so dropped pair products still average out.
+// It also returns, per row, the two dropped diagonals that do NOT average out for p = q: dsum[2p] = sum_n sum_{s+t=NS} d_s d_t and
+// dsum[2p+1] = sum_n sum_{s+t=NS+2} d_s d_t (exact integers, integer atomics: deterministic).  For p != q the dropped pair products
+// have random signs and sum to ~sqrt(N); on the diagonal the (s,s) terms are squares -- a bias of 5e-12 |S|_F at NS = 6, BITS = 7 if left out.
+constexpr int SL_ROWS = 32, SL_KB_PER_WG = 64;
+template <int NS, int BITS>
+__global__ __launch_bounds__(256) void slice_kernel(const double* __restrict__ JT, int64_t ldj, int64_t N, int P, int Ppad, const int* __restrict__ expo,
+                                                    int8_t* __restrict__ planes, int64_t nkb, unsigned long long* __restrict__ dsum) {
+  const int t = threadIdx.x;
+  const int kb_in = t >> 7;                       // two K-blocks per trip
+  const int row = (t & 127) >> 2, quarter = t & 3;
+  const int p = blockIdx.x * SL_ROWS + row;
+  const bool rowok = p < P;
+  // expo[p] already holds the head-room bit for BITS = 8
+  const int shift = rowok ? (BITS == 7 ? 6 : 8 * NS - 1) - expo[p] : 0;      // (ldexp per value: 2^shift itself may not be representable)
+  const double* __restrict__ src = JT + (int64_t)(rowok ? p : 0) * ldj;
+  const int64_t kb_lo = (int64_t)blockIdx.y * SL_KB_PER_WG;
+  long long t_lo = 0, t_hi = 0;
+  for (int it = 0; it < SL_KB_PER_WG / 2; ++it) {
+    const int64_t kb = kb_lo + 2 * it + kb_in;
+    if (kb >= nkb) break;
+    const int64_t n0 = kb * KB + quarter * 8;
+    double x[8];
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+      double2_t v = {0.0, 0.0};
+      if (rowok && n0 + q + 1 < N) v = *reinterpret_cast<const double2_t*>(src + n0 + q);
+      else if (rowok && n0 + q < N) v.x = src[n0 + q];
+      x[q] = ldexp(v.x, shift);
+      x[q + 1] = ldexp(v.y, shift);
+    }
+    int8_t* __restrict__ dst = planes + (((int64_t)kb * NS) * Ppad + p) * KB + quarter * 8;
+    int dig[NS][8];
+    if (BITS == 7) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const double d = rint(x[q]);
+          dig[s][q] = (int)d;
+          x[q] = (x[q] - d) * 128.0;
+        }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        long long M = (long long)rint(x[q]);
+#pragma unroll
+        for (int s = NS - 1; s >= 1; --s) {
+          const int d = (int)((M + 128) & 255) - 128;
+          dig[s][q] = d;
+          M = (M - d) >> 8;
+        }
+        dig[0][q] = (int)M;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      union { int8_t b[8]; int2 w; } u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) u.b[q] = (int8_t)dig[s][q];
+      *reinterpret_cast<int2*>(dst + (int64_t)s * Ppad * KB) = u.w;
+    }
+    int lo = 0, hi = 0;
+#pragma unroll
+    for (int s = 1; s < NS; ++s) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        lo += dig[s][q] * dig[NS - s][q];
+        if (s >= 3 && NS + 2 - s < NS) hi += dig[s][q] * dig[NS + 2 - s][q];
+      }
+    }
+    t_lo += lo;
+    t_hi += hi;
+  }
+  // the four quarters of a row sit in adjacent lanes
+  t_lo += __shfl_xor(t_lo, 1); t_lo += __shfl_xor(t_lo, 2);
+  t_hi += __shfl_xor(t_hi, 1); t_hi += __shfl_xor(t_hi, 2);
+  if (quarter == 0 && rowok) {
+    atomicAdd(dsum + 2 * p, (unsigned long long)t_lo);
+    atomicAdd(dsum + 2 * p + 1, (unsigned long long)t_hi);
+  }
+}
+
+// S_pp += 2^(2 e_p - 12) (2^(-7 NS) dsum[2p] + 2^(-7 (NS+2)) dsum[2p+1]): the diagonal entries of the diagonal tiles of the packed buffer
+__global__ void diag_fix_kernel(const unsigned long long* __restrict__ dsum, const int* __restrict__ expo, int P, int ns, int bits,
+                                double* __restrict__ packed) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int ti = p >> 7, r = p & 127;
+  const double add = ldexp((double)(long long)dsum[2 * p], -bits * ns) + ldexp((double)(long long)dsum[2 * p + 1], -bits * (ns + 2));
+  packed[((int64_t)ti * (ti + 1) / 2 + ti) * (TILE * TILE) + r * TILE + r] += ldexp(add, 2 * expo[p] - (bits == 7 ? 12 : 14));
+}
+
+// One unit = (sample split, lower-triangle tile[, column half]).  WAVES = 8: 512 threads, the whole 128 x 128 tile, wave w -> rows
+// 64 (w >> 2).., columns 32 (w & 3)..; two waves per SIMD, which 6 diagonals allow (234 VGPRs) and 7 do not (they spill).  WAVES = 4:
+// 256 threads, a 128 x 64 half tile (columns 64 half + 32 (w & 1)..), one wave per SIMD with up to 512 registers -- the form for 7 slices.
+template <int NS, int WAVES, int BITS>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void gram_i8_kernel(const int8_t* __restrict__ planes, const int* __restrict__ expo, int Ppad,
+                                                                               int64_t nkb, int ntiles, int nsplit, int64_t kb_per_split,
+                                                                               int units_per_xcd, int diag_flags, const int* __restrict__ perm, double* __restrict__ out) {
+  extern __shared__ int4_t lds_i8[];                  // 2 buffers x (A: NS x 128 rows x 32 B | B: NS x BROWS rows x 32 B)
+  constexpr int BROWS = (WAVES == 8) ? 128 : 64;
+  constexpr int OPA = NS * 128 * KB / 16, OPB = NS * BROWS * KB / 16;      // int4 per operand image
+  constexpr int BUF = OPA + OPB;
+  constexpr int PA = NS * 4, PB = NS * BROWS / 32;    // 1-KiB DMA pieces per operand image
+  constexpr int HALVES = (WAVES == 8) ? 1 : 2;
+  int split, tile, half = 0;
+  if (WAVES == 8) {       // the fp64 kernel's balanced Z-order deal: every XCD owns a contiguous piece of the Morton curve in every split
+    if (!gram_unit(ntiles, nsplit, ntiles * nsplit, units_per_xcd, 2, perm, split, tile)) return;
+  } else {
+    const int unit = (int)blockIdx.x, per_split = ntiles * HALVES;
+    split = unit / per_split;
+    if (split >= nsplit) return;
+    const int within = unit - split * per_split;
+    tile = within / HALVES;
+    half = within - tile * HALVES;
+  }
+  int ti, tj;
+  tri_decode(tile, ti, tj);
+  const bool diag = (ti == tj);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = (WAVES == 8) ? (wave >> 2) : (wave >> 1), wc = (WAVES == 8) ? (wave & 3) : (wave & 1);
+  const int col0 = 64 * half + 32 * wc;               // first column of this wave inside the 128 x 128 tile
+  const int r32 = lane & 31, h = lane >> 5;
+  int64_t kb0 = (int64_t)split * kb_per_split;
+  int64_t kb1 = (kb0 + kb_per_split < nkb) ? (kb0 + kb_per_split) : nkb;
+  // timing diagnostics (VMCPDE_GRAM_I8_DIAG, wrong results): 1 every split reads the first chunk, 2 no barrier in the loop, 4 no DMA in
+  // the loop, 8 no DMA wait in the loop
+  if (diag_flags & 1) { kb1 -= kb0; kb0 = 0; }
+  const bool active = !diag || (64 * wr + 63 >= col0);   // a wave tile entirely above the diagonal of a diagonal tile forms no products
+
+  int16v_t acc[NS][2];
+#pragma unroll
+  for (int k = 0; k < NS; ++k)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[k][m][r] = 0;
+
+  // DMA: piece q of a K-block = (operand, slice, 32-row part); wave w issues q = w, w + WAVES, ...
+  const int npieces = diag ? PA : PA + PB;
+  auto issue = [&](int64_t kb, int buf) {
+    const char* __restrict__ g0 = reinterpret_cast<const char*>(planes) + ((int64_t)kb * NS) * Ppad * KB;
+    for (int q = wave; q < npieces; q += WAVES) {
+      const bool isb = q >= PA;
+      const int rem = isb ? q - PA : q;
+      const int parts = isb ? BROWS / 32 : 4;
+      const int s = rem / parts, part = rem - s * parts;
+      const int row0 = isb ? (tj * 128 + 64 * half * (HALVES - 1)) : ti * 128;
+      const char* src = g0 + ((int64_t)s * Ppad + row0) * KB + part * 1024 + lane * 16;
+      int4_t* dst = lds_i8 + buf * BUF + (isb ? OPA + s * (BROWS * 2) : s * 256) + part * 64;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+    }
+  };
+  // Triple-buffered K-blocks (NBUF = 3 where the LDS allows: 3 x 48 KB at 6 slices): the DMA of K-block kb + 2 is issued before the
+  // products of kb, and the wait at the end of a step covers only the pieces of kb + 1 (issued a whole step earlier) -- with two
+  // buffers every step ended on a full round trip to L2 / HBM.  vmcnt counts this wave's own pieces; the barrier then tells every
+  // wave that all pieces of kb + 1 have landed and that nobody reads buffer kb % NBUF any more.
+  constexpr int NBUF = (3 * BUF * 16 <= 160 * 1024) ? 3 : 2;
+  int mine = 0;                                   // pieces this wave issues per K-block
+  for (int q = wave; q < npieces; q += WAVES) ++mine;
+  auto wait_all_but_newest = [&](bool newest_in_flight) {
+    if (!newest_in_flight) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+    switch (mine) {                               // (s_waitcnt takes an immediate)
+      case 0: break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
+  int cur = 0;
+  if (kb0 < kb1) {
+    issue(kb0, 0);
+    if (NBUF == 3 && kb0 + 1 < kb1) issue(kb0 + 1, 1);
+    wait_all_but_newest(NBUF == 3 && kb0 + 1 < kb1);
+    __syncthreads();
+  }
+  // The two waves that share a SIMD (w and w + WAVES/2) take their non-MFMA phases at opposite ends of a step: the lower half issues
+  // its DMA pieces first and then multiplies, the upper half multiplies first and issues its pieces last -- with both doing
+  // "DMA, fragment reads, MFMAs" in lockstep behind the step's barrier the matrix pipe idled ~40 % of every step (PMC: MFMA busy 52 %).
+  const bool dma_first = (NBUF < 3) || (wave < WAVES / 2);
+  for (int64_t kb = kb0; kb < kb1; ++kb) {
+    const int64_t ahead = kb + NBUF - 1;
+    if (ahead < kb1 && dma_first && !(diag_flags & 4)) {
+      __builtin_amdgcn_s_setprio(2);
+      issue(ahead, (cur + NBUF - 1) % NBUF);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (active) {
+      const int4_t* __restrict__ ap = lds_i8 + cur * BUF + (64 * wr + r32) * 2 + h;
+      // B fragment rows: on a diagonal tile they are rows of the A image; else the B image holds the BROWS rows this unit needs
+      const int4_t* __restrict__ bp = diag ? lds_i8 + cur * BUF + (col0 + r32) * 2 + h
+                                           : lds_i8 + cur * BUF + OPA + (32 * wc + r32) * 2 + h;
+      const int bstride = diag ? 256 : BROWS * 2;
+      // the A fragments of slice s + 1 are requested BEFORE the products of slice s are issued: left to itself hipcc reads them
+      // behind each group of MFMAs and then waits for the LDS with an empty matrix pipe, six times per step
+      int4_t b[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) b[s] = bp[s * bstride];
+      int4_t a0 = ap[0], a1 = ap[64];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        int4_t n0 = a0, n1 = a1;
+        if (s + 1 < NS) {
+          n0 = ap[(s + 1) * 256];
+          n1 = ap[(s + 1) * 256 + 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tt = 0; tt < NS; ++tt)
+          if (s + tt < NS) {
+            acc[s + tt][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b[tt], acc[s + tt][0], 0, 0, 0);
+            acc[s + tt][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b[tt], acc[s + tt][1], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = n0;
+        a1 = n1;
+      }
+    }
+    if (ahead < kb1 && !dma_first && !(diag_flags & 4)) issue(ahead, (cur + NBUF - 1) % NBUF);
+    // K-block kb + 1 must have landed; with three buffers the pieces of kb + 2 issued in this step may stay in flight
+    if (!(diag_flags & 8)) wait_all_but_newest(NBUF == 3 && ahead < kb1);
+    if (!(diag_flags & 2)) __syncthreads();
+    cur = (cur + 1) % NBUF;
+  }
+  // epilogue: C/D element reg of lane (r32, h) of block m: row = 64 wr + 32 m + (reg & 3) + 8 (reg >> 2) + 4 h, column = col0 + r32
+  double* __restrict__ slab = out + ((int64_t)split * ntiles + tile) * (TILE * TILE);
+  const int ecol = expo[tj * 128 + col0 + r32];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = 64 * wr + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      double v = (double)acc[NS - 1][m][reg];
+#pragma unroll
+      for (int k = NS - 2; k >= 0; --k) v = fma(v, BITS == 7 ? 0.0078125 : 0.00390625, (double)acc[k][m][reg]);   // Horner in 2^-BITS, smallest diagonal first
+      slab[row * TILE + col0 + r32] = ldexp(v, expo[ti * 128 + row] + ecol - (BITS == 7 ? 12 : 14));
+    }
+}
+
+struct I8Plan {
+  int nb, ntiles, nsplit, Ppad;
+  int64_t nkb, kb_per_split;
+};
+
+I8Plan make_i8_plan(int P, int64_t N, int bits) {
+  I8Plan g;
+  g.nb = (P + TILE - 1) / TILE;
+  g.ntiles = (int)tri_count(g.nb);
+  g.Ppad = g.nb * TILE;
+  g.nkb = (N + KB - 1) / KB;
+  // one 8-wave workgroup per CU: 256 slots; aim at >= 8 rounds, the last one full.  int32 exactness bounds the samples of a split:
+  // 7-bit digits (|d| <= 64, <= 7 pairs per diagonal) 65 536; 8-bit digits (|d| <= 128, <= 6 pairs) 16 384
+  const int64_t cap = (bits == 7) ? 65536 : 16384;
+  const int64_t min_split = (g.nkb * KB + cap - 1) / cap;
+  int64_t want = (8 * 256 + g.ntiles - 1) / g.ntiles;
+  if (want < min_split) want = min_split;
+  int64_t maxsplit = g.nkb / 64 > 0 ? g.nkb / 64 : 1;
+  if (maxsplit < min_split) maxsplit = min_split;
+  int64_t pick = want < maxsplit ? want : maxsplit;
+  double best = 1e30;
+  for (int64_t c = std::max<int64_t>(min_split, pick > 3 ? pick - 2 : 1); c <= pick + 8 && c <= maxsplit; ++c) {
+    const int64_t rounds = ((g.ntiles * c + 7) / 8 + 31) / 32;          // per XCD: 32 resident workgroups, tiles dealt evenly
+    const double cost = (double)rounds / (double)c;
+    if (cost < best - 1e-9) { best = cost; pick = c; }
+  }
+  pick = env_int("VMCPDE_GRAM_I8_NSPLIT", (int)pick);
+  if (pick < min_split) pick = min_split;
+  g.kb_per_split = (g.nkb + pick - 1) / pick;
+  g.nsplit = (int)((g.nkb + g.kb_per_split - 1) / g.kb_per_split);
+  return g;
+}
+
+__global__ void reduce_splits_i8_kernel(const double* __restrict__ slabs, int nsplit, int64_t per_split, double* __restrict__ packed) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (i >= per_split) return;
+  double2_t s = *reinterpret_cast<const double2_t*>(slabs + i);
+  for (int k = 1; k < nsplit; ++k) {
+    const double2_t v = *reinterpret_cast<const double2_t*>(slabs + (int64_t)k * per_split + i);
+    s.x += v.x;
+    s.y += v.y;
+  }
+  *reinterpret_cast<double2_t*>(packed + i) = s;
+}
+
+int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+extern "C" int64_t vmcpde_gram_i8_workspace_bytes(int32_t P, int64_t n_samples, int32_t n_slices, int32_t digit_bits) {
+  if (P <= 0 || n_samples <= 0 || n_slices < 2 || n_slices > 8 || (digit_bits != 7 && digit_bits != 8)) return 0;
+  const I8Plan g = make_i8_plan(P, n_samples, digit_bits);
+  return align256((int64_t)g.Ppad * (int64_t)sizeof(int)) + align256((int64_t)g.Ppad * 16) + align256(g.nkb * n_slices * (int64_t)g.Ppad * KB) +
+         (int64_t)g.nsplit * g.ntiles * TILE * TILE * (int64_t)sizeof(double);
+}
+
+template <int NS, int BITS>
+static int gram_i8_run(const double* JT, int64_t ldj, int P, int64_t N, double* packed, char* ws, hipStream_t st) {
+  const I8Plan g = make_i8_plan(P, N, BITS);
+  int* expo = reinterpret_cast<int*>(ws);
+  ws += align256((int64_t)g.Ppad * (int64_t)sizeof(int));
+  unsigned long long* dsum = reinterpret_cast<unsigned long long*>(ws);
+  ws += align256((int64_t)g.Ppad * 16);
+  int8_t* planes = reinterpret_cast<int8_t*>(ws);
+  double* slabs = reinterpret_cast<double*>(ws + align256(g.nkb * NS * (int64_t)g.Ppad * KB));
+  VMC_CHECK_HIP(hipMemsetAsync(dsum, 0, (size_t)g.Ppad * 16, st));
+  hipLaunchKernelGGL(row_expo_kernel, dim3(g.Ppad), dim3(256), 0, st, JT, ldj, N, P, BITS == 8 ? 1 : 0, expo);
+  hipLaunchKernelGGL((slice_kernel<NS, BITS>), dim3(g.Ppad / SL_ROWS, (unsigned)((g.nkb + SL_KB_PER_WG - 1) / SL_KB_PER_WG)), dim3(256), 0, st, JT, ldj, N, P,
+                     g.Ppad, expo, planes, g.nkb, dsum);
+  constexpr int WAVES = (NS <= 6) ? 8 : 4;          // 7 diagonals of a 64 x 32 wave tile need more than 256 registers
+  const size_t one = (size_t)NS * (128 + (WAVES == 8 ? 128 : 64)) * KB;          // one K-block: A + B
+  const size_t lds = (3 * one <= 160 * 1024 ? 3 : 2) * one;
+  static bool attr_done = false;     // (per instantiation; first use -- the experiment is single-GPU, single-thread)
+  if (!attr_done) {
+    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_i8_kernel<NS, WAVES, BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  double* out = (g.nsplit > 1) ? slabs : packed;
+  const int* perm = nullptr;
+  int per_xcd = 0;
+  unsigned grid = (unsigned)(g.ntiles * g.nsplit * 2);
+  if (WAVES == 8) {
+    DeviceCtx* ctx = device_ctx();
+    if (!ctx) return -2;
+    DeviceCtxLock lock;
+    if (int rc = ensure_gram_perm(ctx, g.nb, &perm)) return rc;
+    per_xcd = order2_slots_per_xcd(g.ntiles, g.nsplit);
+    grid = (unsigned)per_xcd * 8u;
+  }
+  hipLaunchKernelGGL((gram_i8_kernel<NS, WAVES, BITS>), dim3(grid), dim3(WAVES * 64), lds, st, planes, expo, g.Ppad, g.nkb, g.ntiles, g.nsplit,
+                     g.kb_per_split, per_xcd, env_int("VMCPDE_GRAM_I8_DIAG", 0), perm, out);
+  VMC_CHECK_HIP(hipGetLastError());
+  if (g.nsplit > 1) {
+    const int64_t per_split = (int64_t)g.ntiles * TILE * TILE;
+    hipLaunchKernelGGL(reduce_splits_i8_kernel, dim3((unsigned)((per_split / 2 + 255) / 256)), dim3(256), 0, st, slabs, g.nsplit, per_split, packed);
+    VMC_CHECK_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(diag_fix_kernel, dim3((P + 255) / 256), dim3(256), 0, st, dsum, expo, P, NS, BITS, packed);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vmcpde_gram_i8(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, int32_t n_slices, int32_t digit_bits, double* packed,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+  VMC_REQUIRE(JT && packed && workspace, "vmcpde_gram_i8: null argument");
+  VMC_REQUIRE(P >= 1 && n_samples >= 1, "bad shape");
+  VMC_REQUIRE(ldj >= n_samples && (ldj % 2) == 0, "ldj must be even and >= n_samples");
+  VMC_REQUIRE((reinterpret_cast<uintptr_t>(JT) & 15) == 0, "JT must be 16-byte aligned");
+  VMC_REQUIRE((n_slices == 6 && (digit_bits == 7 || digit_bits == 8)) || (n_slices == 7 && digit_bits == 7),
+              "supported: 6 slices of 7 or 8 bits, 7 slices of 7 bits");
+  VMC_REQUIRE(workspace_bytes >= vmcpde_gram_i8_workspace_bytes(P, n_samples, n_slices, digit_bits), "gram_i8 workspace too small: need %lld bytes",
+              (long long)vmcpde_gram_i8_workspace_bytes(P, n_samples, n_slices, digit_bits));
+  char* ws = static_cast<char*>(workspace);
+  hipStream_t st = (hipStream_t)stream;
+  if (n_slices == 7) return gram_i8_run<7, 7>(JT, ldj, P, n_samples, packed, ws, st);
+  return digit_bits == 8 ? gram_i8_run<6, 8>(JT, ldj, P, n_samples, packed, ws, st) : gram_i8_run<6, 7>(JT, ldj, P, n_samples, packed, ws, st);
+}

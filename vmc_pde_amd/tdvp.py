@@ -82,6 +82,10 @@ class TDVP:
                                   #   cancellation costs < 3 of fp64's 16 digits; centred otherwise
     fuseMoments: bool = True      # uncentred path: sum O and sum O (E - cE) ride in the syrk as two appended Jacobian rows
     f32BlockGram: bool = False    # with an fp32 Jacobian: fp32 MFMA sums over blocks of <= 128 samples, fp64 across blocks (2x MFMA rate)
+    int8Gram: bool = False        # EXPERIMENT (opt-in): the uncentred fp64 Gram on the INT8 matrix pipe by error-free slicing of the Jacobian
+                                  # (csrc/gram_i8.hip: six balanced 8-bit digits per entry, 21 digit-pair products summed exactly in
+                                  # int32, combined in fp64) -- 1.4x the fp64 MFMA syrk at C2, S to ~1e-13 |S|_F of it; centred /
+                                  # weighted / fp32 requests keep the fp64 kernels
     frozenParameters: object = None   # flat parameter indices held fixed: their rows / columns of S and entries of F are zeroed, so
                                   # both solvers return a zero update for them (the pseudo-inverse drops the zero modes, tdvp.py:82;
                                   # the Cholesky pins or floors them).  Not a reference argument: the published diffusion runs used
@@ -155,8 +159,15 @@ class TDVP:
             raise ValueError(f"f32BlockGram needs diagonalShift >= {F32_BLOCK_MIN_SHIFT:g} with the Cholesky solver "
                              f"(got {self.diagonalShift:g}); use the widening fp32 path (f32BlockGram=False) for smaller shifts")
         with self._Section(self, "gram"):             # bench.py: HIP events on the launch stream around the S-build
-            nat.call("vmcpde_gram", nat.ptr(JT), ldj, f32, P, n, nat.ptr(c), nat.ptr(w), nat.ptr(out),
-                     nat.ptr(b["gram_ws"]), b["gram_ws"].numel() * 8, nat.stream())
+            if self.int8Gram and f32 == 0 and c is None and w is None:
+                need8 = nat.lib().vmcpde_gram_i8_workspace_bytes(P, n, 6, 8)
+                if b.get("gram_i8_ws") is None or b["gram_i8_ws"].numel() * 8 < need8:
+                    b["gram_i8_ws"] = torch.empty(need8 // 8 + 1, dtype=global_defs.tReal, device=JT.device)
+                nat.call("vmcpde_gram_i8", nat.ptr(JT), ldj, P, n, 6, 8, nat.ptr(out), nat.ptr(b["gram_i8_ws"]), b["gram_i8_ws"].numel() * 8,
+                         nat.stream())
+            else:
+                nat.call("vmcpde_gram", nat.ptr(JT), ldj, f32, P, n, nat.ptr(c), nat.ptr(w), nat.ptr(out),
+                         nat.ptr(b["gram_ws"]), b["gram_ws"].numel() * 8, nat.stream())
 
     # ---- tdvp.py:36-52 -------------------------------------------------------------------------------------------
     def get_tdvp_equation(self, Eloc, gradients, logProbs, psi=None):
