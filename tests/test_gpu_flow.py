@@ -68,6 +68,12 @@ def test_flow_sample_and_eval_parity(cfg):
     y_p, l_p = vs.net.apply(vs.params, x_o[0, 0].clone(), evaluate=False, inv=False)
     y_o, l_o = O.inn_w_prob(spec, th, x_o[0, 0], evaluate=False, inv=False)
     assert rel_err(y_p, y_o) < 1e-12 and abs(float(l_p) - float(l_o)) < 1e-11 * max(1, abs(float(l_o)))
+    # evaluate=True with inv=True (net.py:209-213 passes `inv` through; no caller of the reference uses it): single point and batch
+    e_p = vs.net.apply(vs.params, z[0, 1].clone(), evaluate=True, inv=True)
+    e_o = O.inn_w_prob(spec, th, z[0, 1], evaluate=True, inv=True)
+    assert abs(float(e_p) - float(e_o)) < 1e-11 * max(1, abs(float(e_o)))
+    e_b = vs.net.apply(vs.params, z[0, :5].clone(), evaluate=True, inv=True)
+    assert e_b.shape == (5,) and abs(float(e_b[1]) - float(e_o)) < 1e-11 * max(1, abs(float(e_o)))
     # J1, J3, J6
     lo, go, Jo = vo(x_o, "eval_coordgrads")
     lp, gp, Jp = vs(x_o, mode="eval_coordgrads")

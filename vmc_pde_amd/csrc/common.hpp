@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <map>
 #include <string>
 
 #include "../../include/vmcpde.h"
@@ -101,8 +102,8 @@ struct DeviceCtx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool attr_chol = false, attr_gram = false, attr_gram_f32 = false, attr_gram_dma = false, attr_solve = false;
   int flow_eval_lds = 0, flow_eval_lds_cap = 0, flow_eval_lds2 = 0, flow_eval_lds4 = 0, flow_sample_lds = 0;   // largest dynamic-LDS size the flow kernels (per directions-per-pass variant) were raised to
-  int* gram_perm = nullptr;                     // [dev] Gram tile order (position -> lower-triangle tile index) for gram_perm_nb row blocks
-  int gram_perm_nb = 0;
+  std::map<int, int*> gram_perms;               // [dev] Gram tile orders (position -> lower-triangle tile index) by number of row blocks: built once
+                                                // per matrix size and GPU and never freed, so alternating sizes / threads never re-synchronise
 };
 // returns nullptr (and sets the error string) if the current device cannot be queried
 DeviceCtx* device_ctx();

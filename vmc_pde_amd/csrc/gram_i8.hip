@@ -13,8 +13,11 @@
 //
 // Pipeline (vmcpde_gram_i8):
 //   1. row_expo_kernel      e_p from the row maxima (one pass over J)
-//   2. slice_kernel         J -> int8 planes in the BLOCKED layout planes[kb][s][p][32]: the 32 samples of K-block kb of slice s of
-//                           128 consecutive rows are 4 KB contiguous -- exactly the LDS image of an operand, so staging is plain DMA
+//   2. slice_kernel         J -> int8 planes in the BLOCKED layout planes[kb][s][row block of 128][k half][row][16 B]: the 32 samples of
+//                           K-block kb of slice s of 128 consecutive rows are 4 KB contiguous -- exactly the LDS image of an operand, so
+//                           staging is plain DMA; the two 16-byte halves of a row sit 2 KB apart, so that the 16-lane groups of a
+//                           ds_read_b128 fragment read (lanes {0-3,12-15,20-27}, ...) touch 16 distinct 16-byte bank groups -- with
+//                           rows of 32 contiguous bytes every fragment read was a 2-way bank conflict
 //   3. gram_i8_kernel       lower-triangle 128 x 128 tiles x sample splits; 8 waves, wave tile 64 x 32, NS int32 diagonals
 //                           (2 x 16 x NS accumulator VGPRs), operands global -> LDS by global_load_lds (double-buffered, 112 KB),
 //                           fragments by ds_read_b128; epilogue: Horner sum of the diagonals in fp64, scale by 2^(e_p+e_q-12),
@@ -97,7 +100,8 @@ __global__ __launch_bounds__(256) void slice_kernel(const double* __restrict__ J
       x[q] = ldexp(v.x, shift);
       x[q + 1] = ldexp(v.y, shift);
     }
-    int8_t* __restrict__ dst = planes + (((int64_t)kb * NS) * Ppad + p) * KB + quarter * 8;
+    // (kb, s = 0, row block p / 128) + k half (quarter / 2) * 2 KB + row-in-block * 16 + (quarter % 2) * 8
+    int8_t* __restrict__ dst = planes + (((int64_t)kb * NS) * Ppad + (p & ~127)) * KB + (quarter >> 1) * 2048 + (p & 127) * 16 + (quarter & 1) * 8;
     int dig[NS][8];
     if (BITS == 7) {
 #pragma unroll
@@ -206,7 +210,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void gram_i8_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[k][m][r] = 0;
 
-  // DMA: piece q of a K-block = (operand, slice, 32-row part); wave w issues q = w, w + WAVES, ...
+  // DMA: piece q of a K-block = (operand, slice, 1-KiB part); wave w issues q = w, w + WAVES, ...  An operand image is
+  // [slice][k half][rows][16 B]; the A image (128 rows) is a plain copy of 4 KB per slice, the B image of the half-tile variant takes the
+  // two 1-KiB runs of its 64 rows
   const int npieces = diag ? PA : PA + PB;
   auto issue = [&](int64_t kb, int buf) {
     const char* __restrict__ g0 = reinterpret_cast<const char*>(planes) + ((int64_t)kb * NS) * Ppad * KB;
@@ -215,9 +221,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void gram_i8_kernel
       const int rem = isb ? q - PA : q;
       const int parts = isb ? BROWS / 32 : 4;
       const int s = rem / parts, part = rem - s * parts;
-      const int row0 = isb ? (tj * 128 + 64 * half * (HALVES - 1)) : ti * 128;
-      const char* src = g0 + ((int64_t)s * Ppad + row0) * KB + part * 1024 + lane * 16;
-      int4_t* dst = lds_i8 + buf * BUF + (isb ? OPA + s * (BROWS * 2) : s * 256) + part * 64;
+      const char* src;
+      int4_t* dst;
+      if (!isb) {
+        src = g0 + ((int64_t)s * Ppad + ti * 128) * KB + part * 1024 + lane * 16;
+        dst = lds_i8 + buf * BUF + s * 256 + part * 64;
+      } else if (BROWS == 128) {
+        src = g0 + ((int64_t)s * Ppad + tj * 128) * KB + part * 1024 + lane * 16;
+        dst = lds_i8 + buf * BUF + OPA + s * 256 + part * 64;
+      } else {       // 64 rows of the tile's block: k half `part`, rows 64 half ..
+        src = g0 + ((int64_t)s * Ppad + tj * 128) * KB + part * 2048 + half * 1024 + lane * 16;
+        dst = lds_i8 + buf * BUF + OPA + s * 128 + part * 64;
+      }
       __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
     }
   };
@@ -261,23 +276,24 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void gram_i8_kernel
       __builtin_amdgcn_s_setprio(0);
     }
     if (active) {
-      const int4_t* __restrict__ ap = lds_i8 + cur * BUF + (64 * wr + r32) * 2 + h;
+      // fragment of lane (r32, h): 16 bytes of row r at k half h = image[slice][h][row] (int4 units: slice 256 / 2 BROWS, half 128 / BROWS)
+      const int4_t* __restrict__ ap = lds_i8 + cur * BUF + h * 128 + 64 * wr + r32;
       // B fragment rows: on a diagonal tile they are rows of the A image; else the B image holds the BROWS rows this unit needs
-      const int4_t* __restrict__ bp = diag ? lds_i8 + cur * BUF + (col0 + r32) * 2 + h
-                                           : lds_i8 + cur * BUF + OPA + (32 * wc + r32) * 2 + h;
+      const int4_t* __restrict__ bp = diag ? lds_i8 + cur * BUF + h * 128 + col0 + r32
+                                           : lds_i8 + cur * BUF + OPA + h * BROWS + 32 * wc + r32;
       const int bstride = diag ? 256 : BROWS * 2;
       // the A fragments of slice s + 1 are requested BEFORE the products of slice s are issued: left to itself hipcc reads them
       // behind each group of MFMAs and then waits for the LDS with an empty matrix pipe, six times per step
       int4_t b[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) b[s] = bp[s * bstride];
-      int4_t a0 = ap[0], a1 = ap[64];
+      int4_t a0 = ap[0], a1 = ap[32];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         int4_t n0 = a0, n1 = a1;
         if (s + 1 < NS) {
           n0 = ap[(s + 1) * 256];
-          n1 = ap[(s + 1) * 256 + 64];
+          n1 = ap[(s + 1) * 256 + 32];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

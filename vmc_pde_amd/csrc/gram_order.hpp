@@ -81,16 +81,15 @@ inline int order2_slots_per_xcd(int ntiles, int nsplit) {
 
 // the device copy of the Morton order for `nb` row blocks, cached per GPU (call under DeviceCtxLock); returns 0 or a negative error code
 inline int ensure_gram_perm(DeviceCtx* ctx, int nb, const int** perm) {
-  if (ctx->gram_perm_nb != nb) {       // (re)build the Z-order tile list for this matrix size: once per size and GPU
+  auto it = ctx->gram_perms.find(nb);
+  if (it == ctx->gram_perms.end()) {       // first use of this matrix size on this GPU (a blocking upload, once)
     const std::vector<int> host = morton_tile_order(nb);
-    if (ctx->gram_perm) (void)hipFree(ctx->gram_perm);
-    ctx->gram_perm = nullptr;
-    ctx->gram_perm_nb = 0;
-    VMC_CHECK_HIP(hipMalloc(&ctx->gram_perm, host.size() * sizeof(int)));
-    VMC_CHECK_HIP(hipMemcpy(ctx->gram_perm, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice));
-    ctx->gram_perm_nb = nb;
+    int* dev = nullptr;
+    VMC_CHECK_HIP(hipMalloc(&dev, host.size() * sizeof(int)));
+    VMC_CHECK_HIP(hipMemcpy(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice));
+    it = ctx->gram_perms.emplace(nb, dev).first;
   }
-  *perm = ctx->gram_perm;
+  *perm = it->second;
   return 0;
 }
 

@@ -150,9 +150,25 @@ class INNwProb:
                 theta[off] = 1.0                       # net.py:81 initializers.ones
         return theta.to(self.device)
 
+    def _latent_logpdf(self, theta, pts):
+        """net.py:10-36 in torch ops on the device (Gauss incl. log det S, Student_t without it -- as the reference writes them) for
+        points (n, d): latent_space_dist(pts - offset, {S = U U^T (util.py:21-26), mu, dist_params})."""
+        tree, d = self.tree_from_flat(theta)["params"], self.dim
+        U = torch.zeros((d, d), dtype=global_defs.tReal, device=self.device)
+        iu = torch.triu_indices(d, d, offset=1, device=self.device)
+        U[iu[0], iu[1]] = tree["L"]
+        U = U + torch.diag(torch.exp(tree["L_diag"]))
+        S = U @ U.T
+        r = pts - torch.as_tensor(self.offset, dtype=global_defs.tReal, device=self.device) - tree["mu"]
+        q = ((r @ torch.linalg.inv(S)) * r).sum(-1)
+        if self.latentSpaceName == "Gauss":
+            return -0.5 * (d * float(np.log(2 * np.pi)) + torch.logdet(S) + q)
+        nu = torch.exp(tree["dist_params"][0]) + 1.0
+        return (torch.lgamma((nu + d) / 2) - torch.lgamma(nu / 2) - d / 2 * torch.log(nu * float(np.pi)) - (nu + d) / 2 * torch.log1p(q / nu))
+
     # ---- net.py:209-217 ---------------------------------------------------------------------------------------
     def apply(self, params, x, evaluate=True, inv=False):
-        """Single sample (d,) or batch (N,d).  evaluate=True: log p(x) (inv is ignored by the reference's callers);
+        """Single sample (d,) or batch (N,d).  evaluate=True: log p(x) (inv=True: the reference's formula with the inverse walk, net.py:209-213);
         evaluate=False: (y, latent(x - offset) - log_jac) in either direction."""
         theta = params if torch.is_tensor(params) else self.flat_from_tree(params)
         theta = theta.to(self.device, global_defs.tReal).contiguous()
@@ -163,7 +179,14 @@ class INNwProb:
         with torch.cuda.device(self.device):
             if evaluate:
                 if inv:
-                    raise NotImplementedError("evaluate=True with inv=True is never used by the reference")
+                    # net.py:209-213 passes `inv` through: z, log_jac = INN(x, inv=True), result = latent(z - offset) + log_jac.  None of
+                    # the reference's callers uses it; the inverse walk comes from the sampling kernel (which returns
+                    # latent(x - offset) - log_jac), the two latent densities from the closed forms of net.py:10-36
+                    y = torch.empty_like(xb)
+                    lp = torch.empty(n, dtype=global_defs.tReal, device=self.device)
+                    nat.call("vmcpde_flow_sample", self.handle, nat.ptr(theta), nat.ptr(xb), n, 1, nat.ptr(y), nat.ptr(lp), nat.stream())
+                    out = self._latent_logpdf(theta, y) + (self._latent_logpdf(theta, xb) - lp)
+                    return out[0] if single else out
                 logp = torch.empty(n, dtype=global_defs.tReal, device=self.device)
                 nat.call("vmcpde_flow_eval", self.handle, nat.ptr(theta), nat.ptr(xb), n, None, 0, nat.ptr(logp), None, None,
                          None, 0, 0, None, 0, nat.stream())
