@@ -672,3 +672,32 @@ def test_int8_gram_option_reproduces_the_fp64_step():
     (S_a, F_a, u_a, r_a), (S_b, F_b, u_b, r_b) = res[False], res[True]
     assert rel_err(S_b, S_a) < 1e-11 and rel_err(F_b, F_a) < 1e-10
     assert float(torch.linalg.norm(S_a @ (u_b - u_a)) / torch.linalg.norm(F_a)) < 1e-8 and r_b < 1e-8
+
+
+def test_steppers_refuse_a_failed_solve_before_handing_the_step_back():
+    """With observables=False a right-hand side does not synchronise with the host; the reference stops inside every call on a NaN
+    update (tdvp.py:136-141).  The steppers therefore call TDVP.check() before they return: a NaN-contaminated or indefinite solve
+    must raise from `step` itself -- not at the next call, and not never (the last step of a run) -- on both solvers."""
+    import vmc_pde_amd as V
+    dim, depth, hidden, latent, coupling, eq, N = CASES[2]
+    spec, th, nrm, chi2, eo, ep = _problem(dim, depth, hidden, latent, coupling, eq, N, lam=0.1)
+    z = O.latent_from_normals(spec, th, nrm, chi2)
+    kw = dict(evolutionEq=ep, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+    bad = th.clone().cuda()
+    bad[th.numel() // 2] = float("nan")
+    for engine, stepper, err in ((V.TDVP(solver="cholesky", diagonalShift=1e-4, svdTol=1e-8), V.FixedStepper(timeStep=1e-4, mode="Euler"), "Cholesky failed"),
+                                 (V.TDVP(solver="cholesky", diagonalShift=1e-4, svdTol=1e-8), V.FixedStepper(timeStep=1e-4, mode="Heun"), "Cholesky failed"),
+                                 (V.TDVP(diagonalizeOnDevice=True), V.FixedStepper(timeStep=1e-4, mode="Euler"), None)):
+        vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()))
+        y, _, _ = stepper.step(0.0, engine, th.cuda(), psi=vs, **kw)          # a healthy step passes the check
+        assert bool(torch.isfinite(y).all())
+        # (spectral path: the eigensolver may already refuse the NaN matrix -- either way `step` must not return)
+        with pytest.raises((FloatingPointError, RuntimeError, ValueError), match=err):
+            stepper.step(0.0, engine, bad, psi=vs, **kw)
+    # the check is also what a driver calls before it writes a checkpoint (examples/main.py)
+    engine = V.TDVP(solver="cholesky", diagonalShift=1e-4, svdTol=1e-8)
+    vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()))
+    engine(bad, 0.0, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)      # returns: nothing synchronised yet
+    with pytest.raises(FloatingPointError, match="before the checkpoint"):
+        engine.check("before the checkpoint")
+    engine.check()                                                                                 # the record is consumed: no second raise

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void gram_i8_kernel
   int64_t kb0 = (int64_t)split * kb_per_split;
   int64_t kb1 = (kb0 + kb_per_split < nkb) ? (kb0 + kb_per_split) : nkb;
   // timing diagnostics (VMCPDE_GRAM_I8_DIAG, wrong results): 1 every split reads the first chunk, 2 no barrier in the loop, 4 no DMA in
-  // the loop, 8 no DMA wait in the loop
+  // the loop, 8 no DMA wait in the loop, 16 no raised priority for the DMA pieces, 32 every wave issues its pieces first, 64 all loads from four L2-resident K-blocks
   if (diag_flags & 1) { kb1 -= kb0; kb0 = 0; }
   const bool active = !diag || (64 * wr + 63 >= col0);   // a wave tile entirely above the diagonal of a diagonal tile forms no products
 
@@ -215,6 +215,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void gram_i8_kernel
   // two 1-KiB runs of its 64 rows
   const int npieces = diag ? PA : PA + PB;
   auto issue = [&](int64_t kb, int buf) {
+    if (diag_flags & 64) kb = (kb & 3);      // (timing diagnostic: every load hits the same four K-blocks -- L2-resident)
     const char* __restrict__ g0 = reinterpret_cast<const char*>(planes) + ((int64_t)kb * NS) * Ppad * KB;
     for (int q = wave; q < npieces; q += WAVES) {
       const bool isb = q >= PA;
@@ -267,11 +268,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void gram_i8_kernel
   // The two waves that share a SIMD (w and w + WAVES/2) take their non-MFMA phases at opposite ends of a step: the lower half issues
   // its DMA pieces first and then multiplies, the upper half multiplies first and issues its pieces last -- with both doing
   // "DMA, fragment reads, MFMAs" in lockstep behind the step's barrier the matrix pipe idled ~40 % of every step (PMC: MFMA busy 52 %).
-  const bool dma_first = (NBUF < 3) || (wave < WAVES / 2);
+  const bool dma_first = (NBUF < 3) || (wave < WAVES / 2) || (diag_flags & 32);
   for (int64_t kb = kb0; kb < kb1; ++kb) {
     const int64_t ahead = kb + NBUF - 1;
     if (ahead < kb1 && dma_first && !(diag_flags & 4)) {
-      __builtin_amdgcn_s_setprio(2);
+      if (!(diag_flags & 16)) __builtin_amdgcn_s_setprio(2);
       issue(ahead, (cur + NBUF - 1) % NBUF);
       __builtin_amdgcn_s_setprio(0);
     }
