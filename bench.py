@@ -313,15 +313,21 @@ def main():
         for _ in range(5):
             tdvp(theta, 0.0, **{**kwargs, "timings": tm})
         stage_ms = {k: {"median": float(np.median(v)) * 1e3, "min": float(np.min(v)) * 1e3} for k, v in tm.timing_dict.items()}
-        stepper = V.FixedStepper(timeStep=1e-4, mode="Heun", maxStep=1e-4, increase_fac=1.0)
+        # (a tiny step: the timing does not depend on it, and the random-init C3 network is so stiff that its Jacobian grows from 4e7 to
+        # 4e19 over a predictor step of 1e-4 -- the steppers now refuse a failed solve, tools/diag/c3_i8_debug.py)
+        stepper = V.FixedStepper(timeStep=1e-8, mode="Heun", maxStep=1e-8, increase_fac=1.0)
         ts = []
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            stepper.step(0.0, tdvp, theta, **kwargs)
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t1)
-        heun_ms = float(np.median(ts)) * 1e3
+        try:
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                stepper.step(0.0, tdvp, theta, **kwargs)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+            heun_ms = float(np.median(ts)) * 1e3
+        except FloatingPointError as exc:      # reported, not fatal: the headline figures above are complete
+            heun_ms = None
+            print(f"bench: Heun probe step refused ({exc})", file=sys.stderr)
     flops = float(args.samples) * P * (P + 1)
     achieved = flops / (gram_ms * 1e-3) / 1e12
     peak_meas = measure_mfma_peak(device)
