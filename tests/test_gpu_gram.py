@@ -191,12 +191,12 @@ def test_row_moments_eloc_stats_and_finalize():
 
 
 # ---- the INT8 experiment (csrc/gram_i8.hip): error-free sliced Gram, same packed sums as the uncentred fp64 kernel ------------------------
-def _gram_i8(JT, ldj, P, N, slices=6, bits=8):
+def _gram_i8(JT, ldj, P, N, slices=6, bits=8, c=None, w=None, stats=None):
     npk = nat.lib().vmcpde_gram_packed_doubles(P)
     packed = torch.full((npk,), float("nan"), dtype=torch.float64, device=DEV)
     need = nat.lib().vmcpde_gram_i8_workspace_bytes(P, N, slices, bits)
     ws = torch.empty(need // 8 + 1, dtype=torch.float64, device=DEV)
-    nat.call("vmcpde_gram_i8", nat.ptr(JT), ldj, P, N, slices, bits, nat.ptr(packed), nat.ptr(ws), ws.numel() * 8, nat.stream())
+    nat.call("vmcpde_gram_i8", nat.ptr(JT), ldj, P, N, slices, bits, nat.ptr(c), nat.ptr(w), nat.ptr(packed), nat.ptr(stats), nat.ptr(ws), ws.numel() * 8, nat.stream())
     return packed
 
 
@@ -250,3 +250,30 @@ def test_gram_i8_is_deterministic_and_handles_zero_and_constant_rows():
     assert abs(S[13, 13] / ref[13, 13] - 1) < 1e-12
     with pytest.raises(nat.VmcpdeError, match="supported"):
         _gram_i8(JT, ldj, P, N, slices=5, bits=8)
+
+
+def test_gram_i8_centred_and_weighted_match_fp64_kernels():
+    """The centring shift and the per-sample weight (tdvp.py:42,47: SExp, rhoVar) applied while slicing: (J - c) w on the int8 pipe
+    against the register-staged fp64 kernels."""
+    P, N = 411, 5000
+    rng = np.random.default_rng(2)
+    J, JT, ldj = _jt(P, N, seed=9, mean=4.0)
+    c = torch.as_tensor(J.mean(0)).to(DEV)
+    w = torch.as_tensor(rng.standard_normal(N) * 3.0).to(DEV)
+    for cc, ww in ((c, None), (None, w), (c, w)):
+        ref = _unpack(_gram(JT, ldj, P, N, c=cc, w=ww), P)
+        got = _unpack(_gram_i8(JT, ldj, P, N, c=cc, w=ww), P)
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-12
+
+
+def test_gram_i8_reports_heavy_tails():
+    """stats[0] = the largest row maximum / row rms (within a factor two): ~5-10 for Gaussian rows, ~sqrt(N) (its upper bound) for a row
+    that is one outlier."""
+    P, N = 130, 20000
+    J, JT, ldj = _jt(P, N, seed=4)
+    st = torch.zeros(1, dtype=torch.float64, device=DEV)
+    _gram_i8(JT, ldj, P, N, stats=st)
+    assert 3.0 < float(st[0]) < 20.0
+    JT[17, 5] = 1e6
+    _gram_i8(JT, ldj, P, N, stats=st)
+    assert 100.0 < float(st[0]) < 300.0            # sqrt(20000) = 141, times the head-room factor

@@ -701,3 +701,27 @@ def test_steppers_refuse_a_failed_solve_before_handing_the_step_back():
     with pytest.raises(FloatingPointError, match="before the checkpoint"):
         engine.check("before the checkpoint")
     engine.check()                                                                                 # the record is consumed: no second raise
+
+
+def test_int8_gram_falls_back_on_heavy_tailed_rows():
+    """The sliced Gram scales every Jacobian row by its maximum; a row with an extreme outlier loses accuracy.  The engine watches the
+    largest row max / row rms of each int8 call and falls back to the fp64 kernel (with one warning) from the next call on."""
+    import vmc_pde_amd as V
+    from vmc_pde_amd import mpi_wrapper as mpi
+    tp = V.TDVP(int8Gram=True, svdTol=1e-10)                # limit sqrt(0.1 * 1e-10 / 4e-15) = 50: Gaussian rows (~8) pass, a one-outlier row (~sqrt(N)) does not
+    N, P = 40000, 40
+    mpi.globNumSamples = N                              # (what TDVP.__call__ sets, tdvp.py:99; get_tdvp_equation divides by it)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    J = torch.randn((1, N, P), generator=g, dtype=torch.float64, device="cuda")
+    E = torch.randn((1, N), generator=g, dtype=torch.float64, device="cuda")
+    lp = torch.randn((1, N), generator=g, dtype=torch.float64, device="cuda")
+    tp.get_tdvp_equation(E, J, lp)
+    assert tp._int8_still_ok() and float(tp._i8_host[0]) < 30
+    S_ref = torch.cov(J[0].T, correction=0)
+    assert rel_err(tp.S0, S_ref) < 1e-11
+    J[0, 7, 3] = 1e7                                    # a row that is one outlier: max / rms = sqrt(N) = 200, the largest possible
+    tp.get_tdvp_equation(E, J, lp)                      # this call still runs on int8 (its figure is read before the next one)
+    with pytest.warns(RuntimeWarning, match="int8Gram"):
+        tp.get_tdvp_equation(E, J, lp)
+    assert not tp._int8_still_ok()
+    assert rel_err(tp.S0, torch.cov(J[0].T, correction=0)) < 1e-11

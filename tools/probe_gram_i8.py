@@ -59,7 +59,7 @@ def run_i8(JT, cfg):
     for it in range(reps + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        nat.call("vmcpde_gram_i8", nat.ptr(JT), ldj, P, N, ns, bits, nat.ptr(packed), nat.ptr(ws), ws.numel() * 8, nat.stream())
+        nat.call("vmcpde_gram_i8", nat.ptr(JT), ldj, P, N, ns, bits, None, None, nat.ptr(packed), None, nat.ptr(ws), ws.numel() * 8, nat.stream())
         e1.record()
         torch.cuda.synchronize()
         if it:

@@ -38,18 +38,22 @@ typedef int int16v_t __attribute__((ext_vector_type(16)));
 constexpr int KB = 32;                 // samples per K-block = bytes per fragment row
 
 // e_p: |J[p][n]| / 2^e_p < 1 for every n (0 for an all-zero row)
-__global__ __launch_bounds__(256) void row_expo_kernel(const double* __restrict__ JT, int64_t ldj, int64_t N, int P, int headroom, int* __restrict__ expo) {
+// (optional centring shift c[p] and per-sample weight w[n]: the sliced operand is (J[p][n] - c[p]) w[n], as in gram.hip's staged variants)
+__global__ __launch_bounds__(256) void row_expo_kernel(const double* __restrict__ JT, int64_t ldj, int64_t N, int P, int headroom,
+                                                       const double* __restrict__ c, const double* __restrict__ w, int* __restrict__ expo) {
   __shared__ double red[4];
   const int t = threadIdx.x, p = blockIdx.x;
   double mx = 0.0;
   if (p < P) {
     const double* __restrict__ row = JT + (int64_t)p * ldj;
+    const double cp = c ? c[p] : 0.0;
     const int64_t N2 = N & ~(int64_t)1;
     for (int64_t n = 2 * t; n < N2; n += 512) {
       const double2_t v = *reinterpret_cast<const double2_t*>(row + n);
-      mx = fmax(mx, fmax(fabs(v.x), fabs(v.y)));
+      const double a = (v.x - cp) * (w ? w[n] : 1.0), b = (v.y - cp) * (w ? w[n + 1] : 1.0);
+      mx = fmax(mx, fmax(fabs(a), fabs(b)));
     }
-    if (t == 0 && N2 < N) mx = fmax(mx, fabs(row[N2]));
+    if (t == 0 && N2 < N) mx = fmax(mx, fabs((row[N2] - cp) * (w ? w[N2] : 1.0)));
   }
   for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
   if ((t & 63) == 0) red[t >> 6] = mx;
@@ -70,13 +74,14 @@ __global__ __launch_bounds__(256) void row_expo_kernel(const double* __restrict_
 //             into BALANCED base-256 digits d = ((M + 128) mod 256) - 128 in [-128, 127] (the carry goes up; the top digit is
 //             <= 65 in magnitude): x = sum d_s 2^(-7-8s) exactly to 2^(-8 NS + 1) -- 47 bits from six slices, no offsets, digits of
 //             either sign, so dropped pair products still average out.
-// It also returns, per row, the two dropped diagonals that do NOT average out for p = q: dsum[2p] = sum_n sum_{s+t=NS} d_s d_t and
-// dsum[2p+1] = sum_n sum_{s+t=NS+2} d_s d_t (exact integers, integer atomics: deterministic).  For p != q the dropped pair products
+// It also returns, per row, the two dropped diagonals that do NOT average out for p = q: dsum[3p] = sum_n sum_{s+t=NS} d_s d_t and
+// dsum[3p+1] = sum_n sum_{s+t=NS+2} d_s d_t (exact integers, integer atomics: deterministic), and dsum[3p+2] = sum_n (d_0 2^BITS + d_1)^2 for the heavy-tail figure of diag_fix_kernel.  For p != q the dropped pair products
 // have random signs and sum to ~sqrt(N); on the diagonal the (s,s) terms are squares -- a bias of 5e-12 |S|_F at NS = 6, BITS = 7 if left out.
 constexpr int SL_ROWS = 32, SL_KB_PER_WG = 64;
 template <int NS, int BITS>
 __global__ __launch_bounds__(256) void slice_kernel(const double* __restrict__ JT, int64_t ldj, int64_t N, int P, int Ppad, const int* __restrict__ expo,
-                                                    int8_t* __restrict__ planes, int64_t nkb, unsigned long long* __restrict__ dsum) {
+                                                    const double* __restrict__ c, const double* __restrict__ w, int8_t* __restrict__ planes,
+                                                    int64_t nkb, unsigned long long* __restrict__ dsum) {
   const int t = threadIdx.x;
   const int kb_in = t >> 7;                       // two K-blocks per trip
   const int row = (t & 127) >> 2, quarter = t & 3;
@@ -85,8 +90,9 @@ __global__ __launch_bounds__(256) void slice_kernel(const double* __restrict__ J
   // expo[p] already holds the head-room bit for BITS = 8
   const int shift = rowok ? (BITS == 7 ? 6 : 8 * NS - 1) - expo[p] : 0;      // (ldexp per value: 2^shift itself may not be representable)
   const double* __restrict__ src = JT + (int64_t)(rowok ? p : 0) * ldj;
+  const double cp = (c && rowok) ? c[p] : 0.0;
   const int64_t kb_lo = (int64_t)blockIdx.y * SL_KB_PER_WG;
-  long long t_lo = 0, t_hi = 0;
+  long long t_lo = 0, t_hi = 0, t_top = 0;
   for (int it = 0; it < SL_KB_PER_WG / 2; ++it) {
     const int64_t kb = kb_lo + 2 * it + kb_in;
     if (kb >= nkb) break;
@@ -95,8 +101,13 @@ __global__ __launch_bounds__(256) void slice_kernel(const double* __restrict__ J
 #pragma unroll
     for (int q = 0; q < 8; q += 2) {
       double2_t v = {0.0, 0.0};
-      if (rowok && n0 + q + 1 < N) v = *reinterpret_cast<const double2_t*>(src + n0 + q);
-      else if (rowok && n0 + q < N) v.x = src[n0 + q];
+      if (rowok && n0 + q + 1 < N) {
+        v = *reinterpret_cast<const double2_t*>(src + n0 + q);
+        v.x = (v.x - cp) * (w ? w[n0 + q] : 1.0);
+        v.y = (v.y - cp) * (w ? w[n0 + q + 1] : 1.0);
+      } else if (rowok && n0 + q < N) {
+        v.x = (src[n0 + q] - cp) * (w ? w[n0 + q] : 1.0);
+      }
       x[q] = ldexp(v.x, shift);
       x[q + 1] = ldexp(v.y, shift);
     }
@@ -141,25 +152,46 @@ __global__ __launch_bounds__(256) void slice_kernel(const double* __restrict__ J
         if (s >= 3 && NS + 2 - s < NS) hi += dig[s][q] * dig[NS + 2 - s][q];
       }
     }
+    long long top = 0;      // (x to two digits)^2: resolves a row rms down to 2^-15 of the row's scale
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const long long v2 = (long long)dig[0][q] * (1 << BITS) + dig[1][q];
+      top += v2 * v2;
+    }
     t_lo += lo;
     t_hi += hi;
+    t_top += top;
   }
   // the four quarters of a row sit in adjacent lanes
   t_lo += __shfl_xor(t_lo, 1); t_lo += __shfl_xor(t_lo, 2);
   t_hi += __shfl_xor(t_hi, 1); t_hi += __shfl_xor(t_hi, 2);
+  t_top += __shfl_xor(t_top, 1); t_top += __shfl_xor(t_top, 2);
   if (quarter == 0 && rowok) {
-    atomicAdd(dsum + 2 * p, (unsigned long long)t_lo);
-    atomicAdd(dsum + 2 * p + 1, (unsigned long long)t_hi);
+    atomicAdd(dsum + 3 * p, (unsigned long long)t_lo);
+    atomicAdd(dsum + 3 * p + 1, (unsigned long long)t_hi);
+    atomicAdd(dsum + 3 * p + 2, (unsigned long long)t_top);      // sum of squares to two digits: the row's rms in units of its scale
   }
 }
 
 // S_pp += 2^(2 e_p - 12) (2^(-7 NS) dsum[2p] + 2^(-7 (NS+2)) dsum[2p+1]): the diagonal entries of the diagonal tiles of the packed buffer
-__global__ void diag_fix_kernel(const unsigned long long* __restrict__ dsum, const int* __restrict__ expo, int P, int ns, int bits,
-                                double* __restrict__ packed) {
+// It also reports how heavy-tailed the rows are: stats[0] = max over rows of (row maximum / row rms), estimated from the top digits
+// (the per-row scale is what the fixed number of digits is relative to: the error of the sliced sums grows like that ratio squared).
+__global__ void diag_fix_kernel(const unsigned long long* __restrict__ dsum, const int* __restrict__ expo, int P, int ns, int bits, int64_t nsamp,
+                                double* __restrict__ packed, double* __restrict__ stats) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   const int ti = p >> 7, r = p & 127;
-  const double add = ldexp((double)(long long)dsum[2 * p], -bits * ns) + ldexp((double)(long long)dsum[2 * p + 1], -bits * (ns + 2));
+  if (stats) {
+    // two leading digits: x 2^(2 bits - 1) = d_0 2^bits + d_1, so rms of x = sqrt(sum / n) / 2^(2 bits - 1); the row maximum is >= 1/4
+    // (8-bit digits, head room) or 1/2 (7-bit)
+    const double top = (double)(long long)dsum[3 * p + 2];
+    if (top > 0.0) {
+      const double rms = ldexp(sqrt(top / (double)nsamp), -(2 * bits - 1));
+      const double ratio = (bits == 7 ? 1.0 : 0.5) / rms;                  // an upper bound of max / rms within a factor two
+      atomicMax(reinterpret_cast<unsigned long long*>(stats), (unsigned long long)__double_as_longlong(ratio));   // (positive doubles order like integers)
+    }
+  }
+  const double add = ldexp((double)(long long)dsum[3 * p], -bits * ns) + ldexp((double)(long long)dsum[3 * p + 1], -bits * (ns + 2));
   packed[((int64_t)ti * (ti + 1) / 2 + ti) * (TILE * TILE) + r * TILE + r] += ldexp(add, 2 * expo[p] - (bits == 7 ? 12 : 14));
 }
 
@@ -381,23 +413,24 @@ int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 extern "C" int64_t vmcpde_gram_i8_workspace_bytes(int32_t P, int64_t n_samples, int32_t n_slices, int32_t digit_bits) {
   if (P <= 0 || n_samples <= 0 || n_slices < 2 || n_slices > 8 || (digit_bits != 7 && digit_bits != 8)) return 0;
   const I8Plan g = make_i8_plan(P, n_samples, digit_bits);
-  return align256((int64_t)g.Ppad * (int64_t)sizeof(int)) + align256((int64_t)g.Ppad * 16) + align256(g.nkb * n_slices * (int64_t)g.Ppad * KB) +
+  return align256((int64_t)g.Ppad * (int64_t)sizeof(int)) + align256((int64_t)g.Ppad * 24) + align256(g.nkb * n_slices * (int64_t)g.Ppad * KB) +
          (int64_t)g.nsplit * g.ntiles * TILE * TILE * (int64_t)sizeof(double);
 }
 
 template <int NS, int BITS>
-static int gram_i8_run(const double* JT, int64_t ldj, int P, int64_t N, double* packed, char* ws, hipStream_t st) {
+static int gram_i8_run(const double* JT, int64_t ldj, int P, int64_t N, const double* c, const double* w, double* packed, double* stats, char* ws, hipStream_t st) {
   const I8Plan g = make_i8_plan(P, N, BITS);
   int* expo = reinterpret_cast<int*>(ws);
   ws += align256((int64_t)g.Ppad * (int64_t)sizeof(int));
   unsigned long long* dsum = reinterpret_cast<unsigned long long*>(ws);
-  ws += align256((int64_t)g.Ppad * 16);
+  ws += align256((int64_t)g.Ppad * 24);
   int8_t* planes = reinterpret_cast<int8_t*>(ws);
   double* slabs = reinterpret_cast<double*>(ws + align256(g.nkb * NS * (int64_t)g.Ppad * KB));
-  VMC_CHECK_HIP(hipMemsetAsync(dsum, 0, (size_t)g.Ppad * 16, st));
-  hipLaunchKernelGGL(row_expo_kernel, dim3(g.Ppad), dim3(256), 0, st, JT, ldj, N, P, BITS == 8 ? 1 : 0, expo);
+  VMC_CHECK_HIP(hipMemsetAsync(dsum, 0, (size_t)g.Ppad * 24, st));
+  if (stats) VMC_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double), st));
+  hipLaunchKernelGGL(row_expo_kernel, dim3(g.Ppad), dim3(256), 0, st, JT, ldj, N, P, BITS == 8 ? 1 : 0, c, w, expo);
   hipLaunchKernelGGL((slice_kernel<NS, BITS>), dim3(g.Ppad / SL_ROWS, (unsigned)((g.nkb + SL_KB_PER_WG - 1) / SL_KB_PER_WG)), dim3(256), 0, st, JT, ldj, N, P,
-                     g.Ppad, expo, planes, g.nkb, dsum);
+                     g.Ppad, expo, c, w, planes, g.nkb, dsum);
   constexpr int WAVES = (NS <= 6) ? 8 : 4;          // 7 diagonals of a 64 x 32 wave tile need more than 256 registers
   const size_t one = (size_t)NS * (128 + (WAVES == 8 ? 128 : 64)) * KB;          // one K-block: A + B
   const size_t lds = (3 * one <= 160 * 1024 ? 3 : 2) * one;
@@ -426,13 +459,13 @@ static int gram_i8_run(const double* JT, int64_t ldj, int P, int64_t N, double* 
     hipLaunchKernelGGL(reduce_splits_i8_kernel, dim3((unsigned)((per_split / 2 + 255) / 256)), dim3(256), 0, st, slabs, g.nsplit, per_split, packed);
     VMC_CHECK_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(diag_fix_kernel, dim3((P + 255) / 256), dim3(256), 0, st, dsum, expo, P, NS, BITS, packed);
+  hipLaunchKernelGGL(diag_fix_kernel, dim3((P + 255) / 256), dim3(256), 0, st, dsum, expo, P, NS, BITS, N, packed, stats);
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-extern "C" int vmcpde_gram_i8(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, int32_t n_slices, int32_t digit_bits, double* packed,
-                              void* workspace, int64_t workspace_bytes, void* stream) {
+extern "C" int vmcpde_gram_i8(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, int32_t n_slices, int32_t digit_bits, const double* c,
+                              const double* w, double* packed, double* stats, void* workspace, int64_t workspace_bytes, void* stream) {
   VMC_REQUIRE(JT && packed && workspace, "vmcpde_gram_i8: null argument");
   VMC_REQUIRE(P >= 1 && n_samples >= 1, "bad shape");
   VMC_REQUIRE(ldj >= n_samples && (ldj % 2) == 0, "ldj must be even and >= n_samples");
@@ -443,6 +476,6 @@ extern "C" int vmcpde_gram_i8(const double* JT, int64_t ldj, int32_t P, int64_t 
               (long long)vmcpde_gram_i8_workspace_bytes(P, n_samples, n_slices, digit_bits));
   char* ws = static_cast<char*>(workspace);
   hipStream_t st = (hipStream_t)stream;
-  if (n_slices == 7) return gram_i8_run<7, 7>(JT, ldj, P, n_samples, packed, ws, st);
-  return digit_bits == 8 ? gram_i8_run<6, 8>(JT, ldj, P, n_samples, packed, ws, st) : gram_i8_run<6, 7>(JT, ldj, P, n_samples, packed, ws, st);
+  if (n_slices == 7) return gram_i8_run<7, 7>(JT, ldj, P, n_samples, c, w, packed, stats, ws, st);
+  return digit_bits == 8 ? gram_i8_run<6, 8>(JT, ldj, P, n_samples, c, w, packed, stats, ws, st) : gram_i8_run<6, 7>(JT, ldj, P, n_samples, c, w, packed, stats, ws, st);
 }

@@ -84,8 +84,8 @@ class TDVP:
     f32BlockGram: bool = False    # with an fp32 Jacobian: fp32 MFMA sums over blocks of <= 128 samples, fp64 across blocks (2x MFMA rate)
     int8Gram: bool = False        # EXPERIMENT (opt-in): the uncentred fp64 Gram on the INT8 matrix pipe by error-free slicing of the Jacobian
                                   # (csrc/gram_i8.hip: six balanced 8-bit digits per entry, 21 digit-pair products summed exactly in
-                                  # int32, combined in fp64) -- 1.4x the fp64 MFMA syrk at C2, S to ~1e-13 |S|_F of it; centred /
-                                  # weighted / fp32 requests keep the fp64 kernels
+                                  # int32, combined in fp64) -- 1.4x the fp64 MFMA syrk at C2, S to ~1e-13 |S|_F of it; also for the
+                                  # centred and the weighted (SExp, rhoVar) sums; an fp32 Jacobian keeps the fp64-accumulating kernels
     frozenParameters: object = None   # flat parameter indices held fixed: their rows / columns of S and entries of F are zeroed, so
                                   # both solvers return a zero update for them (the pseudo-inverse drops the zero modes, tdvp.py:82;
                                   # the Cholesky pins or floors them).  Not a reference argument: the published diffusion runs used
@@ -100,6 +100,8 @@ class TDVP:
             raise ValueError("useSNR=True needs the spectral solver (solver='eigh' or 'auto'); the Cholesky path has no eigenbasis")
         self._guard_host = self._guard_event = None
         self._guard_pending = self._guard_chol = False
+        self._i8_host = self._i8_event = None
+        self._i8_off = False
         self.cholInfo = None
         self._buf = {}
         self._c_prev = None
@@ -148,6 +150,28 @@ class TDVP:
                 self.hook(self.name, self.e0, self.e1)
             return False
 
+    def _int8_tail_limit(self):
+        """Largest row max / row rms the six-digit int8 Gram is trusted with.  Its error is ~4e-15 x ratio^2 of |S|_F (2e-12 at a ratio of
+        23, measured) and must stay a factor ten below what regularises the solve: the spectral cut-off svdTol, or for the Cholesky the
+        larger of svdTol (absolute floor) and diagonalShift.  (The ratio itself never exceeds sqrt(N).)"""
+        reg = max(float(self.svdTol), float(self.diagonalShift) if self._solver() == "cholesky" else 0.0, 1e-16)
+        return math.sqrt(0.1 * reg / 4e-15)
+
+    def _int8_still_ok(self):
+        """The per-row scale of the sliced Gram makes its error grow like (row max / row rms)^2: the previous int8 call's figure is
+        read here (asynchronous copy, as for the uncentred Gram's mean^2 / var check); above the limit the engine warns once and
+        stays on the fp64 kernels."""
+        if self._i8_event is not None and not self._i8_off:
+            self._i8_event.synchronize()
+            ratio, limit = float(self._i8_host[0]), self._int8_tail_limit()
+            if ratio > limit:
+                import warnings
+                warnings.warn(f"int8Gram: a Jacobian row has max / rms ~ {ratio:.3g} > {limit:.3g} (the bound for svdTol = {self.svdTol:g}, "
+                              f"diagonalShift = {self.diagonalShift:g}); the sliced Gram would lose accuracy there -- using the fp64 MFMA "
+                              f"kernel from now on", RuntimeWarning)
+                self._i8_off = True
+        return not self._i8_off
+
     def _gram(self, b, JT, ldj, P, n, c, w, out):
         need = nat.lib().vmcpde_gram_workspace_bytes(P, n)
         if b["gram_ws"] is None or b["gram_ws"].numel() * 8 < need:
@@ -159,12 +183,19 @@ class TDVP:
             raise ValueError(f"f32BlockGram needs diagonalShift >= {F32_BLOCK_MIN_SHIFT:g} with the Cholesky solver "
                              f"(got {self.diagonalShift:g}); use the widening fp32 path (f32BlockGram=False) for smaller shifts")
         with self._Section(self, "gram"):             # bench.py: HIP events on the launch stream around the S-build
-            if self.int8Gram and f32 == 0 and c is None and w is None:
+            if self.int8Gram and f32 == 0 and self._int8_still_ok():
                 need8 = nat.lib().vmcpde_gram_i8_workspace_bytes(P, n, 6, 8)
                 if b.get("gram_i8_ws") is None or b["gram_i8_ws"].numel() * 8 < need8:
                     b["gram_i8_ws"] = torch.empty(need8 // 8 + 1, dtype=global_defs.tReal, device=JT.device)
-                nat.call("vmcpde_gram_i8", nat.ptr(JT), ldj, P, n, 6, 8, nat.ptr(out), nat.ptr(b["gram_i8_ws"]), b["gram_i8_ws"].numel() * 8,
-                         nat.stream())
+                    b["i8_stats"] = torch.zeros(1, dtype=global_defs.tReal, device=JT.device)
+                nat.call("vmcpde_gram_i8", nat.ptr(JT), ldj, P, n, 6, 8, nat.ptr(c), nat.ptr(w), nat.ptr(out), nat.ptr(b["i8_stats"]),
+                         nat.ptr(b["gram_i8_ws"]), b["gram_i8_ws"].numel() * 8, nat.stream())
+                # heavy-tail figure of this call (largest row max / row rms) for the host, without synchronising: read before the next call
+                if self._i8_host is None:
+                    self._i8_host = torch.empty(1, dtype=global_defs.tReal).pin_memory()
+                    self._i8_event = torch.cuda.Event()
+                self._i8_host.copy_(b["i8_stats"], non_blocking=True)
+                self._i8_event.record()
             else:
                 nat.call("vmcpde_gram", nat.ptr(JT), ldj, f32, P, n, nat.ptr(c), nat.ptr(w), nat.ptr(out),
                          nat.ptr(b["gram_ws"]), b["gram_ws"].numel() * 8, nat.stream())
