@@ -434,7 +434,10 @@ static int gram_i8_run(const double* JT, int64_t ldj, int P, int64_t N, const do
   constexpr int WAVES = (NS <= 6) ? 8 : 4;          // 7 diagonals of a 64 x 32 wave tile need more than 256 registers
   const size_t one = (size_t)NS * (128 + (WAVES == 8 ? 128 : 64)) * KB;          // one K-block: A + B
   const size_t lds = (3 * one <= 160 * 1024 ? 3 : 2) * one;
-  static bool attr_done = false;     // (per instantiation; first use -- the experiment is single-GPU, single-thread)
+  DeviceCtx* ctx = device_ctx();
+  if (!ctx) return -2;
+  DeviceCtxLock lock;              // first-use attribute change and the tile-order upload; held over the asynchronous launches (harmless)
+  bool& attr_done = ctx->attr_gram_i8[NS == 7 ? 2 : (BITS == 7 ? 1 : 0)];
   if (!attr_done) {
     VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_i8_kernel<NS, WAVES, BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
@@ -444,9 +447,6 @@ static int gram_i8_run(const double* JT, int64_t ldj, int P, int64_t N, const do
   int per_xcd = 0;
   unsigned grid = (unsigned)(g.ntiles * g.nsplit * 2);
   if (WAVES == 8) {
-    DeviceCtx* ctx = device_ctx();
-    if (!ctx) return -2;
-    DeviceCtxLock lock;
     if (int rc = ensure_gram_perm(ctx, g.nb, &perm)) return rc;
     per_xcd = order2_slots_per_xcd(g.ntiles, g.nsplit);
     grid = (unsigned)per_xcd * 8u;
