@@ -1,27 +1,31 @@
 // EXPERIMENT (opt-in, never the default): the Gram matrix on the INT8 matrix pipe by error-free slicing of the fp64 Jacobian.
 //
-// Reference: tdvp.py:46 / mpi_wrapper.py:21-25 -- the same S0 = <O O^T> (uncentred packed sums, as the DMA variant of gram.hip).
-// MI355X runs v_mfma_i32_32x32x32_i8 at 64x the rate of v_mfma_f64_16x16x4_f64; an fp64 product can be recovered EXACTLY from
-// integer products of slices (Ozaki scheme, integer form):
-//     J[p][n] = 2^e_p * sum_{s<NS} d_s[p][n] 2^(-6-7s),   d_s int8, |d_s| <= 64   (per-row power-of-two scale, residuals rounded to nearest)
-//     S[p][q] = 2^(e_p+e_q-12) sum_k 2^(-7k) T_k[p][q],   T_k = sum_{s+t=k} D_s D_t^T   (int32 accumulators: exact, k <= NS-1 kept)
-// Every pair product is <= 2^12 and a diagonal k holds k+1 <= 7 pairs, so one int32 accumulator per diagonal is exact over up to
-// 74 898 samples -- a sample split (<= 65 536) never overflows.  What is dropped: the slices behind 2^-48 of the row maximum and the
-// pair products with s+t >= NS (2^-46 of max_p max_q per sample, signs random) -- ~1e-14 (max/rms)^2 / sqrt(N) of |S|_F.
-// NS = 7: 28 MFMAs replace one fp64 multiply-add per 32x32x32 block, i.e. 28/64 = 0.44 of the fp64 matrix-pipe time at equal
-// utilisation (measured loop rate with LDS-fed operands: 3.7 POP/s, tools/microbench/i8_sliced_gram.hip).
+// Reference: tdvp.py:46-47 / mpi_wrapper.py:21-25 -- the same packed sums as vmcpde_gram (optionally centred / weighted).
+// MI355X runs v_mfma_i32_32x32x32_i8 at 64x the rate of v_mfma_f64_16x16x4_f64; an fp64 product can be recovered from EXACT integer
+// products of digits (Ozaki scheme, integer form).  Default form (NS = 6 digits of BITS = 8):
+//     J[p][n] = 2^e_p * sum_{s<6} d_s[p][n] 2^(-7-8s),   d_s balanced base-256 digits in [-128, 127]  (per-row power-of-two scale with one
+//                                                        bit of head room; 47 bits, split from the least significant end)
+//     S[p][q] = 2^(e_p+e_q-14) sum_{k<6} 2^(-8k) T_k[p][q],   T_k = sum_{s+t=k} D_s D_t^T   (int32 accumulators: exact)
+// Every digit product is <= 2^14 and diagonal k holds k+1 <= 6 pairs, so one int32 accumulator per diagonal is exact over 16 384
+// samples -- the size limit of a sample split.  What is dropped: the pair products with s + t >= 6 (<= 2^-62 of max_p max_q per
+// sample, random signs: they average out over the samples) EXCEPT the squares (s, s) on the diagonal p = q, which the slicing pass sums
+// exactly and diag_fix_kernel adds back.  21 MFMAs replace 64 fp64 MFMA-equivalents per 32 x 32 x 32 block: 0.33 of the fp64
+// matrix-pipe time at equal utilisation.  Also built, for the record: six 7-bit digits rounded to
+// nearest (BITS = 7: |d| <= 64, 41 bits -- 1.9e-12 of |S|_F on Gaussian data) and seven of them (28 pairs, 1.6e-14, but seven
+// diagonals of a 64 x 32 wave tile do not fit 256 registers: the half-tile form at one wave per SIMD is 2.5x slower).
 //
 // Pipeline (vmcpde_gram_i8):
-//   1. row_expo_kernel      e_p from the row maxima (one pass over J)
+//   1. row_expo_kernel      e_p from the row maxima of (J - c) w (one pass over J)
 //   2. slice_kernel         J -> int8 planes in the BLOCKED layout planes[kb][s][row block of 128][k half][row][16 B]: the 32 samples of
 //                           K-block kb of slice s of 128 consecutive rows are 4 KB contiguous -- exactly the LDS image of an operand, so
 //                           staging is plain DMA; the two 16-byte halves of a row sit 2 KB apart, so that the 16-lane groups of a
 //                           ds_read_b128 fragment read (lanes {0-3,12-15,20-27}, ...) touch 16 distinct 16-byte bank groups -- with
 //                           rows of 32 contiguous bytes every fragment read was a 2-way bank conflict
-//   3. gram_i8_kernel       lower-triangle 128 x 128 tiles x sample splits; 8 waves, wave tile 64 x 32, NS int32 diagonals
-//                           (2 x 16 x NS accumulator VGPRs), operands global -> LDS by global_load_lds (double-buffered, 112 KB),
-//                           fragments by ds_read_b128; epilogue: Horner sum of the diagonals in fp64, scale by 2^(e_p+e_q-12),
-//                           fp64 slab in the layout of gram.hip (reduce_splits / finalize are shared)
+//   3. gram_i8_kernel       lower-triangle 128 x 128 tiles x sample splits (the fp64 kernel's XCD-aware Z-order deal); 8 waves, wave tile
+//                           64 x 32, NS int32 diagonals (2 x 16 x NS accumulator VGPRs), operands global -> LDS by global_load_lds
+//                           (three 48 KB K-block buffers), fragments by ds_read_b128; epilogue: Horner sum of the diagonals in fp64,
+//                           scale by 2^(e_p+e_q-14), fp64 slab in the layout of gram.hip
+//   4. reduce_splits_i8_kernel, diag_fix_kernel (the dropped diagonal squares; the heavy-tail figure max_p row max / row rms)
 #include <algorithm>
 #include <vector>
 
