@@ -24,6 +24,8 @@ CONFIGS = [
     (3, 3, (4,), "Gauss", "no_add+global"),              # global_change (net.py:72,80-82,115-116,150-151), odd d
     (6, 11, (3,), "Student_t", "different_add+global"),  # ... with t-networks; 11 blocks: 'blocks_10' sorts before 'blocks_2'
     (16, 2, (5, 4, 3), "Student_t", "different_add"),    # the ABI's maxima: d = VMCPDE_MAX_DIM (136 Hessian directions), three hidden layers
+    (2, 2, (50,), "Gauss", "no_add"),                    # wider than 8 waves x 6 outputs: two Taylor buffers, eps in an LDS line, 32-sample workgroups
+    (4, 1, (19, 19), "Gauss", "different_add"),          # the in-place plan with the s stash and both networks of a half-step
 ]
 
 
