@@ -285,6 +285,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert torch.isfinite(update).all(), "non-finite TDVP update"
+    tdvp.check("last timed step")          # the health record of the final solve (the earlier ones were checked by the calls that followed them)
     resid = float(tdvp.solverResidual)
 
     # HIP-event brackets on the launch stream inside the timed steps, averaged over the steps: what this rank spent in its shard's

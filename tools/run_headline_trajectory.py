@@ -14,7 +14,8 @@ else:
 sampler = V.Sampler(key=7, dim=dim, name="Gauss", mcmc_info={"offset": offset, "bound": 0.25})
 vs = V.VarState(sampler, dim, 1, 4, network_args={"intmediate": HID, "offset": offset, "latentSpaceName": "Gauss", "dim": dim})
 eq = V.EvolutionEquation(dim=dim, name="advection_hamiltonian_wDiss")
-tdvp = V.TDVP(diagonalShift=shift, svdTol=float(os.environ.get("SVD_TOL", "1e-6")), solver="cholesky")
+tdvp = V.TDVP(diagonalShift=shift, svdTol=float(os.environ.get("SVD_TOL", "1e-6")), solver="cholesky",
+              int8Gram=os.environ.get("INT8_GRAM", "0") == "1")      # INT8_GRAM=1: the S-build on the int8 matrix pipe (experiment)
 stepper = V.FixedStepper(timeStep=1e-4, mode="Heun", maxStep=1e-2, increase_fac=1.3)
 t, n, t0 = 0.0, 0, time.perf_counter()
 next_print = 0.5
