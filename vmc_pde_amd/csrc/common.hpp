@@ -99,6 +99,8 @@ struct LatentCache {
 // and created under a lock: a process may drive several GPUs and call from several threads (one stream per thread).
 struct DeviceCtx {
   hipStream_t side = nullptr;
+  hipStream_t side_masked = nullptr;            // Cholesky lookahead at super-panel level: bulk updates on all but every eighth CU
+  int side_masked_state = 0;                    // 0 not tried, 1 available, -1 the CU-masked stream could not be created
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool attr_chol = false, attr_gram = false, attr_gram_f32 = false, attr_gram_dma = false, attr_solve = false;
   bool attr_gram_i8[3] = {false, false, false};   // (6 slices x 8 bits, 6 x 7, 7 x 7) of the int8 experiment

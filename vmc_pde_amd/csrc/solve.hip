@@ -913,7 +913,7 @@ __global__ __launch_bounds__(D16_THREADS) void chol_update_diag16_kernel(double*
                                                                          int jhi, int nbk, int ntiles, int tpw, int k1,
                                                                          double* __restrict__ Linv_next, int* __restrict__ info) {
   if (blockIdx.x == 0) {
-    chol_diag16_body<D16_THREADS>(A, lda, k1, (P - k1 < NB) ? (P - k1) : NB, Linv_next, info);
+    if (k1 >= 0) chol_diag16_body<D16_THREADS>(A, lda, k1, (P - k1 < NB) ? (P - k1) : NB, Linv_next, info);     // (k1 < 0: a bulk launch without the block)
     return;
   }
   extern __shared__ double lds[];
@@ -1242,6 +1242,25 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
     static_assert(2 * TILE_DMA_LDS_BYTES <= ((size_t)NB * DP + 4 * SB * 17 + 2 * SB) * sizeof(double), "two tiles per workgroup of the update launch");
     int W = env_int("VMCPDE_CHOL_SUPER", 0);
     if (W <= 0) W = (nb >= SUPER_MIN_BLOCKS) ? SUPER_WIDTH : 1;
+    // Lookahead at super-panel level (two-level schedule only): the K = 128 W update that closes super-panel s is split.  Part (a), the
+    // block columns of super-panel s + 1, stays on the caller's stream together with the next diagonal block; part (b), everything to
+    // the right of s + 1, goes to a side stream whose queue is masked to 7 of every 8 CUs, so the latency chain of super-panel s + 1
+    // (diagonal blocks, strips, its K = 128 tiles) always finds free CUs and runs UNDER (b) instead of behind it.  (b) of super-panel s
+    // must be complete before the last panel of s + 1 touches the first block column of s + 2 (mode-1 strips) and before (b) of s + 1.
+    bool overlap = (W > 1) && env_int("VMCPDE_CHOL_OVERLAP", 1) != 0;
+    hipStream_t bulk = nullptr;
+    if (overlap) {
+      DeviceCtxLock lock;
+      if (ctx->side_masked_state == 0) {
+        uint32_t mask[8];                                   // 256 CUs; bit i = CU i: leave every eighth CU to the chain
+        for (int i = 0; i < 8; ++i) mask[i] = 0xFEFEFEFEu;
+        ctx->side_masked_state = (hipExtStreamCreateWithCUMask(&ctx->side_masked, 8, mask) == hipSuccess && ctx->side_masked) ? 1 : -1;
+        if (ctx->side_masked_state < 0) (void)hipGetLastError();
+      }
+      overlap = ctx->side_masked_state == 1;
+      bulk = ctx->side_masked;
+    }
+    bool bulk_pending = false;
     for (int k = 0; k + 1 < nb; ++k) {
       const int k0 = k * NB;
       const int nrem = nb - (k + 1);                                  // block rows below the panel
@@ -1251,6 +1270,10 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
       const int nchunk = last_of_super ? (k + 1 - s0) : 1;
       const int c0 = k0 + NB;
       const double* Lk = Linv + (int64_t)k * NB * NB;
+      if (last_of_super && bulk_pending) {                            // (b) of the previous super-panel has to be in place now
+        VMC_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
+        bulk_pending = false;
+      }
       if (8 * nrem <= 256) {
         hipLaunchKernelGGL(chol_strip_kernel<16>, dim3(8 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 1, c0, 0, Lk);
         hipLaunchKernelGGL(chol_strip_kernel<16>, dim3(8 * nrem), dim3(256), strip_lds, st, A, lda, P, kc0, nchunk, c0, 1, Lk);
@@ -1258,13 +1281,29 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
         hipLaunchKernelGGL(chol_strip_kernel<32>, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, P, k0, 1, c0, 0, Lk);
         hipLaunchKernelGGL(chol_strip_kernel<32>, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, P, kc0, nchunk, c0, 1, Lk);
       }
-      const int jlo = k + 2, jhi = last_of_super ? nb : s1;
-      int64_t ntiles = 0;
-      for (int j = jlo; j < jhi; ++j) ntiles += nb - j;
+      const int jlo = k + 2;
+      int jhi = last_of_super ? nb : s1;
+      const int jsplit = (s1 + W < nb) ? (s1 + W) : nb;              // end of the next super-panel
+      const bool split = overlap && last_of_super && jsplit < nb && jlo < jsplit;
+      if (split) jhi = jsplit;
+      auto count_tiles = [&](int a, int b) { int64_t n = 0; for (int j = a; j < b; ++j) n += nb - j; return n; };
+      const int64_t ntiles = count_tiles(jlo, jhi);
       const int tpw = (ntiles <= 255) ? 1 : 2;
+      if (split) {      // the strips of this panel completed the L columns of the super-panel: fork behind them, in front of part (a)
+        VMC_CHECK_HIP(hipEventRecord(ev_fork, st));
+        VMC_CHECK_HIP(hipStreamWaitEvent(bulk, ev_fork, 0));
+      }
       hipLaunchKernelGGL(chol_update_diag16_kernel, dim3(1u + (unsigned)((ntiles + tpw - 1) / tpw)), dim3(D16_THREADS), diag_lds, st, A, lda, P, kc0,
                          nchunk * NB, jlo, jhi, nb, (int)ntiles, tpw, c0, Linv + (int64_t)(k + 1) * NB * NB, info);
+      if (split) {
+        const int64_t nt_b = count_tiles(jsplit, nb);
+        hipLaunchKernelGGL(chol_update_diag16_kernel, dim3(1u + (unsigned)((nt_b + 1) / 2)), dim3(D16_THREADS), diag_lds, bulk, A, lda, P, kc0,
+                           nchunk * NB, jsplit, nb, nb, (int)nt_b, 2, -1, (double*)nullptr, info);
+        VMC_CHECK_HIP(hipEventRecord(ev_join, bulk));
+        bulk_pending = true;
+      }
     }
+    if (bulk_pending) VMC_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
     VMC_CHECK_HIP(hipGetLastError());
     return 0;
   }
