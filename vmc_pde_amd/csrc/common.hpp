@@ -104,7 +104,8 @@ struct DeviceCtx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool attr_chol = false, attr_gram = false, attr_gram_f32 = false, attr_gram_dma = false, attr_solve = false;
   bool attr_gram_i8[3] = {false, false, false};   // (6 slices x 8 bits, 6 x 7, 7 x 7) of the int8 experiment
-  int flow_eval_lds = 0, flow_eval_lds_cap = 0, flow_eval_lds2 = 0, flow_eval_lds4 = 0, flow_sample_lds = 0;   // largest dynamic-LDS size the flow kernels (per directions-per-pass variant) were raised to
+  int flow_eval_lds_by[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // largest dynamic-LDS size flow_eval_kernel was raised to, by [block width variant][KD = 1, KD = 1 capped, 2, 4]
+  int flow_sample_lds_by[2] = {0, 0};
   std::map<int, int*> gram_perms;               // [dev] Gram tile orders (position -> lower-triangle tile index) by number of row blocks: built once
                                                 // per matrix size and GPU and never freed, so alternating sizes / threads never re-synchronise
 };
