@@ -54,11 +54,13 @@ F32BLOCKS_DIAG_SHIFT = 1e-4     # --jacobian f32blocks only (vmc_pde_amd.tdvp.F3
 PEAK_F64_MFMA_TFLOPS = 78.6     # AMD MI355X spec, fp64 matrix (dense); the guide has no measured f64 MFMA figure
 PEAK_F32_MFMA_TFLOPS = 157.3    # fp32 matrix (MI355X_MICROARCH.md: 157.3 spec / 155 measured) -- only for --jacobian f32blocks
 PEAK_I8_MFMA_POPS = 5.0         # int8 matrix, dense (MI355X_MICROARCH.md: 2x the bf16 rate per clock) -- only for --jacobian i8sliced
-DTYPE_LABEL = {"f64": "f64", "i8sliced": "f64 Jacobian, error-free int8 slicing (six balanced 8-bit digits), int32 sums, f64 combine (experiment)",
+DTYPE_LABEL = {"f64": "f64", "i8f32": "f32 Jacobian storage, four 8-bit int8 digits, int32 sums, f64 combine (BASELINE config 5 on the int8 pipe, experiment)",
+               "i8sliced": "f64 Jacobian, error-free int8 slicing (six balanced 8-bit digits), int32 sums, f64 combine (experiment)",
                "f32": "f64 accumulate, f32 Jacobian storage (BASELINE config 5)",
                "f32blocks": "f32 Jacobian, f32 MFMA sums over 128-sample blocks, f64 across blocks (BASELINE config 5, fast variant)"}
-OPERAND_LABEL = {"f64": "uncentred+DMA", "i8sliced": "uncentred, int8 digit planes + DMA", "f32": "uncentred, fp32 widened in staging", "f32blocks": "uncentred+DMA, fp32 MFMA blocks"}
+OPERAND_LABEL = {"f64": "uncentred+DMA", "i8f32": "uncentred, 4 int8 digit planes + DMA", "i8sliced": "uncentred, int8 digit planes + DMA", "f32": "uncentred, fp32 widened in staging", "f32blocks": "uncentred+DMA, fp32 MFMA blocks"}
 KERNEL_LABEL = {"f64": "gram_dma_kernel (fp64 MFMA syrk, + split-K reduce)",
+                "i8f32": "row_expo + slice + gram_i8_kernel<4,8,8> (v_mfma_i32_32x32x32_i8, 10 digit pairs) + split reduce + diagonal fix",
                 "i8sliced": "row_expo + slice + gram_i8_kernel<6,8,8> (v_mfma_i32_32x32x32_i8, 21 digit pairs) + split reduce + diagonal fix",
                 "f32": "gram_kernel<false,false,float> (fp32 operands widened, fp64 MFMA syrk, + split-K reduce)",
                 "f32blocks": "gram_f32_kernel (fp32 MFMA block sums, fp64 across blocks, + split-K reduce)"}
@@ -226,7 +228,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="BASELINE config (default C2, the headline)")
     ap.add_argument("--samples", type=int, default=0, help="samples per rank (default: the workload's)")
-    ap.add_argument("--jacobian", default="f64", choices=["f64", "f32", "f32blocks", "i8sliced"],
+    ap.add_argument("--jacobian", default="f64", choices=["f64", "f32", "f32blocks", "i8sliced", "i8f32"],
                     help="storage type of the per-sample Jacobian (f32 = BASELINE config 5: fp32 storage, fp64 products and sums; "
                          "f32blocks: fp32 MFMA sums over blocks of 128 samples, fp64 across blocks)")
     args = ap.parse_args()
@@ -254,7 +256,7 @@ def main():
     if not args.samples:
         args.samples = WORKLOADS[args.workload]["n_samp"]
     vs, eq, tdvp, theta = build_problem(device, args.workload, jacobian_dtype=torch.float64 if args.jacobian in ("f64", "i8sliced") else torch.float32)
-    if args.jacobian == "i8sliced":      # experiment, reported BESIDE the fp64 headline, never instead of it
+    if args.jacobian in ("i8sliced", "i8f32"):      # experiments, reported BESIDE the fp64 headline, never instead of it
         tdvp.int8Gram = True
     if args.jacobian == "f32blocks":     # fp32 accumulation inside 128-sample blocks is not exactly PSD: needs the stronger shift
         tdvp.f32BlockGram = True
@@ -335,8 +337,9 @@ def main():
 
     if rank == 0:
         peak_spec = PEAK_F32_MFMA_TFLOPS if args.jacobian == "f32blocks" else PEAK_F64_MFMA_TFLOPS
-        if args.jacobian == "i8sliced":      # the roofline of this variant is the int8 matrix pipe: 21 digit-pair products per fp64 product
-            achieved = 21.0 * flops / (gram_ms * 1e-3) / 1e12
+        i8_pairs = {"i8sliced": 21.0, "i8f32": 10.0}.get(args.jacobian)
+        if i8_pairs:      # the roofline of these variants is the int8 matrix pipe: 21 (10) digit-pair products per fp64 product
+            achieved = i8_pairs * flops / (gram_ms * 1e-3) / 1e12
             peak_spec = PEAK_I8_MFMA_POPS * 1e3
         # HBM traffic of the Gram kernel: NOT measured in this run (PMC counters need their own rocprofv3 passes); the figure of
         # the committed counter profile of the same workload is quoted, with its source
@@ -364,12 +367,12 @@ def main():
                        "mean2_over_var_max": ratio,
                        "diagonal_shift": float(tdvp.diagonalShift), "svd_tol": float(tdvp.svdTol), "solver_residual": resid,
                        "parallelism": f"dp{world} (samples sharded, one all-reduce of (S,F) per step)"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak_spec, "unit": "TFLOP/s" if args.jacobian != "i8sliced" else "TOP/s (int8)",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak_spec, "unit": "TFLOP/s" if not i8_pairs else "TOP/s (int8)",
                          "frac": achieved / peak_spec, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": KERNEL_LABEL[args.jacobian], "ms_per_launch": gram_ms,
-                         "algorithmic_flops_per_launch": flops if args.jacobian != "i8sliced" else 21.0 * flops,
+                         "algorithmic_flops_per_launch": flops * (i8_pairs or 1.0),
                          "fp64_equivalent_tflops": flops / (gram_ms * 1e-3) / 1e12, "measured_mfma_f64_peak": peak_meas,
-                         "frac_of_measured_peak": achieved / peak_meas if (peak_meas > 0 and args.jacobian != "i8sliced") else None},
+                         "frac_of_measured_peak": achieved / peak_meas if (peak_meas > 0 and not i8_pairs) else None},
             "stages_ms": stage_ms, "heun_step_ms": heun_ms,
             # per-rank HIP-event averages over the timed steps (ms): the Amdahl terms of the multi-GPU step
             "rank_stage_ms": [dict(zip(order, r)) for r in per_rank],

@@ -186,13 +186,14 @@ int vmcpde_tdvp_moments(const double* packed, int32_t P, int32_t bordered, doubl
                         void* stream);
 /* EXPERIMENT (opt-in): the same packed sums as vmcpde_gram(JT, ldj, 0, P, n, c, w, ...) -- tdvp.py:46-47, mpi_wrapper.py:21-25; c
  * (centring shift per parameter) and w (weight per sample) may be NULL -- formed on the INT8 matrix pipe from an error-free slicing of the fp64 Jacobian (csrc/gram_i8.hip): per-row
- * power-of-two scale, n_slices (6 or 7) int8 slices of 7 bits, the n_slices (n_slices + 1) / 2 slice-pair products with
+ * power-of-two scale, n_slices int8 digits of digit_bits bits -- (6, 8) the default; (6, 7), (7, 7) for the record; (4, 8) = 31 bits for
+ * an fp32 Jacobian (jt_f32 = 1: BASELINE config 5, every stored value is represented to 2^-31 of its row maximum), 10 digit pairs --, the n_slices (n_slices + 1) / 2 slice-pair products with
  * s + t < n_slices summed exactly in int32 and combined in fp64.  Exact on integer data; on real data the dropped terms are
  * ~1e-14 (row max / row rms)^2 of |S|_F for 6 slices; stats ([dev] 1 double, may be NULL) receives the largest row max / row rms
  * (within a factor two; at most sqrt(n)), which a caller can watch (TDVP falls back to the fp64 kernel above 64).  workspace: [dev] vmcpde_gram_i8_workspace_bytes (row exponents, the
  * n_slices int8 planes = n_slices * P_pad * N bytes, split slabs). */
 int64_t vmcpde_gram_i8_workspace_bytes(int32_t P, int64_t n_samples, int32_t n_slices, int32_t digit_bits);
-int vmcpde_gram_i8(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, int32_t n_slices, int32_t digit_bits, const double* c,
+int vmcpde_gram_i8(const void* JT, int64_t ldj, int32_t jt_f32, int32_t P, int64_t n_samples, int32_t n_slices, int32_t digit_bits, const double* c,
                    const double* w, double* packed, double* stats, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* tdvp.py:93-94 from u and S0 u: out[0] = |S u - F| / |F| with S u = S0 u + (diagonal_shift * diagS + floor_dev[0]) u

@@ -191,16 +191,16 @@ def test_row_moments_eloc_stats_and_finalize():
 
 
 # ---- the INT8 experiment (csrc/gram_i8.hip): error-free sliced Gram, same packed sums as the uncentred fp64 kernel ------------------------
-def _gram_i8(JT, ldj, P, N, slices=6, bits=8, c=None, w=None, stats=None):
+def _gram_i8(JT, ldj, P, N, slices=6, bits=8, c=None, w=None, stats=None, f32=0):
     npk = nat.lib().vmcpde_gram_packed_doubles(P)
     packed = torch.full((npk,), float("nan"), dtype=torch.float64, device=DEV)
     need = nat.lib().vmcpde_gram_i8_workspace_bytes(P, N, slices, bits)
     ws = torch.empty(need // 8 + 1, dtype=torch.float64, device=DEV)
-    nat.call("vmcpde_gram_i8", nat.ptr(JT), ldj, P, N, slices, bits, nat.ptr(c), nat.ptr(w), nat.ptr(packed), nat.ptr(stats), nat.ptr(ws), ws.numel() * 8, nat.stream())
+    nat.call("vmcpde_gram_i8", nat.ptr(JT), ldj, f32, P, N, slices, bits, nat.ptr(c), nat.ptr(w), nat.ptr(packed), nat.ptr(stats), nat.ptr(ws), ws.numel() * 8, nat.stream())
     return packed
 
 
-@pytest.mark.parametrize("slices,bits", [(6, 8), (6, 7), (7, 7)])
+@pytest.mark.parametrize("slices,bits", [(6, 8), (6, 7), (7, 7), (4, 8)])
 def test_gram_i8_lane_maps_with_asymmetric_integer_operand(slices, bits):
     # exact small integers with an asymmetric pattern: a wrong A/B lane map, C/D map, slice order or digit weight shows up bit for bit
     P, N = 300, 200          # ragged in both directions: padded rows, a partial K-block, three tile rows
@@ -209,8 +209,10 @@ def test_gram_i8_lane_maps_with_asymmetric_integer_operand(slices, bits):
     JT[:P, :N] = torch.as_tensor(J.T)
     assert np.array_equal(_unpack(_gram_i8(JT, 208, P, N, slices, bits), P), J.T @ J)
     # wider integers need several digits: still exact (every kept digit-pair sum is an exact integer; nothing is dropped below 2^40)
+    # (four digits keep the pairs with s + t <= 3: two-digit integers -- 11 bits -- are the widest that stay exact)
     rng = np.random.default_rng(3)
-    J = rng.integers(-(1 << 19), 1 << 19, (N, P)).astype(np.float64)
+    wide = 19 if slices >= 6 else 11
+    J = rng.integers(-(1 << wide), 1 << wide, (N, P)).astype(np.float64)
     JT[:P, :N] = torch.as_tensor(J.T)
     assert np.array_equal(_unpack(_gram_i8(JT, 208, P, N, slices, bits), P), J.T @ J)
 
@@ -277,3 +279,23 @@ def test_gram_i8_reports_heavy_tails():
     JT[17, 5] = 1e6
     _gram_i8(JT, ldj, P, N, stats=st)
     assert 100.0 < float(st[0]) < 300.0            # sqrt(20000) = 141, times the head-room factor
+
+
+@pytest.mark.parametrize("P,N", [(129, 1000), (411, 5000), (1030, 40000)])
+def test_gram_i8_four_digits_on_an_fp32_jacobian(P, N):
+    """BASELINE config 5 on the int8 pipe: an fp32 Jacobian sliced into four 8-bit digits (31 bits: every stored value to 2^-31 of its row
+    maximum, 10 digit pairs).  Against the widening fp64 kernel on the same fp32 values: 1e-8 in correlation form (measured 6e-9 at
+    4096 x 65536 -- the size of the fp32 storage error itself, which is what config 5 is about); bit-exact on integer data."""
+    rng = np.random.default_rng(P)
+    J, JT, ldj = _jt(P, N, seed=P + 5, mean=0.3)
+    scale = 10.0 ** rng.uniform(-2, 2, P)
+    J32 = (JT * torch.as_tensor(scale.tolist() + [1.0] * (JT.shape[0] - P), device=DEV)[:, None]).float().contiguous()
+    ref = _unpack(_gram(J32, ldj, P, N, f32=1), P)
+    got = _unpack(_gram_i8(J32, ldj, P, N, slices=4, bits=8, f32=1), P)
+    d = np.sqrt(np.diag(ref))
+    assert np.linalg.norm((got - ref) / np.outer(d, d)) / np.linalg.norm(ref / np.outer(d, d)) < 1e-8
+    Ji = torch.zeros_like(J32)
+    Ji[:P, :N] = torch.as_tensor(rng.integers(-100, 101, (P, N)).astype(np.float32)).to(DEV)
+    assert np.array_equal(_unpack(_gram_i8(Ji, ldj, P, N, slices=4, bits=8, f32=1), P), _unpack(_gram(Ji, ldj, P, N, f32=1), P))
+    with pytest.raises(nat.VmcpdeError, match="fp32 Jacobian"):
+        _gram_i8(J32, ldj, P, N, slices=7, bits=7, f32=1)

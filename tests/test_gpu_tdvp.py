@@ -725,3 +725,31 @@ def test_int8_gram_falls_back_on_heavy_tailed_rows():
         tp.get_tdvp_equation(E, J, lp)
     assert not tp._int8_still_ok()
     assert rel_err(tp.S0, torch.cov(J[0].T, correction=0)) < 1e-11
+
+
+def test_int8_gram_on_an_fp32_jacobian_config5():
+    """BASELINE config 5 with the S-build on the int8 pipe: fp32 Jacobian storage, four 8-bit digits, exact int32 sums.  Against the
+    widening fp64 path on the same samples: S, F to 1e-7 (both carry the fp32 storage error, 6e-9; the digits add as much again), the
+    Cholesky update to 1e-5 in the S-norm (config 5 tolerances 1e-6 / 1e-5 against the fp64 reference)."""
+    import vmc_pde_amd as V
+    dim, depth, hidden, latent, coupling, eq, N = 2, 3, (4, 4), "Gauss", "no_add", "advection_hamiltonian_wDiss", 3000
+    spec, th, nrm, chi2, eo, ep = _problem(dim, depth, hidden, latent, coupling, eq, N, lam=0.1)
+    z = O.latent_from_normals(spec, th, nrm, chi2)
+    res = {}
+    for flag in (False, True):
+        vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()), jacobian_dtype=torch.float32)
+        tp = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", int8Gram=flag)
+        kw = dict(nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+        tp(th.cuda(), 0.1, vs, ep, **kw)
+        upd, _ = tp(th.cuda(), 0.1, vs, ep, **kw)
+        tp.check()
+        if flag:
+            assert tp._i8_digits == 4 and tp._int8_still_ok()
+        res[flag] = (tp.S0.clone(), tp.F0.clone(), upd.clone())
+    (S_a, F_a, u_a), (S_b, F_b, u_b) = res[False], res[True]
+    assert rel_err(S_b, S_a) < 1e-7 and rel_err(F_b, F_a) < 1e-7
+    assert float(torch.linalg.norm(S_a @ (u_b - u_a)) / torch.linalg.norm(F_a)) < 1e-5
+    # and against the fp64 oracle: the config-5 tolerances
+    to = O.TDVPOracle()
+    to.rhs(th, 0.1, O.VarStateOracle(spec, th), eo, z)
+    assert rel_err(S_b, to.S0) < 1e-6 and rel_err(F_b, to.F0) < 1e-6

@@ -50,6 +50,9 @@ def run_f64(JT):
     return packed, sorted(ts)[len(ts) // 2]
 
 
+STATS = torch.zeros(1, dtype=torch.float64, device=dev)
+
+
 def run_i8(JT, cfg):
     ns, bits = cfg
     packed = torch.empty(npk, dtype=torch.float64, device=dev)
@@ -59,7 +62,8 @@ def run_i8(JT, cfg):
     for it in range(reps + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        nat.call("vmcpde_gram_i8", nat.ptr(JT), ldj, P, N, ns, bits, None, None, nat.ptr(packed), None, nat.ptr(ws), ws.numel() * 8, nat.stream())
+        nat.call("vmcpde_gram_i8", nat.ptr(JT), ldj if JT.dtype == torch.float64 else JT.shape[1], 1 if JT.dtype == torch.float32 else 0, P, N, ns, bits, None, None,
+                 nat.ptr(packed), nat.ptr(STATS), nat.ptr(ws), ws.numel() * 8, nat.stream())
         e1.record()
         torch.cuda.synchronize()
         if it:
@@ -68,7 +72,7 @@ def run_i8(JT, cfg):
 
 
 mask = lower_mask()
-CFGS = ((6, 8), (6, 7), (7, 7))        # (slices, bits per digit)
+CFGS = ((6, 8), (6, 7), (7, 7), (4, 8))        # (slices, bits per digit)
 g = torch.Generator(device=dev).manual_seed(7)
 JT = torch.zeros((Pp, ldj), dtype=torch.float64, device=dev)
 JT[:P, :N] = torch.randn((P, N), generator=g, dtype=torch.float64, device=dev)
@@ -83,7 +87,7 @@ for ns in CFGS:
     res[f"i8_{ns[0]}x{ns[1]}bit"] = {"ms_incl_slicing": ms, "rel_frobenius_vs_fp64": err, "max_abs_over_max": worst,
                              "pairs": ns[0] * (ns[0] + 1) // 2, "int8_ops": ns[0] * (ns[0] + 1) // 2 * N * P * (P + 1)}
     print(f"int8 sliced, {ns[0]} slices x {ns[1]} bits ({ns[0] * (ns[0] + 1) // 2} pairs): {ms:.3f} ms incl. exponent + slicing passes, rel-Frobenius vs fp64 {err:.2e}, "
-          f"max |d| / max |S| {worst:.2e}, {ns[0] * (ns[0] + 1) // 2 * N * P * (P + 1) / ms * 1e-12:.2f} POP/s overall", flush=True)
+          f"max |d| / max |S| {worst:.2e}, {ns[0] * (ns[0] + 1) // 2 * N * P * (P + 1) / ms * 1e-12:.2f} POP/s overall, row max/rms figure {float(STATS[0]):.1f}", flush=True)
 # exactness on integer data (both kernels are exact there)
 Ji = torch.zeros((Pp, ldj), dtype=torch.float64, device=dev)
 Ji[:P, :N] = torch.randint(-7, 8, (P, N), generator=g, device=dev).double()
@@ -101,5 +105,28 @@ for ns in CFGS:
     got_h, _ = run_i8(Jh, ns)
     err = float(torch.linalg.norm((got_h - ref_h)[mask]) / torch.linalg.norm(ref_h[mask]))
     res[f"i8_{ns[0]}x{ns[1]}bit"]["rel_frobenius_heavy_tailed_J"] = err
-    print(f"heavy-tailed J (cubed normals), {ns[0]} slices x {ns[1]} bits: rel-Frobenius vs fp64 {err:.2e}", flush=True)
+    print(f"heavy-tailed J (cubed normals), {ns[0]} slices x {ns[1]} bits: rel-Frobenius vs fp64 {err:.2e}, row max/rms figure {float(STATS[0]):.1f}", flush=True)
+# BASELINE config 5: an fp32 Jacobian, four 8-bit digits (31 bits) against the widening fp64 kernel on the same fp32 values
+J32 = torch.zeros((Pp, ldj), dtype=torch.float32, device=dev)
+J32[:P, :N] = JT[:P, :N].float()
+packed32 = torch.empty(npk, dtype=torch.float64, device=dev)
+need = lib.vmcpde_gram_workspace_bytes(P, N)
+ws32 = torch.empty(max(need // 8, 1), dtype=torch.float64, device=dev)
+ts = []
+for it in range(reps + 1):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    nat.call("vmcpde_gram", nat.ptr(J32), ldj, 1, P, N, None, None, nat.ptr(packed32), nat.ptr(ws32), ws32.numel() * 8, nat.stream())
+    e1.record()
+    torch.cuda.synchronize()
+    if it:
+        ts.append(e0.elapsed_time(e1))
+ms_w = sorted(ts)[len(ts) // 2]
+got32, ms32 = run_i8(J32, (4, 8))
+err32 = float(torch.linalg.norm((got32 - packed32)[mask]) / torch.linalg.norm(packed32[mask]))
+err64 = float(torch.linalg.norm((got32 - ref)[mask]) / torch.linalg.norm(ref[mask]))
+res["i8_4x8bit_on_fp32_J"] = {"ms_incl_slicing": ms32, "widening_fp64_kernel_ms": ms_w, "rel_frobenius_vs_widening_fp64_kernel": err32,
+                              "rel_frobenius_vs_fp64_J": err64}
+print(f"fp32 Jacobian (config 5): int8 4 x 8 bits {ms32:.3f} ms incl. slicing against {ms_w:.3f} ms for the widening fp64 kernel; rel-Frobenius vs that kernel "
+      f"{err32:.2e}, vs the fp64 Jacobian's Gram {err64:.2e}", flush=True)
 print(json.dumps(res))

@@ -70,7 +70,7 @@ _PROTOS = {
     "vmcpde_gram_workspace_bytes": (_i64, [_i32, _i64]),
     "vmcpde_gram": (_int, [_vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "vmcpde_gram_i8_workspace_bytes": (_i64, [_i32, _i64, _i32, _i32]),
-    "vmcpde_gram_i8": (_int, [_vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "vmcpde_gram_i8": (_int, [_vp, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "vmcpde_gram_finalize": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f64, _f64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "vmcpde_tdvp_prepare_workspace_bytes": (_i64, []),
     "vmcpde_tdvp_prepare": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

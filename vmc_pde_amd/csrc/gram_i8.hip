@@ -43,21 +43,22 @@ constexpr int KB = 32;                 // samples per K-block = bytes per fragme
 
 // e_p: |J[p][n]| / 2^e_p < 1 for every n (0 for an all-zero row)
 // (optional centring shift c[p] and per-sample weight w[n]: the sliced operand is (J[p][n] - c[p]) w[n], as in gram.hip's staged variants)
-__global__ __launch_bounds__(256) void row_expo_kernel(const double* __restrict__ JT, int64_t ldj, int64_t N, int P, int headroom,
+template <typename TIn>
+__global__ __launch_bounds__(256) void row_expo_kernel(const TIn* __restrict__ JT, int64_t ldj, int64_t N, int P, int headroom,
                                                        const double* __restrict__ c, const double* __restrict__ w, int* __restrict__ expo) {
   __shared__ double red[4];
   const int t = threadIdx.x, p = blockIdx.x;
   double mx = 0.0;
   if (p < P) {
-    const double* __restrict__ row = JT + (int64_t)p * ldj;
+    const TIn* __restrict__ row = JT + (int64_t)p * ldj;
     const double cp = c ? c[p] : 0.0;
     const int64_t N2 = N & ~(int64_t)1;
     for (int64_t n = 2 * t; n < N2; n += 512) {
-      const double2_t v = *reinterpret_cast<const double2_t*>(row + n);
-      const double a = (v.x - cp) * (w ? w[n] : 1.0), b = (v.y - cp) * (w ? w[n + 1] : 1.0);
+      const typename PairOf<TIn>::type v = *reinterpret_cast<const typename PairOf<TIn>::type*>(row + n);
+      const double a = ((double)v.x - cp) * (w ? w[n] : 1.0), b = ((double)v.y - cp) * (w ? w[n + 1] : 1.0);
       mx = fmax(mx, fmax(fabs(a), fabs(b)));
     }
-    if (t == 0 && N2 < N) mx = fmax(mx, fabs((row[N2] - cp) * (w ? w[N2] : 1.0)));
+    if (t == 0 && N2 < N) mx = fmax(mx, fabs(((double)row[N2] - cp) * (w ? w[N2] : 1.0)));
   }
   for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
   if ((t & 63) == 0) red[t >> 6] = mx;
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(256) void row_expo_kernel(const double* __restrict_
 // dsum[3p+1] = sum_n sum_{s+t=NS+2} d_s d_t (exact integers, integer atomics: deterministic), and dsum[3p+2] = sum_n (d_0 2^BITS + d_1)^2 for the heavy-tail figure of diag_fix_kernel.  For p != q the dropped pair products
 // have random signs and sum to ~sqrt(N); on the diagonal the (s,s) terms are squares -- a bias of 5e-12 |S|_F at NS = 6, BITS = 7 if left out.
 constexpr int SL_ROWS = 32, SL_KB_PER_WG = 64;
-template <int NS, int BITS>
-__global__ __launch_bounds__(256) void slice_kernel(const double* __restrict__ JT, int64_t ldj, int64_t N, int P, int Ppad, const int* __restrict__ expo,
+template <int NS, int BITS, typename TIn>
+__global__ __launch_bounds__(256) void slice_kernel(const TIn* __restrict__ JT, int64_t ldj, int64_t N, int P, int Ppad, const int* __restrict__ expo,
                                                     const double* __restrict__ c, const double* __restrict__ w, int8_t* __restrict__ planes,
                                                     int64_t nkb, unsigned long long* __restrict__ dsum) {
   const int t = threadIdx.x;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void slice_kernel(const double* __restrict__ J
   const bool rowok = p < P;
   // expo[p] already holds the head-room bit for BITS = 8
   const int shift = rowok ? (BITS == 7 ? 6 : 8 * NS - 1) - expo[p] : 0;      // (ldexp per value: 2^shift itself may not be representable)
-  const double* __restrict__ src = JT + (int64_t)(rowok ? p : 0) * ldj;
+  const TIn* __restrict__ src = JT + (int64_t)(rowok ? p : 0) * ldj;
   const double cp = (c && rowok) ? c[p] : 0.0;
   const int64_t kb_lo = (int64_t)blockIdx.y * SL_KB_PER_WG;
   long long t_lo = 0, t_hi = 0, t_top = 0;
@@ -106,11 +107,11 @@ __global__ __launch_bounds__(256) void slice_kernel(const double* __restrict__ J
     for (int q = 0; q < 8; q += 2) {
       double2_t v = {0.0, 0.0};
       if (rowok && n0 + q + 1 < N) {
-        v = *reinterpret_cast<const double2_t*>(src + n0 + q);
-        v.x = (v.x - cp) * (w ? w[n0 + q] : 1.0);
-        v.y = (v.y - cp) * (w ? w[n0 + q + 1] : 1.0);
+        const typename PairOf<TIn>::type u2 = *reinterpret_cast<const typename PairOf<TIn>::type*>(src + n0 + q);
+        v.x = ((double)u2.x - cp) * (w ? w[n0 + q] : 1.0);
+        v.y = ((double)u2.y - cp) * (w ? w[n0 + q + 1] : 1.0);
       } else if (rowok && n0 + q < N) {
-        v.x = (src[n0 + q] - cp) * (w ? w[n0 + q] : 1.0);
+        v.x = ((double)src[n0 + q] - cp) * (w ? w[n0 + q] : 1.0);
       }
       x[q] = ldexp(v.x, shift);
       x[q + 1] = ldexp(v.y, shift);
@@ -370,7 +371,7 @@ struct I8Plan {
   int64_t nkb, kb_per_split;
 };
 
-I8Plan make_i8_plan(int P, int64_t N, int bits) {
+I8Plan make_i8_plan(int P, int64_t N, int bits, int n_slices = 6) {
   I8Plan g;
   g.nb = (P + TILE - 1) / TILE;
   g.ntiles = (int)tri_count(g.nb);
@@ -378,7 +379,7 @@ I8Plan make_i8_plan(int P, int64_t N, int bits) {
   g.nkb = (N + KB - 1) / KB;
   // one 8-wave workgroup per CU: 256 slots; aim at >= 8 rounds, the last one full.  int32 exactness bounds the samples of a split:
   // 7-bit digits (|d| <= 64, <= 7 pairs per diagonal) 65 536; 8-bit digits (|d| <= 128, <= 6 pairs) 16 384
-  const int64_t cap = (bits == 7) ? 65536 : 16384;
+  const int64_t cap = (bits == 7) ? 65536 : (n_slices <= 4 ? 32768 : 16384);      // (8-bit digits: n_slices pairs of <= 2^14 per diagonal)
   const int64_t min_split = (g.nkb * KB + cap - 1) / cap;
   int64_t want = (8 * 256 + g.ntiles - 1) / g.ntiles;
   if (want < min_split) want = min_split;
@@ -416,14 +417,14 @@ int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 extern "C" int64_t vmcpde_gram_i8_workspace_bytes(int32_t P, int64_t n_samples, int32_t n_slices, int32_t digit_bits) {
   if (P <= 0 || n_samples <= 0 || n_slices < 2 || n_slices > 8 || (digit_bits != 7 && digit_bits != 8)) return 0;
-  const I8Plan g = make_i8_plan(P, n_samples, digit_bits);
+  const I8Plan g = make_i8_plan(P, n_samples, digit_bits, n_slices);
   return align256((int64_t)g.Ppad * (int64_t)sizeof(int)) + align256((int64_t)g.Ppad * 24) + align256(g.nkb * n_slices * (int64_t)g.Ppad * KB) +
          (int64_t)g.nsplit * g.ntiles * TILE * TILE * (int64_t)sizeof(double);
 }
 
-template <int NS, int BITS>
-static int gram_i8_run(const double* JT, int64_t ldj, int P, int64_t N, const double* c, const double* w, double* packed, double* stats, char* ws, hipStream_t st) {
-  const I8Plan g = make_i8_plan(P, N, BITS);
+template <int NS, int BITS, typename TIn>
+static int gram_i8_run(const TIn* JT, int64_t ldj, int P, int64_t N, const double* c, const double* w, double* packed, double* stats, char* ws, hipStream_t st) {
+  const I8Plan g = make_i8_plan(P, N, BITS, NS);
   int* expo = reinterpret_cast<int*>(ws);
   ws += align256((int64_t)g.Ppad * (int64_t)sizeof(int));
   unsigned long long* dsum = reinterpret_cast<unsigned long long*>(ws);
@@ -432,8 +433,8 @@ static int gram_i8_run(const double* JT, int64_t ldj, int P, int64_t N, const do
   double* slabs = reinterpret_cast<double*>(ws + align256(g.nkb * NS * (int64_t)g.Ppad * KB));
   VMC_CHECK_HIP(hipMemsetAsync(dsum, 0, (size_t)g.Ppad * 24, st));
   if (stats) VMC_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double), st));
-  hipLaunchKernelGGL(row_expo_kernel, dim3(g.Ppad), dim3(256), 0, st, JT, ldj, N, P, BITS == 8 ? 1 : 0, c, w, expo);
-  hipLaunchKernelGGL((slice_kernel<NS, BITS>), dim3(g.Ppad / SL_ROWS, (unsigned)((g.nkb + SL_KB_PER_WG - 1) / SL_KB_PER_WG)), dim3(256), 0, st, JT, ldj, N, P,
+  hipLaunchKernelGGL(row_expo_kernel<TIn>, dim3(g.Ppad), dim3(256), 0, st, JT, ldj, N, P, BITS == 8 ? 1 : 0, c, w, expo);
+  hipLaunchKernelGGL((slice_kernel<NS, BITS, TIn>), dim3(g.Ppad / SL_ROWS, (unsigned)((g.nkb + SL_KB_PER_WG - 1) / SL_KB_PER_WG)), dim3(256), 0, st, JT, ldj, N, P,
                      g.Ppad, expo, c, w, planes, g.nkb, dsum);
   constexpr int WAVES = (NS <= 6) ? 8 : 4;          // 7 diagonals of a 64 x 32 wave tile need more than 256 registers
   const size_t one = (size_t)NS * (128 + (WAVES == 8 ? 128 : 64)) * KB;          // one K-block: A + B
@@ -441,7 +442,7 @@ static int gram_i8_run(const double* JT, int64_t ldj, int P, int64_t N, const do
   DeviceCtx* ctx = device_ctx();
   if (!ctx) return -2;
   DeviceCtxLock lock;              // first-use attribute change and the tile-order upload; held over the asynchronous launches (harmless)
-  bool& attr_done = ctx->attr_gram_i8[NS == 7 ? 2 : (BITS == 7 ? 1 : 0)];
+  bool& attr_done = ctx->attr_gram_i8[NS == 7 ? 2 : (NS == 4 ? 3 : (BITS == 7 ? 1 : 0))];
   if (!attr_done) {
     VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_i8_kernel<NS, WAVES, BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
@@ -468,18 +469,26 @@ static int gram_i8_run(const double* JT, int64_t ldj, int P, int64_t N, const do
   return 0;
 }
 
-extern "C" int vmcpde_gram_i8(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, int32_t n_slices, int32_t digit_bits, const double* c,
-                              const double* w, double* packed, double* stats, void* workspace, int64_t workspace_bytes, void* stream) {
+extern "C" int vmcpde_gram_i8(const void* JT, int64_t ldj, int32_t jt_f32, int32_t P, int64_t n_samples, int32_t n_slices, int32_t digit_bits,
+                              const double* c, const double* w, double* packed, double* stats, void* workspace, int64_t workspace_bytes,
+                              void* stream) {
   VMC_REQUIRE(JT && packed && workspace, "vmcpde_gram_i8: null argument");
   VMC_REQUIRE(P >= 1 && n_samples >= 1, "bad shape");
   VMC_REQUIRE(ldj >= n_samples && (ldj % 2) == 0, "ldj must be even and >= n_samples");
   VMC_REQUIRE((reinterpret_cast<uintptr_t>(JT) & 15) == 0, "JT must be 16-byte aligned");
-  VMC_REQUIRE((n_slices == 6 && (digit_bits == 7 || digit_bits == 8)) || (n_slices == 7 && digit_bits == 7),
-              "supported: 6 slices of 7 or 8 bits, 7 slices of 7 bits");
+  VMC_REQUIRE((n_slices == 6 && (digit_bits == 7 || digit_bits == 8)) || (n_slices == 7 && digit_bits == 7) || (n_slices == 4 && digit_bits == 8),
+              "supported: 6 slices of 7 or 8 bits, 7 slices of 7 bits, 4 slices of 8 bits");
+  VMC_REQUIRE(!jt_f32 || (n_slices == 4 || (n_slices == 6 && digit_bits == 8)), "an fp32 Jacobian is sliced into 4 (or 6) digits of 8 bits");
   VMC_REQUIRE(workspace_bytes >= vmcpde_gram_i8_workspace_bytes(P, n_samples, n_slices, digit_bits), "gram_i8 workspace too small: need %lld bytes",
               (long long)vmcpde_gram_i8_workspace_bytes(P, n_samples, n_slices, digit_bits));
   char* ws = static_cast<char*>(workspace);
   hipStream_t st = (hipStream_t)stream;
-  if (n_slices == 7) return gram_i8_run<7, 7>(JT, ldj, P, n_samples, c, w, packed, stats, ws, st);
-  return digit_bits == 8 ? gram_i8_run<6, 8>(JT, ldj, P, n_samples, c, w, packed, stats, ws, st) : gram_i8_run<6, 7>(JT, ldj, P, n_samples, c, w, packed, stats, ws, st);
+  const double* J64 = static_cast<const double*>(JT);
+  const float* J32 = static_cast<const float*>(JT);
+  if (n_slices == 4) return jt_f32 ? gram_i8_run<4, 8, float>(J32, ldj, P, n_samples, c, w, packed, stats, ws, st)
+                                   : gram_i8_run<4, 8, double>(J64, ldj, P, n_samples, c, w, packed, stats, ws, st);
+  if (jt_f32) return gram_i8_run<6, 8, float>(J32, ldj, P, n_samples, c, w, packed, stats, ws, st);
+  if (n_slices == 7) return gram_i8_run<7, 7, double>(J64, ldj, P, n_samples, c, w, packed, stats, ws, st);
+  return digit_bits == 8 ? gram_i8_run<6, 8, double>(J64, ldj, P, n_samples, c, w, packed, stats, ws, st)
+                         : gram_i8_run<6, 7, double>(J64, ldj, P, n_samples, c, w, packed, stats, ws, st);
 }

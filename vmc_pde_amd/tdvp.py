@@ -102,6 +102,7 @@ class TDVP:
         self._guard_pending = self._guard_chol = False
         self._i8_host = self._i8_event = None
         self._i8_off = False
+        self._i8_digits = 6
         self.cholInfo = None
         self._buf = {}
         self._c_prev = None
@@ -151,11 +152,15 @@ class TDVP:
             return False
 
     def _int8_tail_limit(self):
-        """Largest row max / row rms the six-digit int8 Gram is trusted with.  Its error is ~4e-15 x ratio^2 of |S|_F (2e-12 at a ratio of
-        23, measured) and must stay a factor ten below what regularises the solve: the spectral cut-off svdTol, or for the Cholesky the
-        larger of svdTol (absolute floor) and diagonalShift.  (The ratio itself never exceeds sqrt(N).)"""
+        """Largest row max / row rms figure the int8 Gram is trusted with.  Measured (tools/probe_gram_i8.py, 65 536 x 4096): the error of the
+        six-digit form is 1.2e-13 of |S|_F at a figure of 8 (Gaussian rows) and 1.9e-12 at 68 (cubed normals), i.e. ~1.5e-14 x figure^1.3;
+        the four-digit form used for an fp32 Jacobian (31 bits) is 5e4 times that.  The estimate must stay a factor ten below what
+        regularises the solve: the spectral cut-off svdTol, or for the Cholesky the larger of svdTol (absolute floor) and diagonalShift.
+        (Conservative: rows dominated by a few samples -- the model's own Jacobians reach figures of 150-330 -- are summed far more
+        accurately than this, tools/diag/i8_real_jacobian.py; the figure never exceeds ~2 sqrt(N).)"""
         reg = max(float(self.svdTol), float(self.diagonalShift) if self._solver() == "cholesky" else 0.0, 1e-16)
-        return math.sqrt(0.1 * reg / 4e-15)
+        coeff = 1.5e-14 * (5e4 if self._i8_digits == 4 else 1.0)
+        return (0.1 * reg / coeff) ** (1.0 / 1.3)
 
     def _int8_still_ok(self):
         """The per-row scale of the sliced Gram makes its error grow like (row max / row rms)^2: the previous int8 call's figure is
@@ -183,12 +188,14 @@ class TDVP:
             raise ValueError(f"f32BlockGram needs diagonalShift >= {F32_BLOCK_MIN_SHIFT:g} with the Cholesky solver "
                              f"(got {self.diagonalShift:g}); use the widening fp32 path (f32BlockGram=False) for smaller shifts")
         with self._Section(self, "gram"):             # bench.py: HIP events on the launch stream around the S-build
-            if self.int8Gram and f32 == 0 and self._int8_still_ok():
-                need8 = nat.lib().vmcpde_gram_i8_workspace_bytes(P, n, 6, 8)
+            if self.int8Gram and f32 in (0, 1) and self._int8_still_ok():
+                # six digits for an fp64 Jacobian (47 bits); four for an fp32 one (31 bits: every stored value to 2^-31 of its row maximum)
+                ns = self._i8_digits = 6 if f32 == 0 else 4
+                need8 = nat.lib().vmcpde_gram_i8_workspace_bytes(P, n, ns, 8)
                 if b.get("gram_i8_ws") is None or b["gram_i8_ws"].numel() * 8 < need8:
                     b["gram_i8_ws"] = torch.empty(need8 // 8 + 1, dtype=global_defs.tReal, device=JT.device)
                     b["i8_stats"] = torch.zeros(1, dtype=global_defs.tReal, device=JT.device)
-                nat.call("vmcpde_gram_i8", nat.ptr(JT), ldj, P, n, 6, 8, nat.ptr(c), nat.ptr(w), nat.ptr(out), nat.ptr(b["i8_stats"]),
+                nat.call("vmcpde_gram_i8", nat.ptr(JT), ldj, f32, P, n, ns, 8, nat.ptr(c), nat.ptr(w), nat.ptr(out), nat.ptr(b["i8_stats"]),
                          nat.ptr(b["gram_i8_ws"]), b["gram_i8_ws"].numel() * 8, nat.stream())
                 # heavy-tail figure of this call (largest row max / row rms) for the host, without synchronising: read before the next call
                 if self._i8_host is None:
