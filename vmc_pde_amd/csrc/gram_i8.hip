@@ -235,7 +235,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void gram_i8_kernel
   int64_t kb0 = (int64_t)split * kb_per_split;
   int64_t kb1 = (kb0 + kb_per_split < nkb) ? (kb0 + kb_per_split) : nkb;
   // timing diagnostics (VMCPDE_GRAM_I8_DIAG, wrong results): 1 every split reads the first chunk, 2 no barrier in the loop, 4 no DMA in
-  // the loop, 8 no DMA wait in the loop, 16 no raised priority for the DMA pieces, 32 every wave issues its pieces first, 64 all loads from four L2-resident K-blocks
+  // the loop, 8 no DMA wait in the loop, 16 no raised priority for the DMA pieces, 32 every wave issues its pieces first, 64 all loads from four L2-resident K-blocks, 128 no fragment reads and no MFMAs (DMA only), 256 the DMA pieces of a step in one burst
   if (diag_flags & 1) { kb1 -= kb0; kb0 = 0; }
   const bool active = !diag || (64 * wr + 63 >= col0);   // a wave tile entirely above the diagonal of a diagonal tile forms no products
 
@@ -251,10 +251,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void gram_i8_kernel
   // [slice][k half][rows][16 B]; the A image (128 rows) is a plain copy of 4 KB per slice, the B image of the half-tile variant takes the
   // two 1-KiB runs of its 64 rows
   const int npieces = diag ? PA : PA + PB;
-  auto issue = [&](int64_t kb, int buf) {
+  auto issue_some = [&](int64_t kb, int buf, int first, int count) {     // this wave's pieces first .. first + count - 1 of K-block kb
     if (diag_flags & 64) kb = (kb & 3);      // (timing diagnostic: every load hits the same four K-blocks -- L2-resident)
     const char* __restrict__ g0 = reinterpret_cast<const char*>(planes) + ((int64_t)kb * NS) * Ppad * KB;
-    for (int q = wave; q < npieces; q += WAVES) {
+    for (int q = wave + first * WAVES, c = 0; q < npieces && c < count; q += WAVES, ++c) {
       const bool isb = q >= PA;
       const int rem = isb ? q - PA : q;
       const int parts = isb ? BROWS / 32 : 4;
@@ -274,6 +274,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void gram_i8_kernel
       __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
     }
   };
+  auto issue = [&](int64_t kb, int buf) { issue_some(kb, buf, 0, 1 << 20); };
   // Triple-buffered K-blocks (NBUF = 3 where the LDS allows: 3 x 48 KB at 6 slices): the DMA of K-block kb + 2 is issued before the
   // products of kb, and the wait at the end of a step covers only the pieces of kb + 1 (issued a whole step earlier) -- with two
   // buffers every step ended on a full round trip to L2 / HBM.  vmcnt counts this wave's own pieces; the barrier then tells every
@@ -302,18 +303,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void gram_i8_kernel
     wait_all_but_newest(NBUF == 3 && kb0 + 1 < kb1);
     __syncthreads();
   }
-  // The two waves that share a SIMD (w and w + WAVES/2) take their non-MFMA phases at opposite ends of a step: the lower half issues
-  // its DMA pieces first and then multiplies, the upper half multiplies first and issues its pieces last -- with both doing
-  // "DMA, fragment reads, MFMAs" in lockstep behind the step's barrier the matrix pipe idled ~40 % of every step (PMC: MFMA busy 52 %).
+  // Where a wave issues its DMA pieces.  A `global_load_lds` holds the issuing wave for ~100 cycles; in one burst of six per step
+  // (before or behind the products, or the SIMD's two waves at opposite ends: all within 1 %) the wave issues no MFMA for ~700 cycles
+  // and the load path and the matrix pipe took turns instead of overlapping (timing-only builds: DMA alone 5.1 ms, fragment reads +
+  // MFMAs alone 7.6 ms, together 10.1 ms).  One piece behind each slice's group of products -- the other wave of the SIMD multiplies
+  // meanwhile -- takes 1.0 ms off (9 %).  Waves without products (above the diagonal of a diagonal tile) and two-buffer builds keep
+  // the burst: first half of the waves before their products, second half behind.
   const bool dma_first = (NBUF < 3) || (wave < WAVES / 2) || (diag_flags & 32);
+  const bool mid_group = NS <= 4 && wave >= WAVES / 2;    // (four slices: the SIMD's second wave issues in the middle of a group, -0.15 ms; six: no gain)
   for (int64_t kb = kb0; kb < kb1; ++kb) {
     const int64_t ahead = kb + NBUF - 1;
-    if (ahead < kb1 && dma_first && !(diag_flags & 4)) {
+    const bool spread = !(diag_flags & (256 | 128 | 4)) && NBUF == 3 && active && ahead < kb1;   // one piece behind each slice's products
+    if (ahead < kb1 && dma_first && !spread && !(diag_flags & 4)) {
       if (!(diag_flags & 16)) __builtin_amdgcn_s_setprio(2);
       issue(ahead, (cur + NBUF - 1) % NBUF);
       __builtin_amdgcn_s_setprio(0);
     }
-    if (active) {
+    if (active && !(diag_flags & 128)) {
       // fragment of lane (r32, h): 16 bytes of row r at k half h = image[slice][h][row] (int4 units: slice 256 / 2 BROWS, half 128 / BROWS)
       const int4_t* __restrict__ ap = lds_i8 + cur * BUF + h * 128 + 64 * wr + r32;
       // B fragment rows: on a diagonal tile they are rows of the A image; else the B image holds the BROWS rows this unit needs
@@ -337,15 +343,24 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void gram_i8_kernel
 #pragma unroll
         for (int tt = 0; tt < NS; ++tt)
           if (s + tt < NS) {
+            if (spread && mid_group && tt == (NS - s) / 2) {
+              __builtin_amdgcn_sched_barrier(0);
+              issue_some(ahead, (cur + NBUF - 1) % NBUF, s, s + 1 < NS ? 1 : 1 << 20);
+              __builtin_amdgcn_sched_barrier(0);
+            }
             acc[s + tt][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b[tt], acc[s + tt][0], 0, 0, 0);
             acc[s + tt][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b[tt], acc[s + tt][1], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);
+        if (spread && !mid_group) {
+          issue_some(ahead, (cur + NBUF - 1) % NBUF, s, s + 1 < NS ? 1 : 1 << 20);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         a0 = n0;
         a1 = n1;
       }
     }
-    if (ahead < kb1 && !dma_first && !(diag_flags & 4)) issue(ahead, (cur + NBUF - 1) % NBUF);
+    if (ahead < kb1 && !dma_first && !spread && !(diag_flags & 4)) issue(ahead, (cur + NBUF - 1) % NBUF);
     // K-block kb + 1 must have landed; with three buffers the pieces of kb + 2 issued in this step may stay in flight
     if (!(diag_flags & 8)) wait_all_but_newest(NBUF == 3 && ahead < kb1);
     if (!(diag_flags & 2)) __syncthreads();
