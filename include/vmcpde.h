@@ -248,6 +248,29 @@ int vmcpde_gemv(const double* A, int64_t lda, int32_t rows, int32_t cols, int tr
 int vmcpde_pinv_coeffs(const double* ev, const double* VtF, const double* snr, int32_t P, double svdTol, double snrTol,
                        double* coef, void* stream);
 
+/* ---- tdvp.py:57-64 (eigh of S), the dependent chains of the rank-revealing decomposition (csrc/eig.hip) --------------------------
+ * The reference diagonalises the full P x P matrix.  S = <J^T J> of these models is numerically rank deficient (238 of 4213
+ * eigenvalues above 1e-16 of the largest at the headline size), and a full decomposition [null-space basis | Ritz vectors] follows
+ * from a pivoted Cholesky factor of S and a Householder QR of that factor in O(P r^2) (vmc_pde_amd/tdvp.py makes the GEMMs).
+ *
+ * vmcpde_pivoted_cholesky: steps [first_step, first_step + n_steps) of S = L L^T + R with diagonal pivoting (dpstrf's algorithm,
+ * unblocked, no row interchanges: rows keep their place, L[piv[j]][k] = 0 for j < k).  S: [dev] symmetric, full storage, pitch lds
+ * (row p is read as column p).  LT: [dev] max_rank x ldl, LT[k][i] = L[i][k], ldl = P rounded up to a multiple of 64 (pad columns are
+ * written as zeros).  piv: [dev] max_rank pivot rows.  state: [dev] 2 x int32 -- state[0] = columns completed, state[1] = 1 once the
+ * largest remaining diagonal entry was <= tol_rel * max diag(S) (or not a positive number): further steps return at once.
+ * first_step = 0 starts a new factorisation; later calls continue it (same arguments and workspace), so the host can run a chunk,
+ * read `state`, and go on.  Workspace head, two doubles: max diag(S), and the sum of the positive remaining diagonal entries (the
+ * trace of R) after the last completed step. */
+int64_t vmcpde_pivoted_cholesky_workspace_bytes(int32_t P);
+int vmcpde_pivoted_cholesky(const double* S, int64_t lds, int32_t P, double tol_rel, int32_t first_step, int32_t n_steps,
+                            int32_t max_rank, double* LT, int64_t ldl, int32_t* piv, int32_t* state, void* workspace,
+                            int64_t workspace_bytes, void* stream);
+/* Householder QR of the P x r matrix whose columns are the rows of LT (destroyed: the strict upper part of R, the rest is scratch).  YT: [dev] r x ldl,
+ * row k = reflector v_k (zeros before k, v_k[k] = 1, zeros from P on); tau: [dev] r, H_k = I - tau_k v_k v_k^T, Q = H_0 ... H_{r-1}
+ * = I - Y T Y^T with T^-1 = strict upper part of Y^T Y + diag(1 / tau)  (tau_k is never 0: a column that is already zero below its
+ * diagonal gets v = e_k, tau = 2).  scratch: [dev] r + 1 doubles. */
+int vmcpde_householder_rows(double* LT, int64_t ldl, int32_t P, int32_t r, double* YT, double* tau, double* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

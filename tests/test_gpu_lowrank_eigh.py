@@ -1,0 +1,215 @@
+"""The rank-revealing spectral decomposition (csrc/eig.hip + TDVP._eigh_lowrank; reference: tdvp.py:57-64, eigh of the full matrix):
+its two dependent chains against numpy restatements, the assembled (ev, V) against a dense eigh on the same S at the headline network
+size, and when the engine is (not) taken."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vmc_oracle as O
+from helpers import make_spec, random_theta, make_varstate, FixedSampler
+
+pytestmark = pytest.mark.gpu
+
+
+def _graded_psd(P, per_decade, N, seed):
+    """S = J^T J / N for J with singular values falling by a factor ten every `per_decade` directions (what these models produce)."""
+    rng = np.random.default_rng(seed)
+    lam = 3.0e3 * 10.0 ** (-np.arange(P) / per_decade)
+    Q, _ = np.linalg.qr(rng.standard_normal((P, P)))
+    J = rng.standard_normal((N, P)) * np.sqrt(lam) @ Q.T
+    return J.T @ J / N
+
+
+def _pivoted_cholesky_numpy(S, tol_rel):
+    P = S.shape[0]
+    d = np.diag(S).copy()
+    d0 = d.max()
+    cols, piv = [], []
+    while len(piv) < P:
+        p = int(np.argmax(d))
+        if not d[p] > tol_rel * d0:
+            break
+        L = np.array(cols).T if cols else np.zeros((P, 0))
+        col = (S[:, p] - L @ L[p]) / np.sqrt(d[p])
+        col[piv] = 0.0
+        cols.append(col)
+        d = d - col * col
+        piv.append(p)
+        d[piv] = -np.inf
+    return np.array(cols).T, piv
+
+
+def _run_pivchol(S, tol, cap, chunks):
+    from vmc_pde_amd import _native as nat
+    P = S.shape[0]
+    Sd = torch.from_numpy(S).cuda()
+    ldl = (P + 63) // 64 * 64
+    LT = torch.full((cap, ldl), float("nan"), dtype=torch.float64, device="cuda")
+    piv = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ws = torch.zeros(nat.lib().vmcpde_pivoted_cholesky_workspace_bytes(P) // 8, dtype=torch.float64, device="cuda")
+    step = 0
+    for n in chunks:
+        n = min(n, cap - step)
+        nat.call("vmcpde_pivoted_cholesky", nat.ptr(Sd), P, P, tol, step, n, cap, nat.ptr(LT), ldl, nat.ptr(piv), nat.ptr(state), nat.ptr(ws),
+                 ws.numel() * 8, nat.stream())
+        step += n
+    torch.cuda.synchronize()
+    r, done = int(state[0]), int(state[1])
+    return LT[:r].cpu().numpy(), piv[:r].cpu().numpy(), r, done, ws[:2].cpu().numpy()
+
+
+def test_pivoted_cholesky_against_numpy():
+    P = 700                                                       # ragged: 700 = 10 * 64 + 60
+    S = _graded_psd(P, 9.0, 4096, seed=5)
+    L_ref, piv_ref = _pivoted_cholesky_numpy(S, 1e-16)
+    LT, piv, r, done, head = _run_pivchol(S, 1e-16, cap=400, chunks=(64, 1, 100, 235))      # resumed three times
+    assert done == 1 and abs(r - len(piv_ref)) <= 3, (r, len(piv_ref))
+    # the leading pivots are well separated: same choice, same columns (later ones are decided by round-off)
+    m = r // 2
+    assert list(piv[:m]) == piv_ref[:m]
+    assert np.abs(LT[:m, :P].T - L_ref[:, :m]).max() < 1e-9 * np.abs(L_ref).max()
+    # rows keep their place; a row chosen as pivot has structural zeros in every later column, and pad columns are zero
+    for k in range(1, r):
+        assert np.all(LT[k, piv[:k]] == 0.0)
+    assert np.all(LT[:, P:] == 0.0) and len(set(piv.tolist())) == r
+    # S = L L^T + R with trace(R) as reported: R is what the stopping criterion left
+    lmax = np.linalg.eigvalsh(S)[-1]
+    R = S - LT[:, :P].T @ LT[:, :P]
+    assert np.abs(R).max() < 1e-15 * lmax * 10
+    assert head[0] == np.diag(S).max() and 0.0 <= head[1] <= (P - r) * 1e-16 * head[0]
+    # a cap below the rank: the loop ends without the criterion, state says so, and the trace of what is left is still reported
+    LT2, piv2, r2, done2, head2 = _run_pivchol(S, 1e-16, cap=40, chunks=(40,))
+    assert done2 == 0 and r2 == 40 and list(piv2) == piv_ref[:40]
+    left = np.trace(S - LT2[:, :P].T @ LT2[:, :P])
+    assert abs(head2[1] - left) < 1e-9 * abs(left)
+    # a matrix with a NaN, and a zero matrix: rank 0, criterion "met" at the first step
+    for bad in (np.full((70, 70), np.nan), np.zeros((70, 70))):
+        _, _, r3, done3, _ = _run_pivchol(bad, 1e-16, cap=10, chunks=(10,))
+        assert r3 == 0 and done3 == 1
+
+
+def test_householder_rows_against_numpy():
+    from vmc_pde_amd import _native as nat
+    rng = np.random.default_rng(2)
+    P, r = 613, 90
+    L = rng.standard_normal((P, r)) * 10.0 ** (-np.arange(r) / 11.0)              # columns over eight decades
+    L[:, 17] = 0.0
+    L[17, 17] = 0.3                                                                # a column that is (after 17 steps: nearly) a unit vector
+    ldl = (P + 63) // 64 * 64
+    LT = torch.zeros((r, ldl), dtype=torch.float64, device="cuda")
+    LT[:, :P] = torch.from_numpy(L.T)
+    YT = torch.full((r, ldl), float("nan"), dtype=torch.float64, device="cuda")
+    tau = torch.zeros(r, dtype=torch.float64, device="cuda")
+    scratch = torch.zeros(r + 1, dtype=torch.float64, device="cuda")
+    nat.call("vmcpde_householder_rows", nat.ptr(LT), ldl, P, r, nat.ptr(YT), nat.ptr(tau), nat.ptr(scratch), nat.stream())
+    torch.cuda.synchronize()
+    Y, t, Rm = YT.cpu().numpy()[:, :P].T, tau.cpu().numpy(), LT.cpu().numpy()[:, :P].T
+    assert np.all(YT.cpu().numpy()[:, P:] == 0.0) and np.all(np.triu(Y[:r], 1) == 0.0) and np.all(np.diag(Y[:r]) == 1.0)
+    assert np.all(t > 0.0) and np.all(t <= 2.0)
+    # compact WY: Q = I - Y T Y^T with T^-1 = strict upper(Y^T Y) + diag(1 / tau)
+    Tinv = np.triu(Y.T @ Y, 1) + np.diag(1.0 / t)
+    Q = np.eye(P) - Y @ np.linalg.solve(Tinv, Y.T)
+    assert np.abs(Q.T @ Q - np.eye(P)).max() < 5e-15
+    # Q^T L = [R; 0], column by column relative to the column's norm (the factor's columns differ by 1e8 in size)
+    QtL = Q.T @ L
+    cn = np.linalg.norm(L, axis=0)
+    assert np.abs(QtL[r:] / cn).max() < 1e-14
+    # what the kernel leaves in LT: the strict upper part of R (column k itself is never rewritten -- every workgroup of step k reads it)
+    assert np.abs((np.triu(QtL[:r], 1) - np.triu(Rm[:r], 1)) / cn).max() < 1e-13
+    # and the same R as LAPACK up to the sign of each row
+    R_np = np.linalg.qr(L, mode="r")
+    assert np.abs((np.abs(np.triu(QtL[:r])) - np.abs(R_np)) / cn).max() < 1e-12
+
+
+@pytest.fixture(scope="module")
+def headline_net():
+    """The headline network (d = 2, 4 blocks, hidden (21, 21): P = 4213) with injected latent samples, as a factory of VarStates."""
+    import vmc_pde_amd as V
+    spec = make_spec(2, 4, (21, 21), latent="Gauss", coupling="no_add", offset=[1.0, 1.0], seed=4)
+    th = random_theta(spec, 4, out_scale=0.03)
+    ep = V.EvolutionEquation(dim=2, name="advection_hamiltonian_wDiss")
+    ep.eqParams["advection_hamiltonian_wDiss"]["params"]["lam"] = 0.1
+
+    def varstate(N):
+        g = torch.Generator().manual_seed(9)
+        z = O.latent_from_normals(spec, th, torch.randn(N, 2, generator=g, dtype=torch.float64), None)
+        return make_varstate(spec, th, sampler=FixedSampler(z.cuda()))
+    return varstate, ep, th
+
+
+def test_lowrank_engine_matches_dense_at_headline_size(headline_net):
+    import vmc_pde_amd as V
+    varstate, ep, th = headline_net
+    N = 8192
+    vs = varstate(N)
+    out = {}
+    for engine in ("dense", "lowrank", "auto"):
+        tp = V.TDVP(svdTol=1e-6, spectralEngine=engine)
+        u, _ = tp(th.cuda(), 0.0, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+        out[engine] = (tp.S0.clone(), tp.F0.clone(), tp.ev.clone(), tp.V.clone(), tp.VtF.clone(), u.clone(), dict(tp.spectralInfo),
+                       float(tp.solverResidual), float(tp.tdvp_error))
+    S, F, ev_d, V_d, _, u_d, info_d, res_d, err_d = out["dense"]
+    P = S.shape[0]
+    assert P == 4213 and info_d["engine"] == "dense"
+    for engine in ("lowrank", "auto"):
+        S2, F2, ev, Vv, VtF, u, info, res, err = out[engine]
+        assert torch.equal(S2, S) and torch.equal(F2, F)                 # same samples, same S: what differs is the decomposition
+        assert info["engine"] == "lowrank" and info["converged"] and info["rank"] < P // 6, info
+        lmax = float(ev_d[-1])
+        assert float((ev - ev_d).abs().max()) < 1e-13 * lmax
+        assert bool((ev[1:] >= ev[:-1]).all()) and int((ev == 0).sum()) == P - info["rank"]
+        eye = torch.eye(P, dtype=torch.float64, device="cuda")
+        assert float((Vv.T @ Vv - eye).abs().max()) < 1e-13
+        # residual of the decomposition against the dense one's own
+        r_lr = float(torch.linalg.norm(S @ Vv - Vv * ev)) / lmax
+        r_d = float(torch.linalg.norm(S @ V_d - V_d * ev_d)) / lmax
+        assert r_lr < max(3 * r_d, 1e-13), (r_lr, r_d)
+        # the solve: update in the S-norm, the reference's two diagnostics, and the invariants of every eigenvalue cluster above 1e-9
+        nF = float(torch.linalg.norm(F))
+        assert float(torch.linalg.norm(S @ (u - u_d))) < 1e-10 * nF
+        assert abs(res - res_d) < 1e-10 and abs(err - err_d) < 1e-10
+        evc = ev_d.cpu()
+        bounds = [0] + [k for k in range(1, P) if float(evc[k] - evc[k - 1]) >= 1e-6 * lmax] + [P]
+        f_lr, f_d = (VtF ** 2).cpu(), ((V_d.T @ F) ** 2).cpu()
+        n = 0
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            if float(evc[hi - 1]) < 1e-9 * lmax:
+                continue
+            n += 1
+            assert abs(float(f_lr[lo:hi].sum()) - float(f_d[lo:hi].sum())) < 1e-8 * float(f_d[lo:hi].sum())
+        assert n >= 20
+
+
+def test_engine_choice_and_fallbacks(headline_net):
+    import vmc_pde_amd as V
+    varstate, ep, th = headline_net
+    N = 4096
+    vs = varstate(N)
+    kw = dict(nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+    # a diagonal shift makes S full rank: the dense path is taken without an attempt
+    tp = V.TDVP(svdTol=1e-6, diagonalShift=1e-3)
+    tp(th.cuda(), 0.0, vs, ep, **kw)
+    assert tp.spectralInfo == dict(engine="dense")
+    # a full-rank matrix handed to the engine under "auto": the cap is hit, the dense result is returned and the engine pauses
+    tq = V.TDVP(svdTol=1e-6)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    A = torch.randn(3000, 1200, generator=g, dtype=torch.float64, device="cuda")
+    S = (A.T @ A / 3000).contiguous()
+    F = torch.randn(1200, generator=g, dtype=torch.float64, device="cuda")
+    tq.transform_to_eigenbasis(S, F)
+    assert tq.spectralInfo["engine"] == "dense" and tq.spectralInfo["tried"] == "lowrank" and not tq.spectralInfo["converged"]
+    assert tq.spectralInfo["rank"] == 1200 // 6 and tq._lowrank_backoff > 0
+    ev_ref = torch.linalg.eigvalsh(S)
+    assert float((tq.ev - ev_ref).abs().max()) < 1e-12 * float(ev_ref[-1])
+    before = tq._lowrank_backoff
+    tq.transform_to_eigenbasis(S, F)                                  # no second attempt right away
+    assert tq.spectralInfo == dict(engine="dense") and tq._lowrank_backoff == before - 1
+    # forced: no cap, the factorisation runs to full rank and the result is still a decomposition of S
+    tf = V.TDVP(svdTol=1e-6, spectralEngine="lowrank")
+    tf.transform_to_eigenbasis(S, F)
+    assert tf.spectralInfo["engine"] == "lowrank" and tf.spectralInfo["rank"] == 1200
+    assert float((tf.ev - ev_ref).abs().max()) < 1e-12 * float(ev_ref[-1])
+    assert float(torch.linalg.norm(S @ tf.V - tf.V * tf.ev)) < 1e-12 * float(ev_ref[-1])
+    with pytest.raises(ValueError, match="spectralEngine"):
+        V.TDVP(spectralEngine="jacobi")

@@ -71,8 +71,11 @@ def _assert_stagewise_parity(stages, oracle_stage, tol=1e-9):
         assert float(torch.linalg.norm(to.S0 @ (W @ (W.T @ du)))) < tol * nF, k
 
 
+@pytest.mark.parametrize("engine", ["dense", "lowrank"])
 @pytest.mark.parametrize("case", CASES)
-def test_tdvp_rhs_parity_eigh_path(case):
+def test_tdvp_rhs_parity_eigh_path(case, engine):
+    """engine: how the product obtains (ev, V) -- the dense decomposition of the full matrix (host LAPACK / rocSOLVER by size), or the
+    rank-revealing one of csrc/eig.hip forced onto these small matrices (the default takes it from 1024 parameters on)."""
     import vmc_pde_amd as V
     from vmc_pde_amd import mpi_wrapper as mpi
     dim, depth, hidden, latent, coupling, eq, N = case
@@ -84,13 +87,18 @@ def test_tdvp_rhs_parity_eigh_path(case):
     upd_o, aux = to.rhs(th, 0.2, vo, eo, z)
     # product
     vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()))
-    tp = V.TDVP(solver="eigh")
+    tp = V.TDVP(solver="eigh", spectralEngine=engine)
     # the small-ball integrals (tdvp.py:152-162) with the ball points injected into oracle and product (H4)
     gb = torch.Generator().manual_seed(11)
     ball = O.TDVPOracle.ball_points(torch.randn(1, N, dim, generator=gb, dtype=torch.float64), torch.rand(1, N, generator=gb, dtype=torch.float64))
     tp._ball_samples = lambda psi, n, d: ball.to(psi.device)
     upd_p, info = tp(th.cuda(), 0.2, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None)
     P = vs.numParameters
+    if engine == "lowrank":
+        assert tp.spectralInfo["engine"] == "lowrank" and tp.spectralInfo["converged"] and 1 <= tp.spectralInfo["rank"] <= P, tp.spectralInfo
+        Vp = tp.V.cpu()
+        assert float((Vp.T @ Vp - torch.eye(P, dtype=torch.float64)).abs().max()) < 1e-13
+        assert float(torch.linalg.norm(tp.S0.cpu() @ Vp - Vp * tp.ev.cpu())) < 1e-13 * P * float(tp.ev[-1])
     assert rel_err(tp.S0, to.S0) < 1e-11 and tp.S0.shape == (P, P)
     assert rel_err(tp.F0, to.F0) < 1e-10
     assert abs(float(tp.ElocMean) - float(to.ElocMean)) < 1e-11 * (1 + abs(float(to.ElocMean)))
@@ -146,8 +154,9 @@ def test_tdvp_rhs_parity_eigh_path(case):
     assert mpi.globNumSamples == N
 
 
+@pytest.mark.parametrize("engine", ["dense", "lowrank"])
 @pytest.mark.parametrize("case", CASES)
-def test_tdvp_snr_regularised_solve_parity(case):
+def test_tdvp_snr_regularised_solve_parity(case, engine):
     """useSNR=True end to end (tdvp.py:70-71, 87-89): the signal-to-noise ratio of every mode and the update of the SNR-regularised
     pseudo-inverse against TDVPOracle(useSNR=True), which forms E~O~V explicitly (the product gets rhoVar from an E~^2-weighted Gram)."""
     import vmc_pde_amd as V
@@ -159,7 +168,7 @@ def test_tdvp_snr_regularised_solve_parity(case):
     t_plain = O.TDVPOracle()
     upd_plain, _, _ = t_plain.solve(aux["Eloc"], aux["J"], aux["logp"])
     vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()))
-    tp = V.TDVP(useSNR=True, snrTol=2.0)                         # solver "auto" -> the spectral path
+    tp = V.TDVP(useSNR=True, snrTol=2.0, spectralEngine=engine)  # solver "auto" -> the spectral path
     upd_p, _ = tp(th.cuda(), 0.2, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None)
     assert tp._solver() == "eigh" and tp.snr is not None and tp.ev is not None
     nF = torch.linalg.norm(to.F0)

@@ -1,0 +1,275 @@
+// Rank-revealing pieces of the spectral solve (reference: tdvp.py:57-64, `np.linalg.eigh(S)` / `jnp.linalg.eigh(S)` on the full P x P
+// matrix).  S = <J^T J> of a smooth low-dimensional model is numerically rank deficient: at the headline size (P = 4213) 238
+// eigenvalues lie above 1e-16 of the largest, the other ~4000 are rounding noise around zero.  The full decomposition then needs no
+// O(P^3) work:
+//
+//   1. diagonally pivoted Cholesky  S = L L^T + R,  stopped when the largest remaining diagonal entry is <= tol * max diag(S)
+//      (R is positive semi-definite with trace <= (P - r) tol max diag: the same size as the backward error of a dense eigensolver);
+//      r dependent steps, each one launch: column k = (S[:, p] - L[:, :k] L[p, :k]^T) / sqrt(d_p), d -= column^2, arg max of d.
+//   2. Householder QR of the P x r factor (r dependent steps, each one launch: one workgroup per trailing column) -- column-wise
+//      backward stable whatever the grading of L (its columns span 8 decades), and its compact WY form gives BOTH an orthonormal
+//      basis Q1 of range(L) and one of the complement, Q2, as plain GEMMs (host side: vmc_pde_amd/tdvp.py).
+//   3. Rayleigh-Ritz on range(L): eigh of the r x r matrix Q1^T S Q1, Ritz vectors Q1 W; V = [Q2 | Q1 W] with eigenvalue 0 for Q2.
+//
+// This file holds 1 and 2 (the dependent chains); the GEMMs, the triangular solve and the r x r decomposition of 3 are library
+// calls made from the host.  L is kept TRANSPOSED, LT[k][i] = L[i][k] (row k = column k of L, contiguous): every access of the
+// chains is then a contiguous run of a row.
+#include "common.hpp"
+
+namespace vmcpde {
+namespace {
+
+constexpr int PC_ROWS = 64;                          // rows of S per workgroup (one per lane)
+constexpr int PC_SLICES = 16;                        // waves per workgroup: wave s sums the earlier columns j = s, s + 16, ...
+constexpr int PC_THREADS = PC_ROWS * PC_SLICES;      // 1024
+constexpr double NEG_INF = -__builtin_huge_val();
+
+struct PivWork {            // device-side bookkeeping of one factorisation (head of the workspace)
+  double d0;                // largest diagonal entry of S: the reference of the stopping criterion
+  double trace_left;        // sum of the positive remaining diagonal entries after the last completed step
+};
+
+// (value, index) arg max over a wave, ties to the lower index; every lane returns the result
+__device__ __forceinline__ void wave_argmax(double& v, int& idx) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double ov = __shfl_xor(v, off);
+    const int oi = __shfl_xor(idx, off);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// d = diag(S); per-workgroup candidates (largest entry, its row, sum of the positive entries) into candidate buffer 0
+__global__ __launch_bounds__(PC_ROWS) void pivchol_init_kernel(const double* __restrict__ S, int64_t lds, int P, double* __restrict__ d,
+                                                               double* __restrict__ cand_val, int* __restrict__ cand_idx,
+                                                               double* __restrict__ cand_sum, int32_t* __restrict__ state) {
+  const int i = (int)blockIdx.x * PC_ROWS + (int)threadIdx.x;
+  double v = NEG_INF;
+  if (i < P) {
+    v = S[(int64_t)i * lds + i];
+    d[i] = v;
+  }
+  int idx = i;
+  double pos = (v > 0.0) ? v : 0.0;
+  wave_argmax(v, idx);
+  pos = wave_sum(pos);
+  if (threadIdx.x == 0) {
+    cand_val[blockIdx.x] = v;
+    cand_idx[blockIdx.x] = idx;
+    cand_sum[blockIdx.x] = pos;
+    if (blockIdx.x == 0) { state[0] = 0; state[1] = 0; }
+  }
+}
+
+// One step of the pivoted factorisation.  state[0] = columns completed, state[1] = 1 once the stopping criterion has been met (every
+// later launch returns at once).  The candidates of step s are read from buffer s & 1 and those for step s + 1 written to the other.
+__global__ __launch_bounds__(PC_THREADS) void pivchol_step_kernel(const double* __restrict__ S, int64_t lds, int P, int step, double tol_rel,
+                                                                  double* __restrict__ LT, int64_t ldl, double* __restrict__ d,
+                                                                  double* __restrict__ cand_val, int* __restrict__ cand_idx,
+                                                                  double* __restrict__ cand_sum, int nwg, int32_t* __restrict__ piv,
+                                                                  int32_t* __restrict__ state, PivWork* __restrict__ work) {
+  __shared__ double part[PC_SLICES][PC_ROWS];
+  __shared__ double s_dp, s_sum;
+  __shared__ int s_p, s_done;
+  const int t = threadIdx.x, lane = t & 63;
+  const int slice = __builtin_amdgcn_readfirstlane(t >> 6);
+  const double* cv = cand_val + (step & 1) * nwg;
+  const int* ci = cand_idx + (step & 1) * nwg;
+  const double* cs = cand_sum + (step & 1) * nwg;
+  if (slice == 0) {
+    double v = NEG_INF, sum = 0.0;
+    int idx = 0x7fffffff;
+    for (int q = lane; q < nwg; q += 64) {
+      const double ov = cv[q];
+      const int oi = ci[q];
+      sum += cs[q];
+      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    wave_argmax(v, idx);
+    sum = wave_sum(sum);
+    // state[1]: set by an earlier launch, or by workgroup 0 of this one -- a workgroup that still reads 0 reaches the same verdict
+    // below.  One lane reads it for the workgroup (the barriers that follow need a uniform decision).
+    if (lane == 0) { s_dp = v; s_p = idx; s_sum = sum; s_done = state[1]; }
+  }
+  __syncthreads();
+  if (s_done) return;
+  const double dp = s_dp;
+  const int p = s_p;
+  const double d0 = (step == 0) ? dp : work->d0;
+  if (!(dp > tol_rel * d0)) {    // also: NaN anywhere, nothing left (-inf), a non-positive matrix
+    if (blockIdx.x == 0 && t == 0) {
+      state[1] = 1;
+      state[0] = step;
+      work->trace_left = s_sum;
+      if (step == 0) work->d0 = dp;
+    }
+    return;
+  }
+  if (blockIdx.x == 0 && t == 0) {
+    if (step == 0) work->d0 = dp;
+    state[0] = step + 1;
+    piv[step] = p;
+  }
+  const int i = (int)blockIdx.x * PC_ROWS + lane;      // (< ldl: the pad columns of LT are kept at zero)
+  double sum = 0.0;
+#pragma unroll 4
+  for (int j = slice; j < step; j += PC_SLICES) sum = fma(LT[(int64_t)j * ldl + i], LT[(int64_t)j * ldl + p], sum);
+  part[slice][lane] = sum;
+  __syncthreads();
+  if (slice != 0) return;
+  double total = 0.0;
+#pragma unroll
+  for (int s = 0; s < PC_SLICES; ++s) total += part[s][lane];
+  const bool inside = i < P;
+  const double di = inside ? d[i] : NEG_INF;
+  const bool open = inside && di != NEG_INF;          // rows chosen as pivots earlier are finished: structural zeros of L from here on
+  double col = 0.0;
+  if (open) col = (S[(int64_t)p * lds + i] - total) / sqrt(dp);
+  LT[(int64_t)step * ldl + i] = col;
+  double nd = NEG_INF;
+  if (open && i != p) nd = di - col * col;
+  if (inside) d[i] = nd;
+  int idx = i;
+  double pos = (nd > 0.0) ? nd : 0.0;
+  wave_argmax(nd, idx);
+  pos = wave_sum(pos);
+  if (lane == 0) {
+    const int o = ((step + 1) & 1) * nwg + (int)blockIdx.x;
+    cand_val[o] = nd;
+    cand_idx[o] = idx;
+    cand_sum[o] = pos;
+  }
+}
+
+// sum of the positive remaining diagonal entries once the loop ended WITHOUT meeting the criterion (rank cap reached): the host reports it
+__global__ void pivchol_trace_kernel(const double* __restrict__ cand_sum, int nwg, int steps_done, const int32_t* __restrict__ state,
+                                     PivWork* __restrict__ work) {
+  if (state[1]) return;
+  double sum = 0.0;
+  for (int q = threadIdx.x; q < nwg; q += 64) sum += cand_sum[(steps_done & 1) * nwg + q];
+  sum = wave_sum(sum);
+  if (threadIdx.x == 0) work->trace_left = sum;
+}
+
+constexpr int HQ_THREADS = 1024;
+constexpr int HQ_WAVES = HQ_THREADS / 64;
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  const int t = threadIdx.x;
+  __syncthreads();                                   // (red may still be read from the previous call)
+  if ((t & 63) == 0) red[t >> 6] = v;
+  __syncthreads();
+  double total = 0.0;
+#pragma unroll
+  for (int q = 0; q < HQ_WAVES; ++q) total += red[q];
+  return total;
+}
+
+// Step k of the Householder QR of L (columns = rows of LT): workgroup 0 writes the reflector (v with v_k = 1, zeros above) to row k of YT
+// and tau_k; workgroup m >= 1 applies H_k = I - tau v v^T to column k + m.  Every workgroup derives v from column k itself, which no
+// workgroup of this launch writes; the sum of squares of column k below its diagonal comes from the workgroup that brought that
+// column up to date in step k - 1 (norm2[k]; step 0 sums it itself), so a step is one pass for the dot product and one for the update.
+// (dlarfg's formulas; a column that is already zero below the diagonal gets the reflection I - 2 e_k e_k^T instead of the identity, so
+// that tau is never 0 and the compact WY factor stays regular.)
+__global__ __launch_bounds__(HQ_THREADS) void hqr_step_kernel(double* __restrict__ LT, int64_t ldl, int P, int k, double* __restrict__ YT,
+                                                              double* __restrict__ tau, double* __restrict__ norm2) {
+  __shared__ double red[HQ_WAVES];
+  const int t = threadIdx.x, m = blockIdx.x;
+  const double* __restrict__ x = LT + (int64_t)k * ldl;
+  double s2;
+  if (k == 0) {
+    s2 = 0.0;
+    for (int i = 1 + t; i < P; i += HQ_THREADS) s2 = fma(x[i], x[i], s2);
+    s2 = block_sum(s2, red);
+  } else {
+    s2 = norm2[k];
+  }
+  const double alpha = x[k];
+  const double nrm2 = fma(alpha, alpha, s2);
+  double tk = 2.0, scale = 0.0;
+  if (nrm2 > 0.0) {
+    const double beta = -copysign(sqrt(nrm2), alpha);
+    tk = (beta - alpha) / beta;
+    scale = 1.0 / (alpha - beta);
+  }
+  if (m == 0) {
+    double* __restrict__ y = YT + (int64_t)k * ldl;
+    for (int i = t; i < (int)ldl; i += HQ_THREADS) y[i] = (i < k || i >= P) ? 0.0 : ((i == k) ? 1.0 : x[i] * scale);
+    if (t == 0) tau[k] = tk;
+    return;
+  }
+  double* __restrict__ y = LT + (int64_t)(k + m) * ldl;
+  double dot = (t == 0) ? y[k] : 0.0;
+#pragma unroll 4
+  for (int i = k + 1 + t; i < P; i += HQ_THREADS) dot = fma(x[i] * scale, y[i], dot);
+  dot = block_sum(dot, red);
+  const double w = tk * dot;
+  if (t == 0) y[k] -= w;
+  double next = 0.0;                                  // (m == 1) sum of squares of the new column k + 1 below ITS diagonal
+#pragma unroll 4
+  for (int i = k + 1 + t; i < P; i += HQ_THREADS) {
+    const double v = fma(-w, x[i] * scale, y[i]);
+    y[i] = v;
+    if (i > k + 1) next = fma(v, v, next);
+  }
+  if (m == 1) {
+    next = block_sum(next, red);
+    if (t == 0) norm2[k + 1] = next;
+  }
+}
+
+int64_t pivchol_ws_doubles(int P) {
+  const int64_t nwg = (P + PC_ROWS - 1) / PC_ROWS;
+  return 8 /* PivWork, padded */ + (int64_t)nwg * PC_ROWS /* d */ + 2 * nwg /* cand_val */ + 2 * nwg /* cand_sum */ + nwg /* cand_idx (2 x int32) */ + 8;
+}
+
+}  // namespace
+}  // namespace vmcpde
+
+using namespace vmcpde;
+
+extern "C" int64_t vmcpde_pivoted_cholesky_workspace_bytes(int32_t P) { return (P >= 1) ? pivchol_ws_doubles(P) * (int64_t)sizeof(double) : 0; }
+
+extern "C" int vmcpde_pivoted_cholesky(const double* S, int64_t lds, int32_t P, double tol_rel, int32_t first_step, int32_t n_steps,
+                                       int32_t max_rank, double* LT, int64_t ldl, int32_t* piv, int32_t* state, void* workspace,
+                                       int64_t workspace_bytes, void* stream) {
+  VMC_REQUIRE(S && LT && piv && state && workspace, "vmcpde_pivoted_cholesky: null argument");
+  VMC_REQUIRE(P >= 1 && lds >= P, "vmcpde_pivoted_cholesky: bad shape");
+  VMC_REQUIRE(ldl >= (int64_t)((P + PC_ROWS - 1) / PC_ROWS) * PC_ROWS, "vmcpde_pivoted_cholesky: ldl must be P rounded up to a multiple of 64");
+  VMC_REQUIRE(first_step >= 0 && n_steps >= 0 && max_rank >= 1 && max_rank <= P && first_step + n_steps <= max_rank,
+              "vmcpde_pivoted_cholesky: steps outside [0, max_rank]");
+  VMC_REQUIRE(tol_rel >= 0.0, "vmcpde_pivoted_cholesky: negative tolerance");
+  VMC_REQUIRE(workspace_bytes >= vmcpde_pivoted_cholesky_workspace_bytes(P), "vmcpde_pivoted_cholesky: workspace too small");
+  const int nwg = (P + PC_ROWS - 1) / PC_ROWS;
+  double* w = static_cast<double*>(workspace);
+  PivWork* work = reinterpret_cast<PivWork*>(w);
+  double* d = w + 8;
+  double* cand_val = d + (int64_t)nwg * PC_ROWS;
+  double* cand_sum = cand_val + 2 * nwg;
+  int* cand_idx = reinterpret_cast<int*>(cand_sum + 2 * nwg);
+  hipStream_t st = (hipStream_t)stream;
+  if (first_step == 0)
+    hipLaunchKernelGGL(pivchol_init_kernel, dim3(nwg), dim3(PC_ROWS), 0, st, S, lds, P, d, cand_val, cand_idx, cand_sum, state);
+  for (int s = first_step; s < first_step + n_steps; ++s)
+    hipLaunchKernelGGL(pivchol_step_kernel, dim3(nwg), dim3(PC_THREADS), 0, st, S, lds, P, s, tol_rel, LT, ldl, d, cand_val, cand_idx, cand_sum, nwg,
+                       piv, state, work);
+  hipLaunchKernelGGL(pivchol_trace_kernel, dim3(1), dim3(64), 0, st, cand_sum, nwg, first_step + n_steps, state, work);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vmcpde_householder_rows(double* LT, int64_t ldl, int32_t P, int32_t r, double* YT, double* tau, double* scratch, void* stream) {
+  VMC_REQUIRE(LT && YT && tau && scratch, "vmcpde_householder_rows: null argument");
+  VMC_REQUIRE(P >= 1 && r >= 1 && r <= P && ldl >= P, "vmcpde_householder_rows: bad shape");
+  for (int k = 0; k < r; ++k)
+    hipLaunchKernelGGL(hqr_step_kernel, dim3(r - k), dim3(HQ_THREADS), 0, (hipStream_t)stream, LT, ldl, P, k, YT, tau, scratch);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}

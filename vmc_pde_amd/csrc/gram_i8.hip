@@ -328,10 +328,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void gram_i8_kernel
       const int bstride = diag ? 256 : BROWS * 2;
       // the A fragments of slice s + 1 are requested BEFORE the products of slice s are issued: left to itself hipcc reads them
       // behind each group of MFMAs and then waits for the LDS with an empty matrix pipe, six times per step
+      // The fragments of a step's first products come in two batches.  With LDS DMA in flight hipcc only ever writes `s_waitcnt
+      // lgkmcnt(0)`, so a step used to open with ten reads per wave -- 80 KB through the LDS of a CU -- before its first MFMA.  Now
+      // four reads (a0, a1, b0, b1), a wait (the empty asm is a use the compiler has to wait for), then the other six are requested
+      // and fly under the first four products.
       int4_t b[NS];
-#pragma unroll
-      for (int s = 0; s < NS; ++s) b[s] = bp[s * bstride];
       int4_t a0 = ap[0], a1 = ap[32];
+      b[0] = bp[0];
+      b[1] = bp[bstride];
+      asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b[0]), "+v"(b[1]));
+#pragma unroll
+      for (int s = 2; s < NS; ++s) b[s] = bp[s * bstride];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         int4_t n0 = a0, n1 = a1;

@@ -1143,7 +1143,9 @@ __global__ void pinv_coeffs_kernel(const double* __restrict__ ev, const double* 
     const double qs = snrTol / snr[k];
     reg *= 1.0 / (1.0 + qs * qs * qs * qs * qs * qs);                // :89
   }
-  coef[k] = invEv * reg * VtF[k];                                     // :91
+  // :91.  A mode dropped by the hard cut-off contributes an exact zero whatever its other factors are: the rank-revealing engine
+  // (eig.hip) reports null-space eigenvalues as exact zeros, for which svdTol = 0 or an SNR of 0 / 0 would make `reg` a NaN.
+  coef[k] = (invEv == 0.0) ? 0.0 : invEv * reg * VtF[k];
 }
 
 }  // namespace

@@ -51,6 +51,12 @@ _THREADPOOLS = None
 
 
 DEVICE_EIGH_MIN_P = 640     # diagonalizeOnDevice=None: rocSOLVER's syevd overtakes thread-capped host LAPACK between P = 411 and 1024
+LOWRANK_MIN_P = 1024        # spectralEngine="auto": the rank-revealing decomposition from this many parameters on (below, syevd takes < 25 ms)
+LOWRANK_RANK_CAP = 768      # ... while the numerical rank stays below this and below P / LOWRANK_RANK_DIVISOR: its chains are r dependent
+LOWRANK_RANK_DIVISOR = 6    #   launches of O(P r) work each, and the r x r core goes to syevd
+LOWRANK_TOL = 1e-16         # pivoting stops when the largest remaining diagonal entry is <= this x max diag(S)
+LOWRANK_TRACE_BOUND = 1e-12 # accept only if the trace of the remainder (an upper bound of its norm) is below this x max diag(S)
+LOWRANK_RETRY_AFTER = 50    # "auto": calls on the dense path after one whose rank exceeded the cap, before the next attempt
 
 
 def _round_up(v, m):
@@ -71,6 +77,13 @@ class TDVP:
     solver: str = "auto"          # "eigh": the reference's spectral pseudo-inverse (tdvp.py:57-94) -- what "auto" selects, so that the
                                   #   reference's constructor arguments solve the reference's system and publish ev / V / snr;
                                   # "cholesky": explicit opt-in to the on-device regularised Cholesky (no eigenbasis, hence no SNR)
+    spectralEngine: str = "auto"  # how the spectral path obtains (ev, V) on the device (tdvp.py:57-64).  "dense": rocSOLVER's syevd on the full
+                                  #   matrix (147 ms at P = 4213).  "lowrank": the rank-revealing decomposition of csrc/eig.hip -- pivoted
+                                  #   Cholesky of S, Householder QR of the factor, Rayleigh-Ritz on its range, V = [null space | Ritz
+                                  #   vectors] -- O(P r^2) for numerical rank r (238 of 4213 at the headline size); the same (ev, V) to
+                                  #   the backward error of a dense eigensolver, the ~P - r eigenvalues below 1e-16 of the largest
+                                  #   reported as exact zeros.  "auto": lowrank from LOWRANK_MIN_P parameters on when diagonalShift
+                                  #   leaves S rank deficient, dense whenever the rank exceeds the cap (then not retried for a while).
     residualBound: float = 1e-6   # Cholesky path: a solver residual above this (or a NaN) is treated as a failed factorisation
     centering: str = "auto"       # "exact": global means before the Gram (an extra pass over J, + one tiny all-reduce when sharded)
                                   # "lagged": previous call's global mean as shift -> one pass, a single all-reduce per step
@@ -95,6 +108,11 @@ class TDVP:
     def __post_init__(self):
         if self.solver not in ("auto", "eigh", "cholesky"):
             raise ValueError(f"unknown solver {self.solver!r}")
+        if self.spectralEngine not in ("auto", "dense", "lowrank"):
+            raise ValueError(f"unknown spectralEngine {self.spectralEngine!r}")
+        self._lowrank_backoff = 0
+        self._lowrank_last_rank = 0
+        self.spectralInfo = None
         if self.solver == "cholesky" and self.useSNR:
             # tdvp.py:87-89: the SNR soft cut-off lives in the eigenbasis of S; a Cholesky factor has none
             raise ValueError("useSNR=True needs the spectral solver (solver='eigh' or 'auto'); the Cholesky path has no eigenbasis")
@@ -446,12 +464,95 @@ class TDVP:
                           f"is 0); residual {resid:.2e} is within bound", RuntimeWarning)
             self._warned_pinned = True
 
+    # ---- tdvp.py:57-64 for a numerically rank-deficient S -----------------------------------------------------------
+    def _eigh_lowrank(self, S):
+        """(ev ascending, V) of the symmetric positive semi-definite S from a pivoted Cholesky factor (csrc/eig.hip), or None when the
+        numerical rank exceeds the cap (the caller then takes the dense path).  S = L L^T + R with trace(R) <= (P - r) 1e-16 max diag;
+        L = Q1 R1 by Householder reflectors, Q = [Q1 | Q2] = I - Y T Y^T; Q1^T S Q1 = W diag(w) W^T; ev = sort([w, 0 ... 0]),
+        V = [Q1 W | Q2] in the same order.  What is not in csrc/eig.hip is library GEMM / TRSM and the r x r decomposition."""
+        P, device = S.shape[0], S.device
+        # (forced engine: no cap -- the factorisation runs until its criterion is met)
+        cap = P if self.spectralEngine == "lowrank" else max(1, min(LOWRANK_RANK_CAP, P // LOWRANK_RANK_DIVISOR))
+        key = ("lowrank", P, str(device))
+        w = self._buf_lr.get(key) if hasattr(self, "_buf_lr") else None
+        if w is None:
+            ldl = _round_up(P, 64)
+            w = dict(ldl=ldl,
+                     LT=torch.empty((cap, ldl), dtype=global_defs.tReal, device=device),
+                     YT=torch.empty((cap, ldl), dtype=global_defs.tReal, device=device),
+                     tau=torch.empty(cap, dtype=global_defs.tReal, device=device),
+                     hq=torch.empty(cap + 1, dtype=global_defs.tReal, device=device),
+                     piv=torch.zeros(cap, dtype=torch.int32, device=device),
+                     state=torch.zeros(2, dtype=torch.int32, device=device),
+                     ws=torch.zeros(nat.lib().vmcpde_pivoted_cholesky_workspace_bytes(P) // 8, dtype=global_defs.tReal, device=device),
+                     state_host=torch.zeros(2, dtype=torch.int32).pin_memory(),
+                     info_host=torch.zeros(2, dtype=global_defs.tReal).pin_memory())
+            self._buf_lr = {key: w}
+        ldl, LT, YT, tau = w["ldl"], w["LT"], w["YT"], w["tau"]
+        lds = S.stride(0)
+        step, done = 0, False
+        # the first chunk covers the previous call's rank (the spectrum moves slowly along a trajectory); the host reads `state` per chunk
+        chunk = min(cap, _round_up(self._lowrank_last_rank + 8, 16)) if self._lowrank_last_rank else min(cap, 128)
+        while step < cap:
+            n = min(chunk, cap - step)
+            nat.call("vmcpde_pivoted_cholesky", nat.ptr(S), lds, P, LOWRANK_TOL, step, n, cap, nat.ptr(LT), ldl, nat.ptr(w["piv"]),
+                     nat.ptr(w["state"]), nat.ptr(w["ws"]), w["ws"].numel() * 8, nat.stream())
+            w["state_host"].copy_(w["state"], non_blocking=True)
+            w["info_host"].copy_(w["ws"][:2], non_blocking=True)
+            torch.cuda.current_stream(device).synchronize()
+            step += n
+            chunk = 32
+            if int(w["state_host"][1]):
+                done = True
+                break
+        r = int(w["state_host"][0])
+        d0, left = float(w["info_host"][0]), float(w["info_host"][1])
+        done = done or r == P                                       # full rank: every row was a pivot, nothing is left
+        self.spectralInfo = dict(engine="lowrank", rank=r, cap=cap, max_diag=d0, trace_left=left, converged=done)
+        if not done or r < 1 or not (left <= LOWRANK_TRACE_BOUND * d0):
+            return None
+        self._lowrank_last_rank = r
+        nat.call("vmcpde_householder_rows", nat.ptr(LT), ldl, P, r, nat.ptr(YT), nat.ptr(tau), nat.ptr(w["hq"]), nat.stream())
+        Y = YT[:r, :P]                                             # r x P: row k = reflector k
+        Tinv = torch.triu(Y @ Y.T, 1)
+        Tinv.diagonal().copy_(1.0 / tau[:r])                       # T^-1 = strict upper part of Y^T Y + diag(1 / tau)
+        X = torch.linalg.solve_triangular(Tinv, Y, upper=True)     # T Y^T
+        Q = torch.matmul(Y.T, X).neg_()
+        Q.diagonal().add_(1.0)                                     # Q = I - Y T Y^T = [Q1 | Q2]
+        Q1 = Q[:, :r]
+        T = Q1.T @ (S @ Q1)
+        T = 0.5 * (T + T.T)
+        wv, W = torch.linalg.eigh(T)                               # r x r (rocSOLVER)
+        Q[:, :r] = Q1 @ W
+        vals = torch.cat([wv, torch.zeros(P - r, dtype=global_defs.tReal, device=device)])
+        order = torch.argsort(vals, stable=True)
+        return vals[order], Q.index_select(1, order)
+
     # ---- tdvp.py:57-71 -------------------------------------------------------------------------------------------
     def transform_to_eigenbasis(self, S, F, EOdata=None):
         P = F.numel()
         done = False
         on_device = (P >= DEVICE_EIGH_MIN_P) if self.diagonalizeOnDevice is None else bool(self.diagonalizeOnDevice)
-        if on_device:
+        if self.spectralEngine == "lowrank" and self.diagonalizeOnDevice is None:
+            on_device = True
+        self.spectralInfo = None
+        lowrank = on_device and self.spectralEngine != "dense" and not (self.diagonalShift > 1e-10) and \
+            (self.spectralEngine == "lowrank" or (P >= LOWRANK_MIN_P and self._lowrank_backoff == 0))
+        if on_device and self.spectralEngine == "auto" and self._lowrank_backoff > 0:
+            self._lowrank_backoff -= 1
+        if lowrank:
+            with torch.cuda.device(F.device):
+                res = self._eigh_lowrank(S)
+            if res is not None:
+                self.ev, self.V = res
+                done = True
+            elif self.spectralEngine == "auto":
+                self._lowrank_backoff = LOWRANK_RETRY_AFTER        # rank above the cap: dense for the next calls
+        if on_device and not done:
+            if self.spectralInfo is None or self.spectralInfo.get("engine") != "lowrank":
+                self.spectralInfo = dict(engine="dense")
+            else:
+                self.spectralInfo = dict(self.spectralInfo, engine="dense", tried="lowrank")
             try:
                 self.ev, self.V = torch.linalg.eigh(S)                        # tdvp.py:59 (rocSOLVER)
                 done = True
