@@ -231,6 +231,10 @@ def main():
     ap.add_argument("--jacobian", default="f64", choices=["f64", "f32", "f32blocks", "i8sliced", "i8f32"],
                     help="storage type of the per-sample Jacobian (f32 = BASELINE config 5: fp32 storage, fp64 products and sums; "
                          "f32blocks: fp32 MFMA sums over blocks of 128 samples, fp64 across blocks)")
+    ap.add_argument("--solver", default="cholesky", choices=["cholesky", "eigh", "eigh-dense"],
+                    help="cholesky: the headline (north_star's regularised on-device Cholesky); eigh: TDVP() exactly as the reference constructs "
+                         "it (tdvp.py:21-26: spectral pseudo-inverse, diagonalShift 0, svdTol 1e-11) with the rank-revealing decomposition; "
+                         "eigh-dense: the same with rocSOLVER's syevd on the full matrix -- both reported BESIDE the headline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -261,6 +265,9 @@ def main():
     if args.jacobian == "f32blocks":     # fp32 accumulation inside 128-sample blocks is not exactly PSD: needs the stronger shift
         tdvp.f32BlockGram = True
         tdvp.diagonalShift = F32BLOCKS_DIAG_SHIFT
+    if args.solver != "cholesky":
+        tdvp.solver, tdvp.diagonalShift, tdvp.svdTol = "eigh", 0.0, 1e-11
+        tdvp.spectralEngine = "dense" if args.solver == "eigh-dense" else "auto"
     P = vs.numParameters
     n_total = args.samples * world
     kwargs = dict(evolutionEq=eq, psi=vs, nSamplesTDVP=n_total, nSamplesObs=n_total, timings=None, observables=False)
@@ -362,7 +369,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_LABEL[args.jacobian], "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload]["desc"],
-                       "n_param": P, "n_samp_per_gpu": args.samples, "n_samp_total": n_total, "solver": "cholesky",
+                       "n_param": P, "n_samp_per_gpu": args.samples, "n_samp_total": n_total,
+                       "solver": "cholesky" if args.solver == "cholesky" else "eigh (TDVP() with the reference's constructor defaults: spectral pseudo-inverse)",
+                       **({} if args.solver == "cholesky" else {"spectral": tdvp.spectralInfo}),
                        "gram_operands": OPERAND_LABEL[args.jacobian] if tdvp._uncentred_ok else "centred in staging",
                        "mean2_over_var_max": ratio,
                        "diagonal_shift": float(tdvp.diagonalShift), "svd_tol": float(tdvp.svdTol), "solver_residual": resid,
