@@ -14,8 +14,12 @@ else:
 sampler = V.Sampler(key=7, dim=dim, name="Gauss", mcmc_info={"offset": offset, "bound": 0.25})
 vs = V.VarState(sampler, dim, 1, 4, network_args={"intmediate": HID, "offset": offset, "latentSpaceName": "Gauss", "dim": dim})
 eq = V.EvolutionEquation(dim=dim, name="advection_hamiltonian_wDiss")
-tdvp = V.TDVP(diagonalShift=shift, svdTol=float(os.environ.get("SVD_TOL", "1e-6")), solver="cholesky",
-              int8Gram=os.environ.get("INT8_GRAM", "0") == "1")      # INT8_GRAM=1: the S-build on the int8 matrix pipe (experiment)
+if os.environ.get("SOLVER", "cholesky") == "eigh":     # the reference's spectral solve (diagonalShift 0); ENGINE=dense|lowrank|auto picks how (ev, V) are obtained
+    tdvp = V.TDVP(svdTol=float(os.environ.get("SVD_TOL", "1e-6")), spectralEngine=os.environ.get("ENGINE", "auto"))
+else:
+    tdvp = V.TDVP(diagonalShift=shift, svdTol=float(os.environ.get("SVD_TOL", "1e-6")), solver="cholesky",
+                  int8Gram=os.environ.get("INT8_GRAM", "0") == "1")      # INT8_GRAM=1: the S-build on the int8 matrix pipe (experiment)
+engines, ranks = {}, []
 stepper = V.FixedStepper(timeStep=1e-4, mode="Heun", maxStep=1e-2, increase_fac=1.3)
 t, n, t0 = 0.0, 0, time.perf_counter()
 next_print = 0.5
@@ -25,6 +29,10 @@ while t < T_END:
     vs.set_parameters(dp)
     t += dt
     n += 1
+    if tdvp.spectralInfo is not None:
+        engines[tdvp.spectralInfo["engine"]] = engines.get(tdvp.spectralInfo["engine"], 0) + 1
+        if "rank" in tdvp.spectralInfo:
+            ranks.append(tdvp.spectralInfo["rank"])
     if t >= next_print or t >= T_END:
         # observables are taken before the step: compare with t - dt; every oscillator (x, p) is the same 2 x 2 problem
         x1, cov = info["x1"].cpu().numpy(), info["covar"].cpu().numpy()
@@ -33,3 +41,5 @@ while t < T_END:
         print(f"t={t - dt:.2f} step {n}: mean {x1.round(3)} exact {m_ex.round(3)} | cov diag {np.diagonal(cov).round(3)} exact {c_ex.round(3)} "
               f"| entropy {float(info['entropy']):.3f} | {time.perf_counter() - t0:.1f} s", flush=True)
         next_print += 0.5
+if engines:
+    print(f"spectral engine of the last right-hand side of each step: {engines}; numerical rank {min(ranks) if ranks else '-'} .. {max(ranks) if ranks else '-'}", flush=True)
