@@ -10,6 +10,8 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "C2"
 vs, eq, tdvp, theta = bench.build_problem(dev, wl)
 N = bench.WORKLOADS[wl]["n_samp"]
 tdvp.solver, tdvp.diagonalShift = "eigh", 0.0
+if len(sys.argv) > 2:
+    tdvp.spectralEngine = sys.argv[2]              # "lowrank": no rank cap
 tdvp(theta, 0.0, evolutionEq=eq, psi=vs, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
 S = tdvp.S0
 P = S.shape[0]
@@ -35,7 +37,7 @@ print(f"  + Householder rows, {r} launches: {timed(hq)[0]:.2f} ms", flush=True)
 Y = w["YT"][:r, :P]; tau = w["tau"]
 def wy():
     Tinv = torch.triu(Y @ Y.T, 1); Tinv.diagonal().copy_(1.0 / tau[:r])
-    X = torch.linalg.solve_triangular(Tinv, Y, upper=True)
+    X = torch.linalg.solve_triangular(Tinv, torch.eye(r, dtype=torch.float64, device=dev), upper=True) @ Y
     Q = torch.matmul(Y.T, X).neg_(); Q.diagonal().add_(1.0)
     return Q
 ms, Q = timed(wy); print(f"compact WY -> Q (P x P): {ms:.2f} ms", flush=True)

@@ -516,7 +516,10 @@ class TDVP:
         Y = YT[:r, :P]                                             # r x P: row k = reflector k
         Tinv = torch.triu(Y @ Y.T, 1)
         Tinv.diagonal().copy_(1.0 / tau[:r])                       # T^-1 = strict upper part of Y^T Y + diag(1 / tau)
-        X = torch.linalg.solve_triangular(Tinv, Y, upper=True)     # T Y^T
+        # T itself (r x r, what dlarft forms), then T Y^T as a GEMM: a triangular solve with P right-hand sides makes rocBLAS allocate
+        # a workspace that fails for r in the thousands
+        Tm = torch.linalg.solve_triangular(Tinv, torch.eye(r, dtype=global_defs.tReal, device=device), upper=True)
+        X = Tm @ Y                                                 # T Y^T
         Q = torch.matmul(Y.T, X).neg_()
         Q.diagonal().add_(1.0)                                     # Q = I - Y T Y^T = [Q1 | Q2]
         Q1 = Q[:, :r]
@@ -544,7 +547,13 @@ class TDVP:
             self._lowrank_backoff -= 1
         if lowrank:
             with torch.cuda.device(F.device):
-                res = self._eigh_lowrank(S)
+                try:
+                    res = self._eigh_lowrank(S)
+                except RuntimeError as exc:       # e.g. rocBLAS cannot allocate the TRSM workspace for a rank in the thousands (forced engine)
+                    import warnings
+                    warnings.warn(f"rank-revealing decomposition failed ({str(exc)[:80]}); using the dense eigh for this call", RuntimeWarning)
+                    res = None
+                    self.spectralInfo = dict(self.spectralInfo or {}, engine="lowrank", converged=False, error=str(exc)[:80])
             if res is not None:
                 self.ev, self.V = res
                 done = True
