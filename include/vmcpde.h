@@ -265,6 +265,15 @@ int64_t vmcpde_pivoted_cholesky_workspace_bytes(int32_t P);
 int vmcpde_pivoted_cholesky(const double* S, int64_t lds, int32_t P, double tol_rel, int32_t first_step, int32_t n_steps,
                             int32_t max_rank, double* LT, int64_t ldl, int32_t* piv, int32_t* state, void* workspace,
                             int64_t workspace_bytes, void* stream);
+/* The same factorisation with up to 32 pivots per pair of launches (any pivot order gives S = L L^T + R with R >= 0; candidates are
+ * the largest remaining diagonal entry of up to 32 different 64-row blocks, with pivoting inside the 32 x 32 block and candidates that
+ * fall to the tolerance dropped).  Same buffers and `state` as above (its own workspace size); `restart` != 0 starts a new
+ * factorisation, then n_blocks block steps run, then one settling launch updates state[1] and the trace of the remainder.
+ * state[0] == max_rank with state[1] == 0: the rank cap was reached before the criterion. */
+int64_t vmcpde_pivoted_cholesky_blocked_workspace_bytes(int32_t P);
+int vmcpde_pivoted_cholesky_blocked(const double* S, int64_t lds, int32_t P, double tol_rel, int32_t restart, int32_t n_blocks,
+                                    int32_t max_rank, double* LT, int64_t ldl, int32_t* piv, int32_t* state, void* workspace,
+                                    int64_t workspace_bytes, void* stream);
 /* Householder QR of the P x r matrix whose columns are the rows of LT (destroyed: the strict upper part of R, the rest is scratch).  YT: [dev] r x ldl,
  * row k = reflector v_k (zeros before k, v_k[k] = 1, zeros from P on); tau: [dev] r, H_k = I - tau_k v_k v_k^T, Q = H_0 ... H_{r-1}
  * = I - Y T Y^T with T^-1 = strict upper part of Y^T Y + diag(1 / tau)  (tau_k is never 0: a column that is already zero below its

@@ -89,6 +89,59 @@ def test_pivoted_cholesky_against_numpy():
         assert r3 == 0 and done3 == 1
 
 
+def _run_pivchol_blocked(S, tol, cap, calls):
+    from vmc_pde_amd import _native as nat
+    P = S.shape[0]
+    Sd = torch.from_numpy(S).cuda()
+    ldl = (P + 63) // 64 * 64
+    LT = torch.full((cap, ldl), float("nan"), dtype=torch.float64, device="cuda")
+    piv = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ws = torch.zeros(nat.lib().vmcpde_pivoted_cholesky_blocked_workspace_bytes(P) // 8, dtype=torch.float64, device="cuda")
+    for c, nb in enumerate(calls):
+        nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(Sd), P, P, tol, 1 if c == 0 else 0, nb, cap, nat.ptr(LT), ldl, nat.ptr(piv), nat.ptr(state),
+                 nat.ptr(ws), ws.numel() * 8, nat.stream())
+    torch.cuda.synchronize()
+    r, done = int(state[0]), int(state[1])
+    return LT[:r].cpu().numpy(), piv[:r].cpu().numpy(), r, done, ws[:2].cpu().numpy()
+
+
+@pytest.mark.parametrize("P,per_decade", [(700, 9.0), (4213, 14.0), (130, 2.5)])
+def test_blocked_pivoted_cholesky(P, per_decade):
+    """Up to 32 pivots per pair of launches, in whatever order the candidates come: the properties that make it a pivoted Cholesky
+    factorisation, and the same numerical rank as the greedy order."""
+    S = _graded_psd(P, per_decade, 2048 if P > 2000 else 4096, seed=8)
+    _, piv_ref = _pivoted_cholesky_numpy(S, 1e-14) if P <= 1000 else (None, None)
+    cap = min(P, 600)
+    LT, piv, r, done, head = _run_pivchol_blocked(S, 1e-14, cap, calls=(2, 1, 40))        # resumed twice
+    assert done == 1 and 0 < r < cap
+    if piv_ref is not None:
+        assert abs(r - len(piv_ref)) <= max(4, len(piv_ref) // 20), (r, len(piv_ref))
+    assert len(set(piv.tolist())) == r and piv.min() >= 0 and piv.max() < P
+    L = LT[:, :P].T                                                    # P x r
+    assert np.all(np.isfinite(LT)) and np.all(LT[:, P:] == 0.0)
+    # a pivot row has a positive entry in its own column and structural zeros in every later one
+    for k in range(r):
+        assert L[piv[k], k] > 0.0
+        assert np.all(L[piv[k], k + 1:] == 0.0)
+    # S = L L^T + R, R what the criterion left: every remaining diagonal entry <= 1e-14 max diag (up to the round-off of the downdates)
+    d0 = np.diag(S).max()
+    R = S - L @ L.T
+    assert head[0] == d0
+    assert np.diag(R).max() < 1.2e-14 * d0 and np.abs(R).max() < 1.2e-14 * d0 and np.diag(R).min() > -1e-14 * d0, (np.diag(R).max() / d0, np.diag(R).min() / d0)
+    assert 0.0 <= head[1] <= (P - r) * 1e-14 * d0
+    # the factor spans the range of S as well as the greedy one: eigenvalues of L L^T against those of S
+    ev = np.linalg.eigvalsh(S)
+    ev_l = np.linalg.eigvalsh(L.T @ L)
+    assert np.abs(ev[-r:] - ev_l).max() < 1e-14 * ev[-1]
+    # the rank cap: reached without the criterion
+    cap2 = min(40, r // 2)
+    LT2, piv2, r2, done2, _ = _run_pivchol_blocked(S, 1e-14, cap=cap2, calls=(20,))       # (130 rows are 3 row blocks: 3 candidates per step)
+    assert done2 == 0 and r2 == cap2 and len(set(piv2.tolist())) == cap2
+    assert np.abs(S - LT2[:, :P].T @ LT2[:, :P]).max() < np.abs(S).max()          # (a partial factorisation: positive semi-definite remainder)
+    assert np.linalg.eigvalsh(S - LT2[:, :P].T @ LT2[:, :P]).min() > -1e-13 * d0
+
+
 def test_householder_rows_against_numpy():
     from vmc_pde_amd import _native as nat
     rng = np.random.default_rng(2)

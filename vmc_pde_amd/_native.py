@@ -91,6 +91,8 @@ _PROTOS = {
     "vmcpde_pinv_coeffs": (_int, [_vp, _vp, _vp, _i32, _f64, _f64, _vp, _vp]),
     "vmcpde_pivoted_cholesky_workspace_bytes": (_i64, [_i32]),
     "vmcpde_pivoted_cholesky": (_int, [_vp, _i64, _i32, _f64, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "vmcpde_pivoted_cholesky_blocked_workspace_bytes": (_i64, [_i32]),
+    "vmcpde_pivoted_cholesky_blocked": (_int, [_vp, _i64, _i32, _f64, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "vmcpde_householder_rows": (_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
 }
 

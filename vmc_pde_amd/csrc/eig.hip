@@ -157,6 +157,216 @@ __global__ void pivchol_trace_kernel(const double* __restrict__ cand_sum, int nw
   if (threadIdx.x == 0) work->trace_left = sum;
 }
 
+// ---- the same factorisation, PB pivots per pair of launches ------------------------------------------------------------------
+// A pivot order need not be the greedy one: ANY order gives S = L L^T + R with R >= 0, and stopping when no remaining diagonal entry
+// exceeds tol * max diag bounds trace(R) as before.  A block step takes the largest remaining entry of up to PB different 64-row
+// blocks as candidates C (one wave picks them from the per-block candidates the previous step left), forms the panel
+// A = S[:, C] - L L[C, :]^T (launch 1), factors the PB x PB block A[C, C] with pivoting INSIDE the block -- candidates whose remaining
+// entry falls to <= tol * max diag once their predecessors are eliminated are dropped --, and appends the accepted columns
+// L[:, new] = A[:, C_acc] L_bb^-T row by row, downdates d and renews the candidates (launch 2).  238 columns at P = 4213 take 9 block
+// steps = 18 launches instead of 246.
+constexpr int PB = 32;                               // candidates per block step
+constexpr int PBK = 128;                             // earlier columns staged per tile of the panel product
+constexpr int PF_ROWS = 256;                         // rows per workgroup of the second launch (one per thread)
+constexpr int PB_MAX_BLOCKS = 1024;                  // 64-row blocks a matrix may have (P <= 65 536)
+
+struct PivDesc {             // written by workgroup 0 of the panel launch, read by every workgroup of the factor launch
+  int k, bsel;
+  int C[PB];
+};
+
+__global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* __restrict__ S, int64_t lds, int P, double tol_rel, int max_rank,
+                                                                  const double* __restrict__ LT, int64_t ldl,
+                                                                  const double* __restrict__ cand_val, const int* __restrict__ cand_idx,
+                                                                  const double* __restrict__ cand_sum, int nblk, double* __restrict__ AP,
+                                                                  PivDesc* __restrict__ desc, int32_t* __restrict__ state,
+                                                                  PivWork* __restrict__ work) {
+  __shared__ double cv[PB_MAX_BLOCKS];
+  __shared__ int ci[PB_MAX_BLOCKS];
+  __shared__ double Wt[PBK][PB];
+  __shared__ int s_C[PB];
+  __shared__ int s_bsel, s_k, s_done;
+  __shared__ double s_sum, s_top;
+  const int t = threadIdx.x, lane = t & 63;
+  const int slice = __builtin_amdgcn_readfirstlane(t >> 6);
+  for (int q = t; q < nblk; q += PC_THREADS) { cv[q] = cand_val[q]; ci[q] = cand_idx[q]; }
+  __syncthreads();
+  if (slice == 0) {
+    const int k = state[0];
+    double sum = 0.0;
+    for (int q = lane; q < nblk; q += 64) sum += cand_sum[q];
+    sum = wave_sum(sum);
+    double d0 = (k == 0) ? 0.0 : work->d0;
+    const int room = max_rank - k;
+    int bsel = 0;
+    double top = 0.0;
+    for (int m = 0; m < PB; ++m) {                  // the PB largest per-block candidates, largest first
+      double v = NEG_INF;
+      int idx = 0x7fffffff, where = -1;
+      for (int q = lane; q < nblk; q += 64) {
+        const double ov = cv[q];
+        const int oi = ci[q];
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; where = q; }
+      }
+      double bv = v;
+      int bi = idx;
+      wave_argmax(bv, bi);
+      if (m == 0) { top = bv; if (k == 0) d0 = bv; }
+      if (!(bv > tol_rel * d0) || m >= room) break;
+      if (bi == idx && where >= 0 && bv == v) cv[where] = NEG_INF;     // (the row index is unique: exactly one lane owns it)
+      if (lane == 0) s_C[m] = bi;
+      bsel = m + 1;
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) { s_bsel = bsel; s_k = k; s_done = state[1]; s_sum = sum; s_top = top; }
+  }
+  __syncthreads();
+  if (s_done) return;
+  const int k = s_k, bsel = s_bsel;
+  if (blockIdx.x == 0 && t == 0) {
+    desc->k = k;
+    desc->bsel = bsel;
+    for (int m = 0; m < bsel; ++m) desc->C[m] = s_C[m];
+    if (k == 0) work->d0 = s_top;
+    work->trace_left = s_sum;
+    if (bsel == 0 && k < max_rank) state[1] = 1;                       // nothing left above the tolerance (a full `max_rank` is not "done")
+  }
+  if (bsel == 0) return;
+  // ---- panel: A[i][m] = S[C_m][i] - sum_{j < k} L[i][j] L[C_m][j]; wave s forms the columns 2 s, 2 s + 1 for the 64 rows of the workgroup
+  const int i = (int)blockIdx.x * PC_ROWS + lane;                      // (< ldl)
+  const int m0 = 2 * slice, m1 = m0 + 1;
+  double acc0 = 0.0, acc1 = 0.0;
+  for (int j0 = 0; j0 < k; j0 += PBK) {
+    const int nj = (k - j0 < PBK) ? (k - j0) : PBK;
+    __syncthreads();
+    for (int e = t; e < nj * PB; e += PC_THREADS) {
+      const int jj = e / PB, m = e - jj * PB;
+      Wt[jj][m] = (m < bsel) ? LT[(int64_t)(j0 + jj) * ldl + s_C[m]] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int jj = 0; jj < nj; ++jj) {
+      const double v = LT[(int64_t)(j0 + jj) * ldl + i];
+      acc0 = fma(v, Wt[jj][m0], acc0);
+      acc1 = fma(v, Wt[jj][m1], acc1);
+    }
+  }
+  const bool inside = i < P;
+  AP[(int64_t)m0 * ldl + i] = (inside && m0 < bsel) ? S[(int64_t)s_C[m0] * lds + i] - acc0 : 0.0;
+  AP[(int64_t)m1 * ldl + i] = (inside && m1 < bsel) ? S[(int64_t)s_C[m1] * lds + i] - acc1 : 0.0;
+}
+
+__global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double tol_rel, double* __restrict__ LT, int64_t ldl, double* __restrict__ d,
+                                                                double* __restrict__ cand_val, int* __restrict__ cand_idx,
+                                                                double* __restrict__ cand_sum, int nblk, const double* __restrict__ AP,
+                                                                const PivDesc* __restrict__ desc, int32_t* __restrict__ piv,
+                                                                int32_t* __restrict__ state, const PivWork* __restrict__ work) {
+  __shared__ double LP[PB][PB + 1];        // row n = the n-th accepted pivot's row of the block factor (columns 0 .. n)
+  __shared__ double Lb[PB][PB + 1];        // block factor by candidate: Lb[m][n], n = elimination step
+  __shared__ double Abb[PB][PB + 1];       // the block itself: Abb[m][c] = A[C_m][c] (column c of the panel at the row of candidate m)
+  __shared__ double s_left[PB];            // what is left of every candidate's diagonal entry after the block
+  __shared__ int s_perm[PB], s_C[PB], s_acc[PB];
+  __shared__ int s_bacc, s_k, s_bsel, s_done;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) { s_k = desc->k; s_bsel = desc->bsel; s_done = state[1]; }
+  if (t < PB) { s_C[t] = desc->C[t]; s_acc[t] = 0; }
+  __syncthreads();
+  const int k = s_k, bsel = s_bsel;
+  if (s_done || bsel == 0) return;
+  if (wave == 0) {
+    // the PB x PB block with pivoting: lane m holds candidate m (its row of the block, then its row of the factor); left-looking
+    const int m = lane;
+    const bool mine = m < bsel;
+    const double thresh = tol_rel * work->d0;
+    double Lm[PB];
+#pragma unroll
+    for (int n = 0; n < PB; ++n) {           // (all loads of the block in flight at once: the elimination below then runs out of the LDS)
+      Lm[n] = 0.0;
+      if (mine) Abb[m][n] = (n < bsel) ? AP[(int64_t)n * ldl + s_C[m]] : 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    double diag = mine ? Abb[m][m] : NEG_INF;
+    bool used = !mine;
+    int bacc = 0;
+#pragma unroll
+    for (int n = 0; n < PB; ++n) {
+      double v = used ? NEG_INF : diag;
+      int p = m;
+      wave_argmax(v, p);
+      if (!(v > thresh)) break;              // (wave-uniform)
+      const double lpp = sqrt(v);
+      // l[m][n] = (A[m][p] - sum_{q < n} L[m][q] L[p][q]) / l_pp ; row p of the factor comes from the lane that holds it, through LDS
+      double sum = 0.0;
+#pragma unroll
+      for (int q = 0; q < PB; ++q)
+        if (q < n) sum = fma(Lm[q], Lb[p][q], sum);
+      double l = 0.0;
+      if (mine && !used) l = (m == p) ? lpp : (Abb[m][p] - sum) / lpp;
+      Lm[n] = l;
+      if (mine) Lb[m][n] = l;
+      if (mine && !used && m != p) diag -= l * l;
+      if (m == p) { used = true; s_perm[n] = m; s_acc[m] = 1; }
+      bacc = n + 1;
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the row just written is read by every lane in the next step
+    }
+    if (mine) s_left[m] = diag;
+    if (lane == 0) s_bacc = bacc;
+  }
+  __syncthreads();
+  const int bacc = s_bacc;
+  for (int e = t; e < bacc * PB; e += PF_ROWS) {           // factor rows in elimination order
+    const int n = e / PB, q = e - n * PB;
+    LP[n][q] = (q <= n) ? Lb[s_perm[n]][q] : 0.0;
+  }
+  __syncthreads();
+  // ---- one row per thread: x = A[i][C_acc] L_bb^-T (forward substitution in elimination order), L[i][k + n] = x_n, d_i -= |x|^2
+  const int i = (int)blockIdx.x * PF_ROWS + t;
+  const bool inside = i < P;
+  const double di = inside ? d[i] : NEG_INF;
+  const bool open = inside && di != NEG_INF;
+  int own = PB;                            // elimination step at which this row became a pivot (PB: it is none of this block's pivots)
+  for (int n = 0; n < bacc; ++n)
+    if (s_C[s_perm[n]] == i) own = n;
+  double x[PB];
+  double ss = 0.0;
+#pragma unroll
+  for (int n = 0; n < PB; ++n) {
+    x[n] = 0.0;
+    if (n < bacc) {
+      double v = open ? AP[(int64_t)s_perm[n] * ldl + i] : 0.0;
+#pragma unroll
+      for (int q = 0; q < PB; ++q)
+        if (q < n) v = fma(-x[q], LP[n][q], v);
+      v = (open && n <= own) ? v / LP[n][n] : 0.0;        // (a pivot row is finished: structural zeros in the later columns)
+      x[n] = v;
+      ss = fma(v, v, ss);
+      if (i < (int)ldl) LT[(int64_t)(k + n) * ldl + i] = v;
+    }
+  }
+  double nd = open ? di - ss : NEG_INF;
+  if (open) {
+    for (int m = 0; m < bsel; ++m)
+      if (s_C[m] == i) nd = s_acc[m] ? NEG_INF : s_left[m];     // a pivot is finished; a dropped candidate keeps what the block left of it
+  }
+  if (inside) d[i] = nd;
+  int idx = i;
+  double pos = (nd > 0.0) ? nd : 0.0;
+  wave_argmax(nd, idx);
+  pos = wave_sum(pos);
+  const int blk = (int)blockIdx.x * (PF_ROWS / 64) + wave;
+  if (lane == 0 && blk < nblk) {
+    cand_val[blk] = nd;
+    cand_idx[blk] = idx;
+    cand_sum[blk] = pos;
+  }
+  if (blockIdx.x == 0 && t == 0) {
+    state[0] = k + bacc;
+    for (int n = 0; n < bacc; ++n) piv[k + n] = s_C[s_perm[n]];
+  }
+}
+
 constexpr int HQ_THREADS = 1024;
 constexpr int HQ_WAVES = HQ_THREADS / 64;
 
@@ -230,6 +440,8 @@ int64_t pivchol_ws_doubles(int P) {
   return 8 /* PivWork, padded */ + (int64_t)nwg * PC_ROWS /* d */ + 2 * nwg /* cand_val */ + 2 * nwg /* cand_sum */ + nwg /* cand_idx (2 x int32) */ + 8;
 }
 
+int64_t pivblk_ws_doubles(int P, int64_t ldl) { return pivchol_ws_doubles(P) + 64 /* PivDesc */ + (int64_t)PB * ldl /* panel */; }
+
 }  // namespace
 }  // namespace vmcpde
 
@@ -273,3 +485,46 @@ extern "C" int vmcpde_householder_rows(double* LT, int64_t ldl, int32_t P, int32
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+extern "C" int64_t vmcpde_pivoted_cholesky_blocked_workspace_bytes(int32_t P) {
+  if (P < 1) return 0;
+  const int64_t ldl = (int64_t)((P + PC_ROWS - 1) / PC_ROWS) * PC_ROWS;
+  return pivblk_ws_doubles(P, ldl) * (int64_t)sizeof(double);
+}
+
+extern "C" int vmcpde_pivoted_cholesky_blocked(const double* S, int64_t lds, int32_t P, double tol_rel, int32_t restart, int32_t n_blocks,
+                                               int32_t max_rank, double* LT, int64_t ldl, int32_t* piv, int32_t* state, void* workspace,
+                                               int64_t workspace_bytes, void* stream) {
+  VMC_REQUIRE(S && LT && piv && state && workspace, "vmcpde_pivoted_cholesky_blocked: null argument");
+  VMC_REQUIRE(P >= 1 && lds >= P, "vmcpde_pivoted_cholesky_blocked: bad shape");
+  const int nblk = (P + PC_ROWS - 1) / PC_ROWS;
+  VMC_REQUIRE(nblk <= PB_MAX_BLOCKS, "vmcpde_pivoted_cholesky_blocked: P <= 65536");
+  VMC_REQUIRE(ldl == (int64_t)nblk * PC_ROWS, "vmcpde_pivoted_cholesky_blocked: ldl must be P rounded up to a multiple of 64");
+  VMC_REQUIRE(n_blocks >= 0 && max_rank >= 1 && max_rank <= P, "vmcpde_pivoted_cholesky_blocked: bad step count / rank cap");
+  VMC_REQUIRE(tol_rel >= 0.0, "vmcpde_pivoted_cholesky_blocked: negative tolerance");
+  VMC_REQUIRE(workspace_bytes >= vmcpde_pivoted_cholesky_blocked_workspace_bytes(P), "vmcpde_pivoted_cholesky_blocked: workspace too small");
+  double* w = static_cast<double*>(workspace);
+  PivWork* work = reinterpret_cast<PivWork*>(w);
+  double* d = w + 8;
+  double* cand_val = d + (int64_t)nblk * PC_ROWS;
+  double* cand_sum = cand_val + 2 * nblk;
+  int* cand_idx = reinterpret_cast<int*>(cand_sum + 2 * nblk);
+  PivDesc* desc = reinterpret_cast<PivDesc*>(w + pivchol_ws_doubles(P));
+  double* AP = w + pivchol_ws_doubles(P) + 64;
+  hipStream_t st = (hipStream_t)stream;
+  if (restart) hipLaunchKernelGGL(pivchol_init_kernel, dim3(nblk), dim3(PC_ROWS), 0, st, S, lds, P, d, cand_val, cand_idx, cand_sum, state);
+  const int nfac = (P + PF_ROWS - 1) / PF_ROWS;
+  for (int b = 0; b < n_blocks; ++b) {
+    hipLaunchKernelGGL(pivblk_panel_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, S, lds, P, tol_rel, max_rank, LT, ldl, cand_val, cand_idx, cand_sum,
+                       nblk, AP, desc, state, work);
+    hipLaunchKernelGGL(pivblk_factor_kernel, dim3(nfac), dim3(PF_ROWS), 0, st, P, tol_rel, LT, ldl, d, cand_val, cand_idx, cand_sum, nblk, AP, desc,
+                       piv, state, work);
+  }
+  // one more panel launch settles `state` after the last factor launch: done if nothing is left above the tolerance, and the trace of
+  // the remainder (it selects, writes the descriptor and its panel, which the next call's first launch simply recomputes)
+  hipLaunchKernelGGL(pivblk_panel_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, S, lds, P, tol_rel, max_rank, LT, ldl, cand_val, cand_idx, cand_sum, nblk,
+                     AP, desc, state, work);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+

@@ -54,7 +54,11 @@ DEVICE_EIGH_MIN_P = 640     # diagonalizeOnDevice=None: rocSOLVER's syevd overta
 LOWRANK_MIN_P = 1024        # spectralEngine="auto": the rank-revealing decomposition from this many parameters on (below, syevd takes < 25 ms)
 LOWRANK_RANK_CAP = 768      # ... while the numerical rank stays below this and below P / LOWRANK_RANK_DIVISOR: its chains are r dependent
 LOWRANK_RANK_DIVISOR = 6    #   launches of O(P r) work each, and the r x r core goes to syevd
-LOWRANK_TOL = 1e-16         # pivoting stops when the largest remaining diagonal entry is <= this x max diag(S)
+LOWRANK_TOL = 1e-14         # pivoting stops when the largest remaining diagonal entry is <= this x max diag(S).  The downdated diagonal of a row
+                            #   carries round-off of ~5 eps S_ii, and a pivot p turns noise n into a column of size n / sqrt(p): pivots must
+                            #   stay an order of magnitude above 1e-15 max diag (with 1e-16 the last columns added 4e-13 max diag to L L^T on
+                            #   a 700 x 700 test matrix; LAPACK's dpstrf stops at P eps max diag = 9e-13 here).  max diag <= lambda_max, so
+                            #   everything dropped lies below the reference's hard cut-off at 1e-14 lambda_max (tdvp.py:82)
 LOWRANK_TRACE_BOUND = 1e-12 # accept only if the trace of the remainder (an upper bound of its norm) is below this x max diag(S)
 LOWRANK_RETRY_AFTER = 50    # "auto": calls on the dense path after one whose rank exceeded the cap, before the next attempt
 
