@@ -371,7 +371,7 @@ def main():
             "config": {"workload": WORKLOADS[args.workload]["desc"],
                        "n_param": P, "n_samp_per_gpu": args.samples, "n_samp_total": n_total,
                        "solver": "cholesky" if args.solver == "cholesky" else "eigh (TDVP() with the reference's constructor defaults: spectral pseudo-inverse)",
-                       **({} if args.solver == "cholesky" else {"spectral": tdvp.spectralInfo}),
+                       **({"cholesky_engine": tdvp.choleskyInfo} if args.solver == "cholesky" else {"spectral": tdvp.spectralInfo}),
                        "gram_operands": OPERAND_LABEL[args.jacobian] if tdvp._uncentred_ok else "centred in staging",
                        "mean2_over_var_max": ratio,
                        "diagonal_shift": float(tdvp.diagonalShift), "svd_tol": float(tdvp.svdTol), "solver_residual": resid,

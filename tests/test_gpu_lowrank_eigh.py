@@ -266,3 +266,50 @@ def test_engine_choice_and_fallbacks(headline_net):
     assert float(torch.linalg.norm(S @ tf.V - tf.V * tf.ev)) < 1e-12 * float(ev_ref[-1])
     with pytest.raises(ValueError, match="spectralEngine"):
         V.TDVP(spectralEngine="jacobi")
+
+
+def test_lowrank_cholesky_solve_matches_the_dense_factorisation(headline_net, monkeypatch):
+    """solver="cholesky" through the pivoted factor + Woodbury + refinement against the blocked factorisation of the full matrix: the
+    same regularised system, so the same update to round-off -- and the fallbacks when the low-rank route does not apply."""
+    import vmc_pde_amd as V
+    varstate, ep, th = headline_net
+    N = 8192
+    vs = varstate(N)
+    kw = dict(nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+    out = {}
+    import vmc_pde_amd.tdvp as T
+    for engine in ("dense", "lowrank", "auto", "auto-large"):
+        tp = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine=engine.split("-")[0])
+        if engine == "auto-large":                # "auto" takes the low-rank route from 8192 parameters on: here as if 4213 were that large
+            monkeypatch.setattr(T, "LOWRANK_CHOL_MIN_P", 1024)
+        u, _ = tp(th.cuda(), 0.0, vs, ep, **kw)
+        tp.check()
+        out[engine] = (tp.S0.clone(), tp.F0.clone(), u.clone(), float(tp.solverResidual), float(tp.tdvp_error), dict(tp.choleskyInfo), tp)
+    S, F, u_d, res_d, err_d, info_d, tp_d = out["dense"]
+    assert info_d == dict(engine="dense") and out["auto"][5] == dict(engine="dense")          # P = 4213 < LOWRANK_CHOL_MIN_P
+    assert torch.equal(out["auto"][2], u_d)
+    P = S.shape[0]
+    D = 1e-4 * torch.diagonal(S) + 1e-6 * torch.diagonal(S).max()
+    for engine in ("lowrank", "auto-large"):
+        S2, F2, u, res, err, info, _ = out[engine]
+        assert torch.equal(S2, S) and torch.equal(F2, F)
+        assert info["engine"] == "lowrank" and info["converged"] and 1 <= info["rank"] < P // 6, info
+        assert info["trace_left"] / info["min_shift"] < 1e-5 and abs(info["min_shift"] - float(D.min())) < 1e-12 * float(D.min())
+        # the solution of the same system: against the dense factorisation and against the matrix itself
+        # (the matrix has a condition number of ~3e7: two solutions with residuals of 1e-13 may differ by 1e-6 in norm; the statement is
+        # about the residual of each and about their difference as the matrix sees it)
+        nF = float(torch.linalg.norm(F))
+        du = u - u_d
+        assert float(torch.linalg.norm(S @ du + D * du)) < 1e-11 * nF, float(torch.linalg.norm(S @ du + D * du)) / nF
+        assert float(torch.linalg.norm(S @ u + D * u - F)) < 1e-12 * nF and float(torch.linalg.norm(S @ u_d + D * u_d - F)) < 1e-11 * nF
+        assert float(torch.linalg.norm(du) / torch.linalg.norm(u_d)) < 1e-4
+        assert res < 1e-12 and res_d < 1e-12 and abs(err - err_d) < 1e-10
+    # a floor far below what the factorisation leaves of S: refinement would not contract, the full matrix is factored instead
+    tq = V.TDVP(diagonalShift=1e-6, svdTol=1e-12, solver="cholesky")        # ("auto" with the lowered size threshold still in place)
+    uq, _ = tq(th.cuda(), 0.0, vs, ep, **kw)
+    assert tq.choleskyInfo["engine"] == "dense" and tq.choleskyInfo["tried"] == "lowrank" and tq._chol_backoff > 0
+    assert tq.choleskyInfo["trace_left"] / tq.choleskyInfo["min_shift"] > 1e-4
+    tq(th.cuda(), 0.0, vs, ep, **kw)
+    assert tq.choleskyInfo == dict(engine="dense")                      # not retried right away
+    with pytest.raises(ValueError, match="choleskyEngine"):
+        V.TDVP(choleskyEngine="qr")

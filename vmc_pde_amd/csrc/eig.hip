@@ -170,7 +170,16 @@ constexpr int PBK = 128;                             // earlier columns staged p
 constexpr int PF_ROWS = 256;                         // rows per workgroup of the second launch (one per thread)
 constexpr int PB_MAX_BLOCKS = 1024;                  // 64-row blocks a matrix may have (P <= 65 536)
 
+// Pivots of one block step must not fall far below the largest remaining diagonal entry: a pivot p turns the round-off n of a panel
+// entry into an error n / sqrt(p) of the new column, i.e. 2 sqrt(d_i / p) n in the remaining diagonal of row i.  Greedy pivoting has
+// d_i <= p always; a block that accepted whatever stayed above the stopping tolerance (pivots of 1e-13 max diag next to rows with
+// 1e-6 left -- strongly correlated candidates collapse once their neighbours are eliminated) lost 1e-7 max diag on the model's S.
+// Candidates below PB_THETA x (largest candidate of the step) are therefore neither selected nor accepted inside the block; they
+// stay open with their recomputed diagonal entry and come back when the rest has caught up.
+constexpr double PB_THETA = 0.01;
+
 struct PivDesc {             // written by workgroup 0 of the panel launch, read by every workgroup of the factor launch
+  double top;                // largest remaining diagonal entry at the start of the step
   int k, bsel;
   int C[PB];
 };
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
       int bi = idx;
       wave_argmax(bv, bi);
       if (m == 0) { top = bv; if (k == 0) d0 = bv; }
-      if (!(bv > tol_rel * d0) || m >= room) break;
+      if (!(bv > tol_rel * d0) || !(bv >= PB_THETA * top) || m >= room) break;
       if (bi == idx && where >= 0 && bv == v) cv[where] = NEG_INF;     // (the row index is unique: exactly one lane owns it)
       if (lane == 0) s_C[m] = bi;
       bsel = m + 1;
@@ -224,6 +233,7 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
   if (s_done) return;
   const int k = s_k, bsel = s_bsel;
   if (blockIdx.x == 0 && t == 0) {
+    desc->top = s_top;
     desc->k = k;
     desc->bsel = bsel;
     for (int m = 0; m < bsel; ++m) desc->C[m] = s_C[m];
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double to
     // the PB x PB block with pivoting: lane m holds candidate m (its row of the block, then its row of the factor); left-looking
     const int m = lane;
     const bool mine = m < bsel;
-    const double thresh = tol_rel * work->d0;
+    const double thresh = fmax(tol_rel * work->d0, PB_THETA * desc->top);
     double Lm[PB];
 #pragma unroll
     for (int n = 0; n < PB; ++n) {           // (all loads of the block in flight at once: the elimination below then runs out of the LDS)

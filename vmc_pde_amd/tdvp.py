@@ -60,6 +60,9 @@ LOWRANK_TOL = 1e-14         # pivoting stops when the largest remaining diagonal
                             #   a 700 x 700 test matrix; LAPACK's dpstrf stops at P eps max diag = 9e-13 here).  max diag <= lambda_max, so
                             #   everything dropped lies below the reference's hard cut-off at 1e-14 lambda_max (tdvp.py:82)
 LOWRANK_TRACE_BOUND = 1e-12 # accept only if the trace of the remainder (an upper bound of its norm) is below this x max diag(S)
+LOWRANK_CHOL_MIN_P = 8192   # choleskyEngine="auto": the low-rank solve from this many parameters on (P = 4213: 3.3 ms against 2.1 ms for the blocked
+                            #   factorisation of the full matrix -- 20 block steps of 75 us and ~40 library launches; P = 16 181: 7.4 against 38 ms)
+LOWRANK_SOLVE_RHO = 1e-4    # low-rank Cholesky solve: largest trace(R) / min D accepted (the contraction factor of its iterative refinement)
 LOWRANK_RETRY_AFTER = 50    # "auto": calls on the dense path after one whose rank exceeded the cap, before the next attempt
 
 
@@ -88,6 +91,14 @@ class TDVP:
                                   #   the backward error of a dense eigensolver, the ~P - r eigenvalues below 1e-16 of the largest
                                   #   reported as exact zeros.  "auto": lowrank from LOWRANK_MIN_P parameters on when diagonalShift
                                   #   leaves S rank deficient, dense whenever the rank exceeds the cap (then not retried for a while).
+    choleskyEngine: str = "auto"  # how solver="cholesky" solves (S + diagonalShift diag(S) + floor I) u = F.  "dense": the blocked factorisation of
+                                  #   the full matrix (csrc/solve.hip: 2.0 ms at P = 4213, 36 ms at 16 181).  "lowrank": S = L L^T + R by the
+                                  #   pivoted Cholesky of csrc/eig.hip (r = 190 columns of 4213), the diagonal part D through the Woodbury
+                                  #   identity -- a Cholesky of the r x r matrix I + L^T D^-1 L -- and one or two steps of iterative refinement
+                                  #   against the TRUE matrix S + D, which remove what R and the identity's cancellation left (the solution
+                                  #   of the same system to ~1e-14).  "auto": lowrank from LOWRANK_CHOL_MIN_P parameters on (where the O(P^3)
+                                  #   factorisation costs more than the r dependent block steps) while the rank stays under the cap and
+                                  #   trace(R) under 1e-4 min D; dense otherwise (and for the next LOWRANK_RETRY_AFTER calls).
     residualBound: float = 1e-6   # Cholesky path: a solver residual above this (or a NaN) is treated as a failed factorisation
     centering: str = "auto"       # "exact": global means before the Gram (an extra pass over J, + one tiny all-reduce when sharded)
                                   # "lagged": previous call's global mean as shift -> one pass, a single all-reduce per step
@@ -114,6 +125,10 @@ class TDVP:
             raise ValueError(f"unknown solver {self.solver!r}")
         if self.spectralEngine not in ("auto", "dense", "lowrank"):
             raise ValueError(f"unknown spectralEngine {self.spectralEngine!r}")
+        if self.choleskyEngine not in ("auto", "dense", "lowrank"):
+            raise ValueError(f"unknown choleskyEngine {self.choleskyEngine!r}")
+        self._chol_backoff = 0
+        self.choleskyInfo = None
         self._lowrank_backoff = 0
         self._lowrank_last_rank = 0
         self.spectralInfo = None
@@ -468,50 +483,102 @@ class TDVP:
                           f"is 0); residual {resid:.2e} is within bound", RuntimeWarning)
             self._warned_pinned = True
 
+    # ---- the pivoted Cholesky factor of S shared by the rank-revealing spectral decomposition and the low-rank Cholesky solve ----
+    def _lowrank_buffers(self, P, device, cap):
+        key = ("lowrank", P, str(device))
+        w = self._buf_lr.get(key) if hasattr(self, "_buf_lr") else None
+        if w is None or w["LT"].shape[0] < cap:
+            ldl = _round_up(P, 64)
+            w = dict(ldl=ldl,
+                     LT=torch.empty((cap, ldl), dtype=global_defs.tReal, device=device),
+                     YT=None, tau=None, hq=None,
+                     piv=torch.zeros(cap, dtype=torch.int32, device=device),
+                     state=torch.zeros(2, dtype=torch.int32, device=device),
+                     ws=torch.zeros(nat.lib().vmcpde_pivoted_cholesky_blocked_workspace_bytes(P) // 8, dtype=global_defs.tReal, device=device),
+                     state_host=torch.zeros(2, dtype=torch.int32).pin_memory(),
+                     info_host=torch.zeros(3, dtype=global_defs.tReal).pin_memory())
+            self._buf_lr = {key: w}
+        return w
+
+    def _pivoted_factor(self, S, w, cap, extra=None):
+        """S = L L^T + R by blocked diagonal pivoting (up to 32 columns per pair of launches) into w["LT"]; returns (rank, converged,
+        max diag, trace of R, extra's value).  The first call covers the previous call's rank (the spectrum moves slowly along a
+        trajectory); the host reads `state` after every call (`extra`: a device scalar copied along)."""
+        P, device = S.shape[0], S.device
+        done, first = False, True
+        nblocks = (self._lowrank_last_rank + 31) // 32 + 2 if self._lowrank_last_rank else 10
+        while True:
+            nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S), S.stride(0), P, LOWRANK_TOL, 1 if first else 0, nblocks, cap, nat.ptr(w["LT"]),
+                     w["ldl"], nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), w["ws"].numel() * 8, nat.stream())
+            w["state_host"].copy_(w["state"], non_blocking=True)
+            w["info_host"][:2].copy_(w["ws"][:2], non_blocking=True)
+            if extra is not None and first:
+                w["info_host"][2:3].copy_(extra.reshape(1), non_blocking=True)
+            torch.cuda.current_stream(device).synchronize()
+            first, nblocks = False, 3
+            if int(w["state_host"][1]):
+                done = True
+                break
+            if int(w["state_host"][0]) >= cap:
+                break
+        r = int(w["state_host"][0])
+        done = done or r == P                                       # full rank: every row was a pivot, nothing is left
+        return r, done, float(w["info_host"][0]), float(w["info_host"][1]), float(w["info_host"][2])
+
+    # ---- solver="cholesky" through the low-rank factor ----------------------------------------------------------------
+    def _solve_lowrank(self, b, F, P, update):
+        """(S0 + D) u = F with D = diagonalShift diag(S0) + floor I > 0 and S0 = L L^T + R:  M = D + L L^T is inverted by the Woodbury
+        identity, M^-1 v = D^-1 v - D^-1 L G^-1 L^T D^-1 v with G = I + L^T D^-1 L (r x r, Cholesky), and u <- u + M^-1 (F - (S0 + D) u)
+        with the TRUE S0 removes what R (|M^-1 R| <= trace(R) / min D) and the identity's cancellation left.  False: not applicable
+        (rank above the cap, D not positive, R too large) -- the caller factors the full matrix."""
+        device = F.device
+        S0 = b["S"][:P, :P]
+        cap = P if self.choleskyEngine == "lowrank" else max(1, min(LOWRANK_RANK_CAP, P // LOWRANK_RANK_DIVISOR))
+        w = self._lowrank_buffers(P, device, cap)
+        D = b["diagS"] * float(self.diagonalShift)
+        if self._floor is not None:
+            D = D + self._floor
+        r, done, d0, left, dmin = self._pivoted_factor(S0, w, cap, extra=D.min())
+        rho = left / dmin if dmin > 0 else float("inf")
+        self.choleskyInfo = dict(engine="lowrank", rank=r, cap=cap, max_diag=d0, trace_left=left, min_shift=dmin, converged=done)
+        if not done or r < 1 or not (rho <= LOWRANK_SOLVE_RHO):
+            return False
+        self._lowrank_last_rank = r
+        LTr = w["LT"][:r, :P]
+        Ls = LTr / D                                                # L^T D^-1  (r x P)
+        G = Ls @ LTr.T
+        G.diagonal().add_(1.0)
+        Gc = torch.linalg.cholesky(G)
+
+        def minv(v):
+            t = torch.cholesky_solve((Ls @ v)[:, None], Gc)[:, 0]
+            return v / D - Ls.T @ t
+
+        u = minv(F)
+        Su = torch.empty(P, dtype=global_defs.tReal, device=device)
+        for _ in range(1 if rho <= 1e-7 else 2):
+            nat.call("vmcpde_gemv", nat.ptr(b["S"]), b["Ppad"], P, P, 0, nat.ptr(u), nat.ptr(Su), nat.stream())
+            u = u + minv(F - Su - D * u)
+        update.copy_(u)
+        b["info"].zero_()
+        return True
+
     # ---- tdvp.py:57-64 for a numerically rank-deficient S -----------------------------------------------------------
     def _eigh_lowrank(self, S):
         """(ev ascending, V) of the symmetric positive semi-definite S from a pivoted Cholesky factor (csrc/eig.hip), or None when the
-        numerical rank exceeds the cap (the caller then takes the dense path).  S = L L^T + R with trace(R) <= (P - r) 1e-16 max diag;
+        numerical rank exceeds the cap (the caller then takes the dense path).  S = L L^T + R with trace(R) <= (P - r) LOWRANK_TOL max diag;
         L = Q1 R1 by Householder reflectors, Q = [Q1 | Q2] = I - Y T Y^T; Q1^T S Q1 = W diag(w) W^T; ev = sort([w, 0 ... 0]),
         V = [Q1 W | Q2] in the same order.  What is not in csrc/eig.hip is library GEMM / TRSM and the r x r decomposition."""
         P, device = S.shape[0], S.device
         # (forced engine: no cap -- the factorisation runs until its criterion is met)
         cap = P if self.spectralEngine == "lowrank" else max(1, min(LOWRANK_RANK_CAP, P // LOWRANK_RANK_DIVISOR))
-        key = ("lowrank", P, str(device))
-        w = self._buf_lr.get(key) if hasattr(self, "_buf_lr") else None
-        if w is None:
-            ldl = _round_up(P, 64)
-            w = dict(ldl=ldl,
-                     LT=torch.empty((cap, ldl), dtype=global_defs.tReal, device=device),
-                     YT=torch.empty((cap, ldl), dtype=global_defs.tReal, device=device),
-                     tau=torch.empty(cap, dtype=global_defs.tReal, device=device),
-                     hq=torch.empty(cap + 1, dtype=global_defs.tReal, device=device),
-                     piv=torch.zeros(cap, dtype=torch.int32, device=device),
-                     state=torch.zeros(2, dtype=torch.int32, device=device),
-                     ws=torch.zeros(nat.lib().vmcpde_pivoted_cholesky_workspace_bytes(P) // 8, dtype=global_defs.tReal, device=device),
-                     state_host=torch.zeros(2, dtype=torch.int32).pin_memory(),
-                     info_host=torch.zeros(2, dtype=global_defs.tReal).pin_memory())
-            self._buf_lr = {key: w}
+        w = self._lowrank_buffers(P, device, cap)
+        if w["YT"] is None or w["YT"].shape[0] < cap:
+            w["YT"] = torch.empty((w["LT"].shape[0], w["ldl"]), dtype=global_defs.tReal, device=device)
+            w["tau"] = torch.empty(w["LT"].shape[0], dtype=global_defs.tReal, device=device)
+            w["hq"] = torch.empty(w["LT"].shape[0] + 1, dtype=global_defs.tReal, device=device)
         ldl, LT, YT, tau = w["ldl"], w["LT"], w["YT"], w["tau"]
-        lds = S.stride(0)
-        step, done = 0, False
-        # the first chunk covers the previous call's rank (the spectrum moves slowly along a trajectory); the host reads `state` per chunk
-        chunk = min(cap, _round_up(self._lowrank_last_rank + 8, 16)) if self._lowrank_last_rank else min(cap, 128)
-        while step < cap:
-            n = min(chunk, cap - step)
-            nat.call("vmcpde_pivoted_cholesky", nat.ptr(S), lds, P, LOWRANK_TOL, step, n, cap, nat.ptr(LT), ldl, nat.ptr(w["piv"]),
-                     nat.ptr(w["state"]), nat.ptr(w["ws"]), w["ws"].numel() * 8, nat.stream())
-            w["state_host"].copy_(w["state"], non_blocking=True)
-            w["info_host"].copy_(w["ws"][:2], non_blocking=True)
-            torch.cuda.current_stream(device).synchronize()
-            step += n
-            chunk = 32
-            if int(w["state_host"][1]):
-                done = True
-                break
-        r = int(w["state_host"][0])
-        d0, left = float(w["info_host"][0]), float(w["info_host"][1])
-        done = done or r == P                                       # full rank: every row was a pivot, nothing is left
+        r, done, d0, left, _ = self._pivoted_factor(S, w, cap)
         self.spectralInfo = dict(engine="lowrank", rank=r, cap=cap, max_diag=d0, trace_left=left, converged=done)
         if not done or r < 1 or not (left <= LOWRANK_TRACE_BOUND * d0):
             return None
@@ -595,7 +662,22 @@ class TDVP:
         device = F.device
         update = torch.empty(P, dtype=global_defs.tReal, device=device)
         with torch.cuda.device(device):
+            lowrank_done = False
             if self._solver() == "cholesky":
+                try_lr = self.choleskyEngine == "lowrank" or (self.choleskyEngine == "auto" and P >= LOWRANK_CHOL_MIN_P and self._chol_backoff == 0)
+                if self.choleskyEngine == "auto" and self._chol_backoff > 0:
+                    self._chol_backoff -= 1
+                self.choleskyInfo = dict(engine="dense")
+                if try_lr:
+                    lowrank_done = self._solve_lowrank(b, F, P, update)
+                    if not lowrank_done:
+                        self.choleskyInfo = dict(self.choleskyInfo, engine="dense", tried="lowrank")
+                        if self.choleskyEngine == "auto":
+                            self._chol_backoff = LOWRANK_RETRY_AFTER
+            if lowrank_done:
+                self.ev = self.V = self.VtF = None
+                self.cholInfo = b["info"]
+            elif self._solver() == "cholesky":
                 A, Ppad = b["A"], b["Ppad"]
                 bordered = P < Ppad          # a spare padded row: factor [[A, F], [F^T, beta]] -> its last row is y = L^-1 F
                 Pf = P + 1 if bordered else P
