@@ -266,8 +266,9 @@ int vmcpde_pivoted_cholesky(const double* S, int64_t lds, int32_t P, double tol_
                             int32_t max_rank, double* LT, int64_t ldl, int32_t* piv, int32_t* state, void* workspace,
                             int64_t workspace_bytes, void* stream);
 /* The same factorisation with up to 32 pivots per pair of launches (any pivot order gives S = L L^T + R with R >= 0; candidates are
- * the largest remaining diagonal entry of up to 32 different 64-row blocks, with pivoting inside the 32 x 32 block and candidates that
- * fall to the tolerance dropped).  Same buffers and `state` as above (its own workspace size); `restart` != 0 starts a new
+ * the largest of the two largest remaining diagonal entries of every 64-row block, none below 1/100 of the largest -- a pivot p turns
+ * round-off n into n / sqrt(p) --, with pivoting inside the 32 x 32 block; candidates that fall below that bound there stay open).
+ * P <= 32768.  Same buffers and `state` as above (its own workspace size); `restart` != 0 starts a new
  * factorisation, then n_blocks block steps run, then one settling launch updates state[1] and the trace of the remainder.
  * state[0] == max_rank with state[1] == 0: the rank cap was reached before the criterion. */
 int64_t vmcpde_pivoted_cholesky_blocked_workspace_bytes(int32_t P);

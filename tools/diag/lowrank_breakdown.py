@@ -27,9 +27,10 @@ print(f"whole engine {ms:.2f} ms", flush=True)
 w = tdvp._buf_lr[("lowrank", P, str(S.device))]
 r = tdvp.spectralInfo["rank"]; cap = w["LT"].shape[0]; ldl = w["ldl"]
 def pc():
-    nat.call("vmcpde_pivoted_cholesky", nat.ptr(S), S.stride(0), P, T.LOWRANK_TOL, 0, min(cap, r + 8), cap, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]),
+    nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S), S.stride(0), P, T.LOWRANK_TOL, 1, (r + 12) // 13 + 2, cap, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]),
              nat.ptr(w["state"]), nat.ptr(w["ws"]), w["ws"].numel() * 8, nat.stream())
-print(f"pivoted Cholesky, {min(cap, r + 8)} launches: {timed(pc)[0]:.2f} ms", flush=True)
+ms_pc = timed(pc)[0]
+print(f"blocked pivoted Cholesky, {(r + 12) // 13 + 2} block steps (2 launches each): {ms_pc:.2f} ms -> rank {int(w['state'][0])} done {int(w['state'][1])}", flush=True)
 def hq():
     pc()
     nat.call("vmcpde_householder_rows", nat.ptr(w["LT"]), ldl, P, r, nat.ptr(w["YT"]), nat.ptr(w["tau"]), nat.ptr(w["hq"]), nat.stream())

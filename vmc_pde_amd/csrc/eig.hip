@@ -48,23 +48,38 @@ __device__ __forceinline__ double wave_sum(double v) {
 // d = diag(S); per-workgroup candidates (largest entry, its row, sum of the positive entries) into candidate buffer 0
 __global__ __launch_bounds__(PC_ROWS) void pivchol_init_kernel(const double* __restrict__ S, int64_t lds, int P, double* __restrict__ d,
                                                                double* __restrict__ cand_val, int* __restrict__ cand_idx,
-                                                               double* __restrict__ cand_sum, int32_t* __restrict__ state) {
+                                                               double* __restrict__ cand_sum, int32_t* __restrict__ state, int two) {
   const int i = (int)blockIdx.x * PC_ROWS + (int)threadIdx.x;
-  double v = NEG_INF;
+  double mine = NEG_INF;
   if (i < P) {
-    v = S[(int64_t)i * lds + i];
-    d[i] = v;
+    mine = S[(int64_t)i * lds + i];
+    d[i] = mine;
   }
+  double v = mine;
   int idx = i;
   double pos = (v > 0.0) ? v : 0.0;
   wave_argmax(v, idx);
   pos = wave_sum(pos);
-  if (threadIdx.x == 0) {
-    cand_val[blockIdx.x] = v;
-    cand_idx[blockIdx.x] = idx;
-    cand_sum[blockIdx.x] = pos;
-    if (blockIdx.x == 0) { state[0] = 0; state[1] = 0; }
+  if (!two) {
+    if (threadIdx.x == 0) {
+      cand_val[blockIdx.x] = v;
+      cand_idx[blockIdx.x] = idx;
+      cand_sum[blockIdx.x] = pos;
+    }
+  } else {                       // the blocked factorisation keeps the two largest entries of every 64-row block
+    double v2 = (i == idx) ? NEG_INF : mine;
+    int idx2 = i;
+    wave_argmax(v2, idx2);
+    if (threadIdx.x == 0) {
+      cand_val[2 * blockIdx.x] = v;
+      cand_idx[2 * blockIdx.x] = idx;
+      cand_sum[2 * blockIdx.x] = pos;
+      cand_val[2 * blockIdx.x + 1] = v2;
+      cand_idx[2 * blockIdx.x + 1] = idx2;
+      cand_sum[2 * blockIdx.x + 1] = 0.0;
+    }
   }
+  if (threadIdx.x == 0 && blockIdx.x == 0) { state[0] = 0; state[1] = 0; }
 }
 
 // One step of the pivoted factorisation.  state[0] = columns completed, state[1] = 1 once the stopping criterion has been met (every
@@ -159,16 +174,32 @@ __global__ void pivchol_trace_kernel(const double* __restrict__ cand_sum, int nw
 
 // ---- the same factorisation, PB pivots per pair of launches ------------------------------------------------------------------
 // A pivot order need not be the greedy one: ANY order gives S = L L^T + R with R >= 0, and stopping when no remaining diagonal entry
-// exceeds tol * max diag bounds trace(R) as before.  A block step takes the largest remaining entry of up to PB different 64-row
-// blocks as candidates C (one wave picks them from the per-block candidates the previous step left), forms the panel
+// exceeds tol * max diag bounds trace(R) as before.  A block step takes up to PB candidates C from the two largest remaining entries
+// of every 64-row block (one wave picks the largest of those the previous step left), forms the panel
 // A = S[:, C] - L L[C, :]^T (launch 1), factors the PB x PB block A[C, C] with pivoting INSIDE the block -- candidates whose remaining
 // entry falls to <= tol * max diag once their predecessors are eliminated are dropped --, and appends the accepted columns
-// L[:, new] = A[:, C_acc] L_bb^-T row by row, downdates d and renews the candidates (launch 2).  238 columns at P = 4213 take 9 block
-// steps = 18 launches instead of 246.
+// L[:, new] = A[:, C_acc] L_bb^-T row by row, downdates d and renews the candidates (launch 2).
+// d = sqrt(p) and 1 / d for a positive normal p: v_rsq_f64 seed, two coupled Goldschmidt steps, one residual correction (the library's
+// sqrt() and a division carry range handling that this dependent chain does not need)
+__device__ __forceinline__ void sqrt_and_inverse(double p, double& d, double& inv_d) {
+  const double y = __builtin_amdgcn_rsq(p);
+  double g = p * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double e = fma(-g, g, p);
+  g = fma(e, h, g);
+  d = g;
+  inv_d = h + h;
+}
+
 constexpr int PB = 32;                               // candidates per block step
-constexpr int PBK = 128;                             // earlier columns staged per tile of the panel product
+constexpr int PBK = 64;                              // earlier columns staged per tile of the panel product
 constexpr int PF_ROWS = 256;                         // rows per workgroup of the second launch (one per thread)
-constexpr int PB_MAX_BLOCKS = 1024;                  // 64-row blocks a matrix may have (P <= 65 536)
+constexpr int PB_MAX_BLOCKS = 1024;                  // candidates a step chooses from: two per 64-row block (P <= 32 768)
 
 // Pivots of one block step must not fall far below the largest remaining diagonal entry: a pivot p turns the round-off n of a panel
 // entry into an error n / sqrt(p) of the new column, i.e. 2 sqrt(d_i / p) n in the remaining diagonal of row i.  Greedy pivoting has
@@ -193,40 +224,62 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
   __shared__ double cv[PB_MAX_BLOCKS];
   __shared__ int ci[PB_MAX_BLOCKS];
   __shared__ double Wt[PBK][PB];
+  __shared__ double red[3][PC_ROWS][17];
   __shared__ int s_C[PB];
   __shared__ int s_bsel, s_k, s_done;
   __shared__ double s_sum, s_top;
   const int t = threadIdx.x, lane = t & 63;
   const int slice = __builtin_amdgcn_readfirstlane(t >> 6);
-  for (int q = t; q < nblk; q += PC_THREADS) { cv[q] = cand_val[q]; ci[q] = cand_idx[q]; }
+  const int ncand = 2 * nblk;
+  for (int q = t; q < ncand; q += PC_THREADS) { cv[q] = cand_val[q]; ci[q] = cand_idx[q]; }
   __syncthreads();
   if (slice == 0) {
     const int k = state[0];
     double sum = 0.0;
-    for (int q = lane; q < nblk; q += 64) sum += cand_sum[q];
+    for (int q = lane; q < ncand; q += 64) sum += cand_sum[q];
     sum = wave_sum(sum);
-    double d0 = (k == 0) ? 0.0 : work->d0;
-    const int room = max_rank - k;
-    int bsel = 0;
-    double top = 0.0;
-    for (int m = 0; m < PB; ++m) {                  // the PB largest per-block candidates, largest first
-      double v = NEG_INF;
-      int idx = 0x7fffffff, where = -1;
-      for (int q = lane; q < nblk; q += 64) {
-        const double ov = cv[q];
-        const int oi = ci[q];
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; where = q; }
-      }
-      double bv = v;
-      int bi = idx;
-      wave_argmax(bv, bi);
-      if (m == 0) { top = bv; if (k == 0) d0 = bv; }
-      if (!(bv > tol_rel * d0) || !(bv >= PB_THETA * top) || m >= room) break;
-      if (bi == idx && where >= 0 && bv == v) cv[where] = NEG_INF;     // (the row index is unique: exactly one lane owns it)
-      if (lane == 0) s_C[m] = bi;
-      bsel = m + 1;
-      __builtin_amdgcn_wave_barrier();
+    // the candidates of the step: every entry >= max(tol d0, PB_THETA top), at most min(PB, room) of them -- if more qualify the bound
+    // is raised in steps of 10^(1/8) until they fit.  Their order does not matter (the block pivots inside), so they are placed by
+    // ballot and prefix count: one wave reduction for `top` instead of PB dependent arg-max rounds (19 us of ds_bpermute at PB = 32).
+    double top = NEG_INF;
+    int topi = 0x7fffffff;
+    for (int q = lane; q < ncand; q += 64) {
+      const double ov = cv[q];
+      const int oi = ci[q];
+      if (ov > top || (ov == top && oi < topi)) { top = ov; topi = oi; }
     }
+    wave_argmax(top, topi);
+    const double d0 = (k == 0) ? top : work->d0;
+    const int room = (max_rank - k < PB) ? (max_rank - k) : PB;
+    int bsel = 0;
+    if (top > tol_rel * d0 && room > 0) {
+      double thr = fmax(tol_rel * d0, PB_THETA * top);
+      const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      for (int tries = 0; tries < 20; ++tries) {
+        int count = 0;
+        for (int q0 = 0; q0 < ncand; q0 += 64) {
+          const int q = q0 + lane;
+          count += __popcll(__ballot(q < ncand && cv[q] >= thr && cv[q] > tol_rel * d0));
+        }
+        if (count <= room) break;
+        thr *= 1.333521432163324;                    // 10^(1/8)
+      }
+      int base = 0;
+      for (int q0 = 0; q0 < ncand; q0 += 64) {
+        const int q = q0 + lane;
+        const bool take = q < ncand && cv[q] >= thr && cv[q] > tol_rel * d0;
+        const unsigned long long mask = __ballot(take);
+        const int pos = base + __popcll(mask & below);
+        if (take && pos < room) s_C[pos] = ci[q];
+        base += __popcll(mask);
+      }
+      bsel = (base < room) ? base : room;
+      if (bsel == 0) {                               // (ties that never fit under the rising bound: the largest entry alone)
+        if (lane == 0) s_C[0] = topi;
+        bsel = 1;
+      }
+    }
+    if (!(top > NEG_INF)) top = 0.0;
     if (lane == 0) { s_bsel = bsel; s_k = k; s_done = state[1]; s_sum = sum; s_top = top; }
   }
   __syncthreads();
@@ -243,9 +296,14 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
   }
   if (bsel == 0) return;
   // ---- panel: A[i][m] = S[C_m][i] - sum_{j < k} L[i][j] L[C_m][j]; wave s forms the columns 2 s, 2 s + 1 for the 64 rows of the workgroup
+  // wave s = (quarter jq = s >> 2 of the earlier columns, group cg = s & 3 of eight panel columns): every row of L is loaded by four
+  // waves instead of sixteen and a thread's loop is k / 4 long with eight independent sums (2 columns x all of k per wave took 8 us
+  // of dependent loads at k = 150); the four quarters meet in the LDS, sixteen panel columns at a time
   const int i = (int)blockIdx.x * PC_ROWS + lane;                      // (< ldl)
-  const int m0 = 2 * slice, m1 = m0 + 1;
-  double acc0 = 0.0, acc1 = 0.0;
+  const int jq = slice >> 2, cg = slice & 3;
+  double acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.0;
   for (int j0 = 0; j0 < k; j0 += PBK) {
     const int nj = (k - j0 < PBK) ? (k - j0) : PBK;
     __syncthreads();
@@ -255,15 +313,30 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
     }
     __syncthreads();
 #pragma unroll 4
-    for (int jj = 0; jj < nj; ++jj) {
+    for (int jj = jq; jj < nj; jj += 4) {
       const double v = LT[(int64_t)(j0 + jj) * ldl + i];
-      acc0 = fma(v, Wt[jj][m0], acc0);
-      acc1 = fma(v, Wt[jj][m1], acc1);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = fma(v, Wt[jj][8 * cg + c], acc[c]);
     }
   }
   const bool inside = i < P;
-  AP[(int64_t)m0 * ldl + i] = (inside && m0 < bsel) ? S[(int64_t)s_C[m0] * lds + i] - acc0 : 0.0;
-  AP[(int64_t)m1 * ldl + i] = (inside && m1 < bsel) ? S[(int64_t)s_C[m1] * lds + i] - acc1 : 0.0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();                                                   // (red is free: first use, or the previous half has been read)
+    if ((cg >> 1) == h && jq > 0) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) red[jq - 1][lane][8 * (cg & 1) + c] = acc[c];
+    }
+    __syncthreads();
+    if ((cg >> 1) == h && jq == 0) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int m = 8 * cg + c;
+        const double sum = acc[c] + red[0][lane][8 * (cg & 1) + c] + red[1][lane][8 * (cg & 1) + c] + red[2][lane][8 * (cg & 1) + c];
+        AP[(int64_t)m * ldl + i] = (inside && m < bsel) ? S[(int64_t)s_C[m] * lds + i] - sum : 0.0;
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double tol_rel, double* __restrict__ LT, int64_t ldl, double* __restrict__ d,
@@ -275,6 +348,8 @@ __global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double to
   __shared__ double Lb[PB][PB + 1];        // block factor by candidate: Lb[m][n], n = elimination step
   __shared__ double Abb[PB][PB + 1];       // the block itself: Abb[m][c] = A[C_m][c] (column c of the panel at the row of candidate m)
   __shared__ double s_left[PB];            // what is left of every candidate's diagonal entry after the block
+  __shared__ double sdiag[PB];             // the open candidates' remaining entries during the block's elimination
+  __shared__ double s_rinv[PB];            // 1 / l_nn of the accepted pivots
   __shared__ int s_perm[PB], s_C[PB], s_acc[PB];
   __shared__ int s_bacc, s_k, s_bsel, s_done;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -297,26 +372,39 @@ __global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double to
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     double diag = mine ? Abb[m][m] : NEG_INF;
-    bool used = !mine;
+    bool used = !mine, going = true;
     int bacc = 0;
 #pragma unroll
     for (int n = 0; n < PB; ++n) {
-      double v = used ? NEG_INF : diag;
-      int p = m;
-      wave_argmax(v, p);
-      if (!(v > thresh)) break;              // (wave-uniform)
-      const double lpp = sqrt(v);
+      // arg max of the open candidates' remaining entries: every lane reads all PB of them (a ds_bpermute reduction costs ~1100
+      // cycles per step; ties go to the lower candidate)
+      if (m < PB) sdiag[m] = used ? NEG_INF : diag;
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      double a[PB];
+#pragma unroll
+      for (int c = 0; c < PB; ++c) a[c] = sdiag[c];
+#pragma unroll
+      for (int wd = PB / 2; wd >= 1; wd >>= 1)
+#pragma unroll
+        for (int c = 0; c < wd; ++c) a[c] = fmax(a[c], a[c + wd]);
+      const double v = a[0];
+      going = going && (v > thresh);         // (wave-uniform)
+      if (!going) continue;
+      const int p = __ffsll((unsigned long long)__ballot(m < PB && !used && diag == v)) - 1;     // the lowest candidate that holds the maximum
+      double lpp, rpp;
+      sqrt_and_inverse(v, lpp, rpp);
       // l[m][n] = (A[m][p] - sum_{q < n} L[m][q] L[p][q]) / l_pp ; row p of the factor comes from the lane that holds it, through LDS
       double sum = 0.0;
 #pragma unroll
       for (int q = 0; q < PB; ++q)
         if (q < n) sum = fma(Lm[q], Lb[p][q], sum);
       double l = 0.0;
-      if (mine && !used) l = (m == p) ? lpp : (Abb[m][p] - sum) / lpp;
+      if (mine && !used) l = (m == p) ? lpp : (Abb[m][p] - sum) * rpp;
       Lm[n] = l;
       if (mine) Lb[m][n] = l;
       if (mine && !used && m != p) diag -= l * l;
-      if (m == p) { used = true; s_perm[n] = m; s_acc[m] = 1; }
+      if (m == p) { used = true; s_perm[n] = m; s_acc[m] = 1; s_rinv[n] = rpp; }
       bacc = n + 1;
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the row just written is read by every lane in the next step
@@ -349,7 +437,7 @@ __global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double to
 #pragma unroll
       for (int q = 0; q < PB; ++q)
         if (q < n) v = fma(-x[q], LP[n][q], v);
-      v = (open && n <= own) ? v / LP[n][n] : 0.0;        // (a pivot row is finished: structural zeros in the later columns)
+      v = (open && n <= own) ? v * s_rinv[n] : 0.0;       // (a pivot row is finished: structural zeros in the later columns)
       x[n] = v;
       ss = fma(v, v, ss);
       if (i < (int)ldl) LT[(int64_t)(k + n) * ldl + i] = v;
@@ -361,15 +449,22 @@ __global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double to
       if (s_C[m] == i) nd = s_acc[m] ? NEG_INF : s_left[m];     // a pivot is finished; a dropped candidate keeps what the block left of it
   }
   if (inside) d[i] = nd;
+  double v1 = nd;
   int idx = i;
   double pos = (nd > 0.0) ? nd : 0.0;
-  wave_argmax(nd, idx);
+  wave_argmax(v1, idx);
   pos = wave_sum(pos);
+  double v2 = (i == idx) ? NEG_INF : nd;      // the block's second largest entry: two candidates per 64 rows
+  int idx2 = i;
+  wave_argmax(v2, idx2);
   const int blk = (int)blockIdx.x * (PF_ROWS / 64) + wave;
   if (lane == 0 && blk < nblk) {
-    cand_val[blk] = nd;
-    cand_idx[blk] = idx;
-    cand_sum[blk] = pos;
+    cand_val[2 * blk] = v1;
+    cand_idx[2 * blk] = idx;
+    cand_sum[2 * blk] = pos;
+    cand_val[2 * blk + 1] = v2;
+    cand_idx[2 * blk + 1] = idx2;
+    cand_sum[2 * blk + 1] = 0.0;
   }
   if (blockIdx.x == 0 && t == 0) {
     state[0] = k + bacc;
@@ -478,7 +573,7 @@ extern "C" int vmcpde_pivoted_cholesky(const double* S, int64_t lds, int32_t P, 
   int* cand_idx = reinterpret_cast<int*>(cand_sum + 2 * nwg);
   hipStream_t st = (hipStream_t)stream;
   if (first_step == 0)
-    hipLaunchKernelGGL(pivchol_init_kernel, dim3(nwg), dim3(PC_ROWS), 0, st, S, lds, P, d, cand_val, cand_idx, cand_sum, state);
+    hipLaunchKernelGGL(pivchol_init_kernel, dim3(nwg), dim3(PC_ROWS), 0, st, S, lds, P, d, cand_val, cand_idx, cand_sum, state, 0);
   for (int s = first_step; s < first_step + n_steps; ++s)
     hipLaunchKernelGGL(pivchol_step_kernel, dim3(nwg), dim3(PC_THREADS), 0, st, S, lds, P, s, tol_rel, LT, ldl, d, cand_val, cand_idx, cand_sum, nwg,
                        piv, state, work);
@@ -508,7 +603,7 @@ extern "C" int vmcpde_pivoted_cholesky_blocked(const double* S, int64_t lds, int
   VMC_REQUIRE(S && LT && piv && state && workspace, "vmcpde_pivoted_cholesky_blocked: null argument");
   VMC_REQUIRE(P >= 1 && lds >= P, "vmcpde_pivoted_cholesky_blocked: bad shape");
   const int nblk = (P + PC_ROWS - 1) / PC_ROWS;
-  VMC_REQUIRE(nblk <= PB_MAX_BLOCKS, "vmcpde_pivoted_cholesky_blocked: P <= 65536");
+  VMC_REQUIRE(2 * nblk <= PB_MAX_BLOCKS, "vmcpde_pivoted_cholesky_blocked: P <= 32768");
   VMC_REQUIRE(ldl == (int64_t)nblk * PC_ROWS, "vmcpde_pivoted_cholesky_blocked: ldl must be P rounded up to a multiple of 64");
   VMC_REQUIRE(n_blocks >= 0 && max_rank >= 1 && max_rank <= P, "vmcpde_pivoted_cholesky_blocked: bad step count / rank cap");
   VMC_REQUIRE(tol_rel >= 0.0, "vmcpde_pivoted_cholesky_blocked: negative tolerance");
@@ -522,7 +617,7 @@ extern "C" int vmcpde_pivoted_cholesky_blocked(const double* S, int64_t lds, int
   PivDesc* desc = reinterpret_cast<PivDesc*>(w + pivchol_ws_doubles(P));
   double* AP = w + pivchol_ws_doubles(P) + 64;
   hipStream_t st = (hipStream_t)stream;
-  if (restart) hipLaunchKernelGGL(pivchol_init_kernel, dim3(nblk), dim3(PC_ROWS), 0, st, S, lds, P, d, cand_val, cand_idx, cand_sum, state);
+  if (restart) hipLaunchKernelGGL(pivchol_init_kernel, dim3(nblk), dim3(PC_ROWS), 0, st, S, lds, P, d, cand_val, cand_idx, cand_sum, state, 1);
   const int nfac = (P + PF_ROWS - 1) / PF_ROWS;
   for (int b = 0; b < n_blocks; ++b) {
     hipLaunchKernelGGL(pivblk_panel_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, S, lds, P, tol_rel, max_rank, LT, ldl, cand_val, cand_idx, cand_sum,
