@@ -59,7 +59,8 @@ LOWRANK_TOL = 1e-14         # pivoting stops when the largest remaining diagonal
                             #   stay an order of magnitude above 1e-15 max diag (with 1e-16 the last columns added 4e-13 max diag to L L^T on
                             #   a 700 x 700 test matrix; LAPACK's dpstrf stops at P eps max diag = 9e-13 here).  max diag <= lambda_max, so
                             #   everything dropped lies below the reference's hard cut-off at 1e-14 lambda_max (tdvp.py:82)
-LOWRANK_TRACE_BOUND = 1e-12 # accept only if the trace of the remainder (an upper bound of its norm) is below this x max diag(S)
+LOWRANK_TRACE_BOUND = 1e-11 # accept only if the trace of the remainder (an upper bound of its norm; <= (P - r) LOWRANK_TOL by construction: 1.1e-12
+                            #   at P = 16 181) is below this x max diag(S)
 LOWRANK_CHOL_MIN_P = 8192   # choleskyEngine="auto": the low-rank solve from this many parameters on (P = 4213: 3.3 ms against 2.1 ms for the blocked
                             #   factorisation of the full matrix -- 20 block steps of 75 us and ~40 library launches; P = 16 181: 7.4 against 38 ms)
 LOWRANK_SOLVE_RHO = 1e-4    # low-rank Cholesky solve: largest trace(R) / min D accepted (the contraction factor of its iterative refinement)
