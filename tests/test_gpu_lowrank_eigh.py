@@ -266,6 +266,15 @@ def test_engine_choice_and_fallbacks(headline_net):
     assert float(torch.linalg.norm(S @ tf.V - tf.V * tf.ev)) < 1e-12 * float(ev_ref[-1])
     with pytest.raises(ValueError, match="spectralEngine"):
         V.TDVP(spectralEngine="jacobi")
+    # a NaN in S is not "a smaller pivot": the engine declines and the dense path reports it as before
+    Sn = S.clone()
+    Sn[17, 17] = float("nan")
+    assert V.TDVP(spectralEngine="lowrank")._eigh_lowrank(Sn) is None
+    low = (A[:, :40] @ A[:, :40].T / 40)[:1200, :1200].contiguous()             # rank 40: the engine applies ...
+    tl = V.TDVP()
+    assert tl._eigh_lowrank(low) is not None and tl.spectralInfo["rank"] == 40
+    low[5, 5] = float("inf")                                                      # ... and declines once an entry is not finite
+    assert tl._eigh_lowrank(low) is None
 
 
 def test_lowrank_cholesky_solve_matches_the_dense_factorisation(headline_net, monkeypatch):

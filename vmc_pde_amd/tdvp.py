@@ -507,8 +507,8 @@ class TDVP:
         trajectory); the host reads `state` after every call (`extra`: a device scalar copied along)."""
         P, device = S.shape[0], S.device
         done, first = False, True
-        nblocks = (self._lowrank_last_rank + 31) // 32 + 2 if self._lowrank_last_rank else 10
-        while True:
+        nblocks = (self._lowrank_last_rank + 12) // 13 + 2 if self._lowrank_last_rank else 12      # (a step accepts ~13 columns)
+        for _ in range(cap // 3 + 8):           # (every step makes progress -- a column, or candidates lowered to what is left of them)
             nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S), S.stride(0), P, LOWRANK_TOL, 1 if first else 0, nblocks, cap, nat.ptr(w["LT"]),
                      w["ldl"], nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), w["ws"].numel() * 8, nat.stream())
             w["state_host"].copy_(w["state"], non_blocking=True)
@@ -579,9 +579,11 @@ class TDVP:
             w["tau"] = torch.empty(w["LT"].shape[0], dtype=global_defs.tReal, device=device)
             w["hq"] = torch.empty(w["LT"].shape[0] + 1, dtype=global_defs.tReal, device=device)
         ldl, LT, YT, tau = w["ldl"], w["LT"], w["YT"], w["tau"]
-        r, done, d0, left, _ = self._pivoted_factor(S, w, cap)
+        # (a NaN on the diagonal compares as "smaller" in the pivot search and would simply be left out: the trace rides along with the
+        # first host read, and a non-finite S goes to the dense path, which reports it as before)
+        r, done, d0, left, tr = self._pivoted_factor(S, w, cap, extra=torch.diagonal(S).sum())
         self.spectralInfo = dict(engine="lowrank", rank=r, cap=cap, max_diag=d0, trace_left=left, converged=done)
-        if not done or r < 1 or not (left <= LOWRANK_TRACE_BOUND * d0):
+        if not done or r < 1 or not (left <= LOWRANK_TRACE_BOUND * d0) or not np.isfinite(tr):
             return None
         self._lowrank_last_rank = r
         nat.call("vmcpde_householder_rows", nat.ptr(LT), ldl, P, r, nat.ptr(YT), nat.ptr(tau), nat.ptr(w["hq"]), nat.stream())
