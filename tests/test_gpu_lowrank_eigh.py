@@ -287,19 +287,17 @@ def test_lowrank_cholesky_solve_matches_the_dense_factorisation(headline_net, mo
     kw = dict(nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
     out = {}
     import vmc_pde_amd.tdvp as T
-    for engine in ("dense", "lowrank", "auto", "auto-large"):
-        tp = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine=engine.split("-")[0])
-        if engine == "auto-large":                # "auto" takes the low-rank route from 8192 parameters on: here as if 4213 were that large
-            monkeypatch.setattr(T, "LOWRANK_CHOL_MIN_P", 1024)
+    assert T.LOWRANK_CHOL_MIN_P <= 4213            # "auto" takes the low-rank route at the headline size
+    for engine in ("dense", "lowrank", "auto"):
+        tp = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine=engine)
         u, _ = tp(th.cuda(), 0.0, vs, ep, **kw)
         tp.check()
         out[engine] = (tp.S0.clone(), tp.F0.clone(), u.clone(), float(tp.solverResidual), float(tp.tdvp_error), dict(tp.choleskyInfo), tp)
     S, F, u_d, res_d, err_d, info_d, tp_d = out["dense"]
-    assert info_d == dict(engine="dense") and out["auto"][5] == dict(engine="dense")          # P = 4213 < LOWRANK_CHOL_MIN_P
-    assert torch.equal(out["auto"][2], u_d)
+    assert info_d == dict(engine="dense")
     P = S.shape[0]
     D = 1e-4 * torch.diagonal(S) + 1e-6 * torch.diagonal(S).max()
-    for engine in ("lowrank", "auto-large"):
+    for engine in ("lowrank", "auto"):
         S2, F2, u, res, err, info, _ = out[engine]
         assert torch.equal(S2, S) and torch.equal(F2, F)
         assert info["engine"] == "lowrank" and info["converged"] and 1 <= info["rank"] < P // 6, info
@@ -313,8 +311,39 @@ def test_lowrank_cholesky_solve_matches_the_dense_factorisation(headline_net, mo
         assert float(torch.linalg.norm(S @ u + D * u - F)) < 1e-12 * nF and float(torch.linalg.norm(S @ u_d + D * u_d - F)) < 1e-11 * nF
         assert float(torch.linalg.norm(du) / torch.linalg.norm(u_d)) < 1e-4
         assert res < 1e-12 and res_d < 1e-12 and abs(err - err_d) < 1e-10
+    # the calls after the first run in static mode (no host read): same system, same solution; the plan is checked one call later
+    tp = out["lowrank"][6]
+    assert tp.choleskyInfo["mode"] == "planning" and tp._chol_static is not None and tp._chol_static["rmax"] % 128 == 0
+    for rep in range(3):
+        u, _ = tp(th.cuda(), 0.0, vs, ep, **kw)
+        tp.check()
+        assert tp.choleskyInfo["mode"] == "static" and tp.choleskyInfo["rmax"] == tp._chol_static["rmax"], tp.choleskyInfo
+        du = u - u_d
+        assert float(torch.linalg.norm(S @ du + D * du)) < 1e-11 * nF and float(tp.solverResidual) < 1e-12
+        if rep:
+            assert int(tp._chol_static["host"][1]) == 1 and int(tp._chol_static["host"][0]) == tp.choleskyInfo["planned_rank"]
+    # the plan is checked one call later: a rank within 32 columns of the pad makes the next call plan anew
+    tp._chol_static["host"][0] = tp._chol_static["rmax"] - 20
+    u, _ = tp(th.cuda(), 0.0, vs, ep, **kw)
+    tp.check()
+    assert tp.choleskyInfo["mode"] == "planning" and float(tp.solverResidual) < 1e-12
+    # a plan far too small for the matrix (made so by hand: a quarter of the rank, four block steps): the call still returns, its
+    # measured residual fails the guard LOUDLY at the next check, the plan is dropped and the repeated call plans anew
+    u, _ = tp(th.cuda(), 0.0, vs, ep, **kw)
+    assert tp.choleskyInfo["mode"] == "static"
+    tp.check()
+    tp._chol_static["rmax"], tp._chol_static["nsteps"] = 128, 4
+    tp._chol_static["host"][0] = 50                      # (as if the previous call had fitted this plan)
+    u, _ = tp(th.cuda(), 0.0, vs, ep, **kw)
+    assert tp.choleskyInfo["mode"] == "static" and tp.choleskyInfo["rmax"] == 128
+    with pytest.raises(FloatingPointError, match="outgrew the static plan"):
+        tp.check()
+    assert tp._chol_static is None
+    u, _ = tp(th.cuda(), 0.0, vs, ep, **kw)
+    tp.check()
+    assert tp.choleskyInfo["mode"] == "planning" and tp._chol_static["rmax"] >= 256 and float(tp.solverResidual) < 1e-12
     # a floor far below what the factorisation leaves of S: refinement would not contract, the full matrix is factored instead
-    tq = V.TDVP(diagonalShift=1e-6, svdTol=1e-12, solver="cholesky")        # ("auto" with the lowered size threshold still in place)
+    tq = V.TDVP(diagonalShift=1e-6, svdTol=1e-12, solver="cholesky")
     uq, _ = tq(th.cuda(), 0.0, vs, ep, **kw)
     assert tq.choleskyInfo["engine"] == "dense" and tq.choleskyInfo["tried"] == "lowrank" and tq._chol_backoff > 0
     assert tq.choleskyInfo["trace_left"] / tq.choleskyInfo["min_shift"] > 1e-4
@@ -322,3 +351,7 @@ def test_lowrank_cholesky_solve_matches_the_dense_factorisation(headline_net, mo
     assert tq.choleskyInfo == dict(engine="dense")                      # not retried right away
     with pytest.raises(ValueError, match="choleskyEngine"):
         V.TDVP(choleskyEngine="qr")
+    monkeypatch.setattr(T, "LOWRANK_CHOL_MIN_P", 8192)                     # below the size threshold "auto" factors the full matrix
+    ts = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky")
+    us, _ = ts(th.cuda(), 0.0, vs, ep, **kw)
+    assert ts.choleskyInfo == dict(engine="dense") and torch.equal(us, u_d)

@@ -376,6 +376,7 @@ __global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double to
     int bacc = 0;
 #pragma unroll
     for (int n = 0; n < PB; ++n) {
+      if (!going || n >= bsel) continue;     // (wave-uniform: nothing left to eliminate)
       // arg max of the open candidates' remaining entries: every lane reads all PB of them (a ds_bpermute reduction costs ~1100
       // cycles per step; ties go to the lower candidate)
       if (m < PB) sdiag[m] = used ? NEG_INF : diag;
@@ -430,10 +431,12 @@ __global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double to
   double x[PB];
   double ss = 0.0;
 #pragma unroll
+  for (int n = 0; n < PB; ++n)               // (all of the row's panel entries in flight at once, not one round trip per column)
+    x[n] = (n < bacc && open) ? AP[(int64_t)s_perm[n] * ldl + i] : 0.0;
+#pragma unroll
   for (int n = 0; n < PB; ++n) {
-    x[n] = 0.0;
     if (n < bacc) {
-      double v = open ? AP[(int64_t)s_perm[n] * ldl + i] : 0.0;
+      double v = x[n];
 #pragma unroll
       for (int q = 0; q < PB; ++q)
         if (q < n) v = fma(-x[q], LP[n][q], v);

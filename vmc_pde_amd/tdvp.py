@@ -61,8 +61,9 @@ LOWRANK_TOL = 1e-14         # pivoting stops when the largest remaining diagonal
                             #   everything dropped lies below the reference's hard cut-off at 1e-14 lambda_max (tdvp.py:82)
 LOWRANK_TRACE_BOUND = 1e-11 # accept only if the trace of the remainder (an upper bound of its norm; <= (P - r) LOWRANK_TOL by construction: 1.1e-12
                             #   at P = 16 181) is below this x max diag(S)
-LOWRANK_CHOL_MIN_P = 8192   # choleskyEngine="auto": the low-rank solve from this many parameters on (P = 4213: 3.3 ms against 2.1 ms for the blocked
-                            #   factorisation of the full matrix -- 20 block steps of 75 us and ~40 library launches; P = 16 181: 7.4 against 38 ms)
+LOWRANK_CHOL_MIN_P = 4096   # choleskyEngine="auto": the low-rank solve from this many parameters on.  P = 4213: 1.3 ms against 2.1 ms for the blocked
+                            #   factorisation of the full matrix (which scales as P^3: 0.8 ms at 3072) -- in the static mode, i.e. without a host
+                            #   read in the step; with one (planning mode) 2.5 ms.  P = 16 181: 7 against 38 ms
 LOWRANK_SOLVE_RHO = 1e-4    # low-rank Cholesky solve: largest trace(R) / min D accepted (the contraction factor of its iterative refinement)
 LOWRANK_RETRY_AFTER = 50    # "auto": calls on the dense path after one whose rank exceeded the cap, before the next attempt
 
@@ -129,6 +130,7 @@ class TDVP:
         if self.choleskyEngine not in ("auto", "dense", "lowrank"):
             raise ValueError(f"unknown choleskyEngine {self.choleskyEngine!r}")
         self._chol_backoff = 0
+        self._chol_static = None
         self.choleskyInfo = None
         self._lowrank_backoff = 0
         self._lowrank_last_rank = 0
@@ -475,6 +477,14 @@ class TDVP:
                 raise FloatingPointError(f"nan encountered in the TDVP update ({when})")
             return
         if not (resid <= self.residualBound):      # also catches NaN
+            if (self.choleskyInfo or {}).get("mode") == "static":
+                # the rank of S outgrew the plan of the low-rank solve within one call (it is re-planned 32 columns before the pad, and a
+                # factorisation that stops at the pad still refines to ~1e-8: this needs a jump of the rank by a large factor): the
+                # plan is dropped, so a caller that catches this and repeats the step gets a planning call
+                self._chol_static = None
+                raise FloatingPointError(f"low-rank Cholesky solve ({when}): solver residual {resid:.3e} > {self.residualBound:g} -- the "
+                                         f"numerical rank of S outgrew the static plan {self.choleskyInfo}; the next call plans anew "
+                                         f"(choleskyEngine='dense' avoids the low-rank route)")
             raise FloatingPointError(f"on-device Cholesky failed ({when}): solver residual {resid:.3e} > {self.residualBound:g} with "
                                      f"{pinned} pinned pivot(s); S + shift is not positive definite -- raise diagonalShift / svdTol "
                                      f"or use solver='eigh'")
@@ -531,7 +541,14 @@ class TDVP:
         """(S0 + D) u = F with D = diagonalShift diag(S0) + floor I > 0 and S0 = L L^T + R:  M = D + L L^T is inverted by the Woodbury
         identity, M^-1 v = D^-1 v - D^-1 L G^-1 L^T D^-1 v with G = I + L^T D^-1 L (r x r, Cholesky), and u <- u + M^-1 (F - (S0 + D) u)
         with the TRUE S0 removes what R (|M^-1 R| <= trace(R) / min D) and the identity's cancellation left.  False: not applicable
-        (rank above the cap, D not positive, R too large) -- the caller factors the full matrix."""
+        (rank above the cap, D not positive, R too large) -- the caller factors the full matrix.
+
+        Two modes.  PLANNING (first call, and whenever the plan no longer fits): the host reads the rank after the factorisation and
+        sizes everything by it.  STATIC (the calls after): the rank is padded to the plan's rmax with zero columns of L -- G gets an
+        identity block there --, the factorisation runs a fixed number of block steps (those after the criterion return at once), and
+        the host reads nothing: `state` is copied asynchronously and looked at by the NEXT call, which re-plans if the factorisation
+        did not finish or the rank came close to rmax.  A call whose factorisation stopped short still refines against the full
+        matrix, and its solver residual is measured and guarded like every other (`residualBound`)."""
         device = F.device
         S0 = b["S"][:P, :P]
         cap = P if self.choleskyEngine == "lowrank" else max(1, min(LOWRANK_RANK_CAP, P // LOWRANK_RANK_DIVISOR))
@@ -539,9 +556,19 @@ class TDVP:
         D = b["diagS"] * float(self.diagonalShift)
         if self._floor is not None:
             D = D + self._floor
+        st = self._chol_static
+        if st is not None and st["P"] == P and st["rmax"] <= w["LT"].shape[0]:
+            if st["event"] is not None:                 # the previous static call's factorisation: finished, with room to spare?
+                st["event"].synchronize()
+                prev_rank, prev_done = int(st["host"][0]), int(st["host"][1])
+                if not prev_done or prev_rank > st["rmax"] - 32:     # (re-plan well before the rank reaches the pad)
+                    st = self._chol_static = None
+            if st is not None:
+                self._solve_lowrank_static(b, F, P, update, w, D, st)
+                return True
         r, done, d0, left, dmin = self._pivoted_factor(S0, w, cap, extra=D.min())
         rho = left / dmin if dmin > 0 else float("inf")
-        self.choleskyInfo = dict(engine="lowrank", rank=r, cap=cap, max_diag=d0, trace_left=left, min_shift=dmin, converged=done)
+        self.choleskyInfo = dict(engine="lowrank", mode="planning", rank=r, cap=cap, max_diag=d0, trace_left=left, min_shift=dmin, converged=done)
         if not done or r < 1 or not (rho <= LOWRANK_SOLVE_RHO):
             return False
         self._lowrank_last_rank = r
@@ -557,12 +584,56 @@ class TDVP:
 
         u = minv(F)
         Su = torch.empty(P, dtype=global_defs.tReal, device=device)
-        for _ in range(1 if rho <= 1e-7 else 2):
+        nref = 1 if rho <= 1e-8 else 2
+        for _ in range(nref):
             nat.call("vmcpde_gemv", nat.ptr(b["S"]), b["Ppad"], P, P, 0, nat.ptr(u), nat.ptr(Su), nat.stream())
             u = u + minv(F - Su - D * u)
         update.copy_(u)
         b["info"].zero_()
+        rmax = _round_up(r + 40, 128)
+        if rmax <= w["LT"].shape[0] and rmax <= cap + 127:
+            self._chol_static = dict(P=P, rmax=rmax, nsteps=r // 10 + 4, nref=nref, rank=r, event=None,
+                                     host=torch.zeros(2, dtype=torch.int32).pin_memory())
         return True
+
+    def _solve_lowrank_static(self, b, F, P, update, w, D, st):
+        device, rmax = F.device, st["rmax"]
+        S0 = b["S"][:P, :P]
+        if w.get("G") is None or w["G"].shape[0] != rmax:
+            need = nat.lib().vmcpde_chol_workspace_bytes(rmax)
+            w["G"] = torch.zeros((rmax, rmax), dtype=global_defs.tReal, device=device)
+            w["G_ws"] = torch.empty(need // 8, dtype=global_defs.tReal, device=device)
+            w["G_info"] = torch.zeros(1, dtype=torch.int32, device=device)
+            w["t2"] = torch.empty(rmax, dtype=global_defs.tReal, device=device)
+            w["Su"] = torch.empty(P, dtype=global_defs.tReal, device=device)
+        G, gws, t2, Su = w["G"], w["G_ws"], w["t2"], w["Su"]
+        need = gws.numel() * 8
+        w["LT"][:rmax].zero_()                                      # columns past the rank: zero, i.e. an identity block in G
+        nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S0), S0.stride(0), P, LOWRANK_TOL, 1, st["nsteps"], rmax, nat.ptr(w["LT"]), w["ldl"],
+                 nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), w["ws"].numel() * 8, nat.stream())
+        st["host"].copy_(w["state"], non_blocking=True)             # for the next call
+        if st["event"] is None:
+            st["event"] = torch.cuda.Event()
+        st["event"].record()
+        LTr = w["LT"][:rmax, :P]
+        Ls = LTr / D
+        torch.mm(Ls, LTr.T, out=G)
+        G.diagonal().add_(1.0)
+        nat.call("vmcpde_cholesky", nat.ptr(G), rmax, rmax, nat.ptr(w["G_info"]), nat.ptr(gws), need, nat.stream())
+
+        def minv(v):
+            t1 = Ls @ v
+            nat.call("vmcpde_chol_solve", nat.ptr(G), rmax, rmax, nat.ptr(t1), nat.ptr(t2), nat.ptr(gws), need, nat.stream())
+            return torch.addmv(v / D, Ls.T, t2, alpha=-1.0)
+
+        u = minv(F)
+        for _ in range(st["nref"]):
+            nat.call("vmcpde_gemv", nat.ptr(b["S"]), b["Ppad"], P, P, 0, nat.ptr(u), nat.ptr(Su), nat.stream())
+            u = u + minv(F - Su - D * u)
+        update.copy_(u)
+        b["info"].zero_()
+        self.choleskyInfo = dict(engine="lowrank", mode="static", rmax=rmax, block_steps=st["nsteps"], refinements=st["nref"],
+                                 planned_rank=st["rank"])
 
     # ---- tdvp.py:57-64 for a numerically rank-deficient S -----------------------------------------------------------
     def _eigh_lowrank(self, S):
