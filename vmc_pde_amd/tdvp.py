@@ -616,15 +616,26 @@ class TDVP:
             st["event"] = torch.cuda.Event()
         st["event"].record()
         LTr = w["LT"][:rmax, :P]
-        Ls = LTr / D
-        torch.mm(Ls, LTr.T, out=G)
+        # G = I + L^T D^-1 L, contraction length P, result only rmax x rmax: as ONE library GEMM the 256 x 256 x 4213 shape runs on 8
+        # workgroups (0.23 ms; the engine's own weighted syrk path 0.17 ms) -- as a batched GEMM over column chunks of 128 (the zero pad
+        # of the rows of LT included) it fills the chip, and the chunk sums are added up
+        ldl = w["ldl"]
+        ck = 128 if ldl % 128 == 0 else 64
+        if w.get("Dpad") is None:
+            w["Dpad"] = torch.ones(ldl, dtype=global_defs.tReal, device=device)
+        w["Dpad"][:P] = D
+        Lfull = w["LT"][:rmax]                                      # rmax x ldl, pad columns zero
+        A3 = (Lfull / w["Dpad"]).view(rmax, ldl // ck, ck).permute(1, 0, 2)
+        B3 = Lfull.view(rmax, ldl // ck, ck).permute(1, 2, 0)
+        torch.sum(torch.bmm(A3, B3), dim=0, out=G)
         G.diagonal().add_(1.0)
         nat.call("vmcpde_cholesky", nat.ptr(G), rmax, rmax, nat.ptr(w["G_info"]), nat.ptr(gws), need, nat.stream())
 
         def minv(v):
-            t1 = Ls @ v
+            y = v / D
+            t1 = LTr @ y
             nat.call("vmcpde_chol_solve", nat.ptr(G), rmax, rmax, nat.ptr(t1), nat.ptr(t2), nat.ptr(gws), need, nat.stream())
-            return torch.addmv(v / D, Ls.T, t2, alpha=-1.0)
+            return torch.addcdiv(y, LTr.T @ t2, D, value=-1.0)
 
         u = minv(F)
         for _ in range(st["nref"]):
