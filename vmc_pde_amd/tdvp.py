@@ -584,7 +584,7 @@ class TDVP:
 
         u = minv(F)
         Su = torch.empty(P, dtype=global_defs.tReal, device=device)
-        nref = 1 if rho <= 1e-8 else 2
+        nref = 1 if rho <= 1e-6 else 2             # (error after j refinements ~ rho^(j+1); the residual is measured either way)
         for _ in range(nref):
             nat.call("vmcpde_gemv", nat.ptr(b["S"]), b["Ppad"], P, P, 0, nat.ptr(u), nat.ptr(Su), nat.stream())
             u = u + minv(F - Su - D * u)
@@ -592,7 +592,7 @@ class TDVP:
         b["info"].zero_()
         rmax = _round_up(r + 40, 128)
         if rmax <= w["LT"].shape[0] and rmax <= cap + 127:
-            self._chol_static = dict(P=P, rmax=rmax, nsteps=r // 10 + 4, nref=nref, rank=r, event=None,
+            self._chol_static = dict(P=P, rmax=rmax, nsteps=r // 11 + 3, nref=nref, rank=r, event=None,
                                      host=torch.zeros(2, dtype=torch.int32).pin_memory())
         return True
 
