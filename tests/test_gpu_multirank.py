@@ -15,6 +15,13 @@ pytestmark = pytest.mark.gpu
 N, DIM, DEPTH, HIDDEN = 6001, 2, 3, (5, 5)     # odd N: ranks get 3001 / 3000 samples
 
 
+# the two solvers, and both through the pivoted low-rank factor of S (forced: the default takes those routes from 1024 / 4096 parameters
+# on) -- the second call of the Cholesky variant runs its static plan
+SOLVERS = (("chol", dict(diagonalShift=1e-5, solver="cholesky")), ("eigh", dict(solver="eigh")),
+           ("chol-lowrank", dict(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine="lowrank")),
+           ("eigh-lowrank", dict(solver="eigh", spectralEngine="lowrank")))
+
+
 def _problem():
     import vmc_pde_amd as V
     sampler = V.Sampler(key=77, dim=DIM, name="Gauss", mcmc_info={"offset": np.ones(DIM), "bound": 0.25})
@@ -41,7 +48,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     V, vs, eq = _problem()
     res = {}
-    for name, kw in (("chol", dict(diagonalShift=1e-5, solver="cholesky")), ("eigh", dict(solver="eigh"))):
+    for name, kw in SOLVERS:
         res[name] = _two_calls(V, vs, eq, kw)
     q.put((rank, {k: [v.numpy() if torch.is_tensor(v) else v for v in vals] for k, vals in res.items()}))   # by value
     dist.barrier()
@@ -50,7 +57,7 @@ def _worker(rank, world, port, q):
 
 def test_two_ranks_match_single_rank():
     V, vs, eq = _problem()
-    single = {name: _two_calls(V, vs, eq, kw) for name, kw in (("chol", dict(diagonalShift=1e-5, solver="cholesky")), ("eigh", dict(solver="eigh")))}
+    single = {name: _two_calls(V, vs, eq, kw) for name, kw in SOLVERS}
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -65,7 +72,7 @@ def test_two_ranks_match_single_rank():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    for name in ("chol", "eigh"):
+    for name, _ in SOLVERS:
         u0, S0, F0, u1, S1, F1, Em, Ev = single[name]
         for rank in (0, 1):
             r = got[rank][name]
@@ -74,7 +81,7 @@ def test_two_ranks_match_single_rank():
             assert float((r[4] - S1).abs().max() / S1.abs().max()) < 1e-11        # second call: lagged centring, one all-reduce
             assert float((r[5] - F1).abs().max() / F1.abs().max()) < 1e-10
             assert abs(r[6] - Em) < 1e-11 * (1 + abs(Em)) and abs(r[7] - Ev) < 1e-10 * (1 + abs(Ev))
-            if name == "chol":                                                       # well conditioned: updates agree directly
+            if name.startswith("chol"):                                              # well conditioned: updates agree directly
                 assert float(torch.linalg.norm(r[0] - u0) / torch.linalg.norm(u0)) < 1e-7
                 assert float(torch.linalg.norm(r[3] - u1) / torch.linalg.norm(u1)) < 1e-7
             else:                                                                    # singular S: compare in the S-norm
