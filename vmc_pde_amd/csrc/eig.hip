@@ -343,7 +343,8 @@ __global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double to
                                                                 double* __restrict__ cand_val, int* __restrict__ cand_idx,
                                                                 double* __restrict__ cand_sum, int nblk, const double* __restrict__ AP,
                                                                 const PivDesc* __restrict__ desc, int32_t* __restrict__ piv,
-                                                                int32_t* __restrict__ state, const PivWork* __restrict__ work) {
+                                                                int32_t* __restrict__ state, const PivWork* __restrict__ work, int diag_flags) {
+  // (timing diagnostics, VMCPDE_PIVBLK_DIAG, wrong results: 1 the block's eliminations stop after the first, 2 no row substitution)
   __shared__ double LP[PB][PB + 1];        // row n = the n-th accepted pivot's row of the block factor (columns 0 .. n)
   __shared__ double Lb[PB][PB + 1];        // block factor by candidate: Lb[m][n], n = elimination step
   __shared__ double Abb[PB][PB + 1];       // the block itself: Abb[m][c] = A[C_m][c] (column c of the panel at the row of candidate m)
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double to
     int bacc = 0;
 #pragma unroll
     for (int n = 0; n < PB; ++n) {
-      if (!going || n >= bsel) continue;     // (wave-uniform: nothing left to eliminate)
+      if (!going || n >= bsel || ((diag_flags & 1) && n >= 1)) continue;     // (wave-uniform: nothing left to eliminate)
       // arg max of the open candidates' remaining entries: every lane reads all PB of them (a ds_bpermute reduction costs ~1100
       // cycles per step; ties go to the lower candidate)
       if (m < PB) sdiag[m] = used ? NEG_INF : diag;
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double to
   }
   __syncthreads();
   // ---- one row per thread: x = A[i][C_acc] L_bb^-T (forward substitution in elimination order), L[i][k + n] = x_n, d_i -= |x|^2
+  if (diag_flags & 2) return;
   const int i = (int)blockIdx.x * PF_ROWS + t;
   const bool inside = i < P;
   const double di = inside ? d[i] : NEG_INF;
@@ -622,11 +624,12 @@ extern "C" int vmcpde_pivoted_cholesky_blocked(const double* S, int64_t lds, int
   hipStream_t st = (hipStream_t)stream;
   if (restart) hipLaunchKernelGGL(pivchol_init_kernel, dim3(nblk), dim3(PC_ROWS), 0, st, S, lds, P, d, cand_val, cand_idx, cand_sum, state, 1);
   const int nfac = (P + PF_ROWS - 1) / PF_ROWS;
+  const int diag_flags = env_int("VMCPDE_PIVBLK_DIAG", 0);
   for (int b = 0; b < n_blocks; ++b) {
     hipLaunchKernelGGL(pivblk_panel_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, S, lds, P, tol_rel, max_rank, LT, ldl, cand_val, cand_idx, cand_sum,
                        nblk, AP, desc, state, work);
     hipLaunchKernelGGL(pivblk_factor_kernel, dim3(nfac), dim3(PF_ROWS), 0, st, P, tol_rel, LT, ldl, d, cand_val, cand_idx, cand_sum, nblk, AP, desc,
-                       piv, state, work);
+                       piv, state, work, diag_flags);
   }
   // one more panel launch settles `state` after the last factor launch: done if nothing is left above the tolerance, and the trace of
   // the remainder (it selects, writes the descriptor and its panel, which the next call's first launch simply recomputes)
