@@ -355,3 +355,37 @@ def test_lowrank_cholesky_solve_matches_the_dense_factorisation(headline_net, mo
     ts = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky")
     us, _ = ts(th.cuda(), 0.0, vs, ep, **kw)
     assert ts.choleskyInfo == dict(engine="dense") and torch.equal(us, u_d)
+
+
+def test_low_precision_gram_variants_keep_the_dense_solve(headline_net):
+    """An S built from four int8 digits of an fp32 Jacobian (or from fp32 block sums) is 1e-8 away from the exact Gram: below that it has
+    no numerical rank to reveal, and the low-rank routes must not be taken (a plan made on the first, fp64-built S of a run once
+    failed the residual guard on the first int8-built one).  The six-digit form (1e-13) keeps them with a tolerance of 1e-12."""
+    import vmc_pde_amd as V
+    from helpers import make_spec, random_theta
+    varstate, ep, th = headline_net
+    N = 8192
+    kw = dict(nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+    spec = make_spec(2, 4, (21, 21), latent="Gauss", coupling="no_add", offset=[1.0, 1.0], seed=4)
+    g = torch.Generator().manual_seed(9)
+    z = O.latent_from_normals(spec, th, torch.randn(N, 2, generator=g, dtype=torch.float64), None)
+    vs32 = make_varstate(spec, th, sampler=FixedSampler(z.cuda()), jacobian_dtype=torch.float32)
+    tp = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", int8Gram=True)
+    seen = []
+    for _ in range(5):
+        tp(th.cuda(), 0.0, vs32, ep, **kw)
+        tp.check()
+        seen.append((tp._i8_digits, tp._lowrank_tol(), tp.choleskyInfo["engine"]))
+        assert float(tp.solverResidual) < 1e-10
+    assert seen[-1] == (4, None, "dense") and seen[-2][2] == "dense", seen
+    vs64 = varstate(N)
+    t6 = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", int8Gram=True)
+    for _ in range(5):
+        t6(th.cuda(), 0.0, vs64, ep, **kw)
+        t6.check()
+    assert t6._i8_digits == 6 and t6._lowrank_tol() == 1e-12 and t6.choleskyInfo["engine"] == "lowrank" and float(t6.solverResidual) < 1e-11
+    tb = V.TDVP(diagonalShift=1e-3, svdTol=1e-6, solver="cholesky", f32BlockGram=True)
+    for _ in range(3):
+        tb(th.cuda(), 0.0, vs32, ep, **kw)
+        tb.check()
+    assert tb._lowrank_tol() is None and tb.choleskyInfo == dict(engine="dense")

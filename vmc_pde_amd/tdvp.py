@@ -511,6 +511,27 @@ class TDVP:
             self._buf_lr = {key: w}
         return w
 
+    def _lowrank_tol(self):
+        """Pivoting tolerance of the low-rank routes for THIS call's S, or None when they do not apply: the factorisation must stop
+        above the noise of S.  An fp64-accumulated Gram (fp64 or fp32 Jacobian storage) is exact to round-off: LOWRANK_TOL.  The
+        six-digit int8 S-build is 1.2e-13 |S|_F away from it: 1e-12.  Four int8 digits (fp32 Jacobian: 6e-9) and fp32 block sums
+        (2e-8) bury everything below ~1e-8 max diag in noise -- such an S has no usable numerical rank (measured: a plan made on the
+        first, fp64-built S failed the residual guard on the first int8-built one), so those variants keep the dense paths."""
+        if self.f32BlockGram:
+            return None
+        tol = LOWRANK_TOL
+        if self.int8Gram and not self._i8_off:
+            if self._i8_digits == 4:
+                return None
+            tol = 1e-12
+        if self._uncentred_ok and self._ratio_host is not None:
+            # the uncentred Gram subtracts N m m^T afterwards: relative noise ~ eps * max_p mean_p^2 / var_p (the figure the engine
+            # watches to stay below 1e3; 1.3e-4 for the headline network), read from the previous call's record
+            r = float(self._ratio_host[0])
+            if r == r:
+                tol = max(tol, 2e-15 * r)
+        return tol
+
     def _pivoted_factor(self, S, w, cap, extra=None):
         """S = L L^T + R by blocked diagonal pivoting (up to 32 columns per pair of launches) into w["LT"]; returns (rank, converged,
         max diag, trace of R, extra's value).  The first call covers the previous call's rank (the spectrum moves slowly along a
@@ -519,7 +540,7 @@ class TDVP:
         done, first = False, True
         nblocks = (self._lowrank_last_rank + 12) // 13 + 2 if self._lowrank_last_rank else 12      # (a step accepts ~13 columns)
         for _ in range(cap // 3 + 8):           # (every step makes progress -- a column, or candidates lowered to what is left of them)
-            nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S), S.stride(0), P, LOWRANK_TOL, 1 if first else 0, nblocks, cap, nat.ptr(w["LT"]),
+            nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S), S.stride(0), P, self._lowrank_tol() or LOWRANK_TOL, 1 if first else 0, nblocks, cap, nat.ptr(w["LT"]),
                      w["ldl"], nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), w["ws"].numel() * 8, nat.stream())
             w["state_host"].copy_(w["state"], non_blocking=True)
             w["info_host"][:2].copy_(w["ws"][:2], non_blocking=True)
@@ -609,7 +630,7 @@ class TDVP:
         G, gws, t2, Su = w["G"], w["G_ws"], w["t2"], w["Su"]
         need = gws.numel() * 8
         w["LT"][:rmax].zero_()                                      # columns past the rank: zero, i.e. an identity block in G
-        nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S0), S0.stride(0), P, LOWRANK_TOL, 1, st["nsteps"], rmax, nat.ptr(w["LT"]), w["ldl"],
+        nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S0), S0.stride(0), P, self._lowrank_tol() or LOWRANK_TOL, 1, st["nsteps"], rmax, nat.ptr(w["LT"]), w["ldl"],
                  nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), w["ws"].numel() * 8, nat.stream())
         st["host"].copy_(w["state"], non_blocking=True)             # for the next call
         if st["event"] is None:
@@ -706,7 +727,7 @@ class TDVP:
         if self.spectralEngine == "lowrank" and self.diagonalizeOnDevice is None:
             on_device = True
         self.spectralInfo = None
-        lowrank = on_device and self.spectralEngine != "dense" and not (self.diagonalShift > 1e-10) and \
+        lowrank = on_device and self.spectralEngine != "dense" and not (self.diagonalShift > 1e-10) and self._lowrank_tol() is not None and \
             (self.spectralEngine == "lowrank" or (P >= LOWRANK_MIN_P and self._lowrank_backoff == 0))
         if on_device and self.spectralEngine == "auto" and self._lowrank_backoff > 0:
             self._lowrank_backoff -= 1
@@ -758,7 +779,10 @@ class TDVP:
         with torch.cuda.device(device):
             lowrank_done = False
             if self._solver() == "cholesky":
-                try_lr = self.choleskyEngine == "lowrank" or (self.choleskyEngine == "auto" and P >= LOWRANK_CHOL_MIN_P and self._chol_backoff == 0)
+                try_lr = self._lowrank_tol() is not None and (self.choleskyEngine == "lowrank" or
+                                                              (self.choleskyEngine == "auto" and P >= LOWRANK_CHOL_MIN_P and self._chol_backoff == 0))
+                if self._lowrank_tol() is None:
+                    self._chol_static = None
                 if self.choleskyEngine == "auto" and self._chol_backoff > 0:
                     self._chol_backoff -= 1
                 self.choleskyInfo = dict(engine="dense")
