@@ -231,7 +231,7 @@ def main():
     ap.add_argument("--jacobian", default="f64", choices=["f64", "f32", "f32blocks", "i8sliced", "i8f32"],
                     help="storage type of the per-sample Jacobian (f32 = BASELINE config 5: fp32 storage, fp64 products and sums; "
                          "f32blocks: fp32 MFMA sums over blocks of 128 samples, fp64 across blocks)")
-    ap.add_argument("--solver", default="cholesky", choices=["cholesky", "cholesky-dense", "eigh", "eigh-dense"],
+    ap.add_argument("--solver", default="cholesky", choices=["cholesky", "cholesky-dense", "matrixfree", "eigh", "eigh-dense"],
                     help="cholesky: the headline (north_star's regularised on-device Cholesky solve, by the product's default route: from 4096 "
                          "parameters on a pivoted low-rank factor of S + Woodbury + refinement against the full matrix when S is rank "
                          "deficient); cholesky-dense: the blocked factorisation of the full matrix always; eigh: TDVP() exactly as the reference constructs "
@@ -267,7 +267,9 @@ def main():
     if args.jacobian == "f32blocks":     # fp32 accumulation inside 128-sample blocks is not exactly PSD: needs the stronger shift
         tdvp.f32BlockGram = True
         tdvp.diagonalShift = F32BLOCKS_DIAG_SHIFT
-    if args.solver == "cholesky-dense":
+    if args.solver == "matrixfree":       # EXPERIMENT, reported beside the headline: the same regularised solve without an assembled S
+        tdvp.matrixFree = True
+    elif args.solver == "cholesky-dense":
         tdvp.choleskyEngine = "dense"
     elif args.solver != "cholesky":
         tdvp.solver, tdvp.diagonalShift, tdvp.svdTol = "eigh", 0.0, 1e-11
@@ -374,8 +376,8 @@ def main():
             "dtype": DTYPE_LABEL[args.jacobian], "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload]["desc"],
                        "n_param": P, "n_samp_per_gpu": args.samples, "n_samp_total": n_total,
-                       "solver": "cholesky" if args.solver.startswith("cholesky") else "eigh (TDVP() with the reference's constructor defaults: spectral pseudo-inverse)",
-                       **({"cholesky_engine": tdvp.choleskyInfo} if args.solver.startswith("cholesky") else {"spectral": tdvp.spectralInfo}),
+                       "solver": "cholesky" if args.solver.startswith("cholesky") else ("cholesky, matrix-free (EXPERIMENT: S never assembled)" if args.solver == "matrixfree" else "eigh (TDVP() with the reference's constructor defaults: spectral pseudo-inverse)"),
+                       **({"cholesky_engine": tdvp.choleskyInfo} if (args.solver.startswith("cholesky") or args.solver == "matrixfree") else {"spectral": tdvp.spectralInfo}),
                        "gram_operands": OPERAND_LABEL[args.jacobian] if tdvp._uncentred_ok else "centred in staging",
                        "mean2_over_var_max": ratio,
                        "diagonal_shift": float(tdvp.diagonalShift), "svd_tol": float(tdvp.svdTol), "solver_residual": resid,

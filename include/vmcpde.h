@@ -275,6 +275,23 @@ int64_t vmcpde_pivoted_cholesky_blocked_workspace_bytes(int32_t P);
 int vmcpde_pivoted_cholesky_blocked(const double* S, int64_t lds, int32_t P, double tol_rel, int32_t restart, int32_t n_blocks,
                                     int32_t max_rank, double* LT, int64_t ldl, int32_t* piv, int32_t* state, void* workspace,
                                     int64_t workspace_bytes, void* stream);
+/* ---- EXPERIMENT: the same factorisation without an assembled S (matrix-free TDVP step, vmc_pde_amd/tdvp.py `matrixFree`) -------
+ * S = J^T J / N - m m^T enters the pivoted factorisation only through its diagonal and the 32 columns a block step pivots on, so the
+ * Jacobian is read once per block step instead of N P^2 flop:
+ *   vmcpde_lowrank_begin(diag)        start from the diagonal of S ([dev] P); same workspace / state as the blocked factorisation
+ *   vmcpde_lowrank_step(NULL, ..)     choose the step's candidates: their rows are the int32[32] at
+ *                                     vmcpde_lowrank_candidates_byte_offset(P) in the workspace (unused entries repeat a valid row)
+ *   vmcpde_gram_columns(..)           Scol[m][i] = sum_n JT[rows[m]][n] JT[i][n] / n_total - mean[i] mean[rows[m]]   ([32][ldl];
+ *                                     an fp64-MFMA skinny GEMM, one pass over JT; mean NULL = uncentred)
+ *   vmcpde_lowrank_step(Scol, ..)     panel, block factorisation with pivoting, new columns of L (as launches 1-2 of a blocked step) */
+int64_t vmcpde_lowrank_candidates_byte_offset(int32_t P);
+int vmcpde_lowrank_begin(const double* diag, int32_t P, int32_t* state, void* workspace, int64_t workspace_bytes, void* stream);
+int vmcpde_lowrank_step(const double* Scol, int32_t P, double tol_rel, int32_t max_rank, double* LT, int64_t ldl, int32_t* piv,
+                        int32_t* state, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t vmcpde_gram_columns_workspace_bytes(int32_t P, int64_t n_samples);
+int vmcpde_gram_columns(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, const int32_t* rows32, const double* mean,
+                        double n_total, double* Scol, int64_t ldl, const int32_t* state /* NULL, or: skip when state[1] != 0 */,
+                        void* workspace, int64_t workspace_bytes, void* stream);
 /* Householder QR of the P x r matrix whose columns are the rows of LT (destroyed: the strict upper part of R, the rest is scratch).  YT: [dev] r x ldl,
  * row k = reflector v_k (zeros before k, v_k[k] = 1, zeros from P on); tau: [dev] r, H_k = I - tau_k v_k v_k^T, Q = H_0 ... H_{r-1}
  * = I - Y T Y^T with T^-1 = strict upper part of Y^T Y + diag(1 / tau)  (tau_k is never 0: a column that is already zero below its

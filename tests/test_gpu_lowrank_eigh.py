@@ -389,3 +389,31 @@ def test_low_precision_gram_variants_keep_the_dense_solve(headline_net):
         tb(th.cuda(), 0.0, vs32, ep, **kw)
         tb.check()
     assert tb._lowrank_tol() is None and tb.choleskyInfo == dict(engine="dense")
+
+
+def test_matrix_free_step_matches_the_assembled_one(headline_net):
+    """EXPERIMENT `TDVP(matrixFree=True)`: the regularised solve with S = <J^T J> never assembled (its diagonal, the columns the pivoted
+    factorisation asks for and products S0 v come from passes over the Jacobian) against the assembled path on the same samples."""
+    import vmc_pde_amd as V
+    varstate, ep, th = headline_net
+    N = 8192
+    vs = varstate(N)
+    kw = dict(nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+    td = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine="dense")
+    u_d, _ = td(th.cuda(), 0.0, vs, ep, **kw)
+    td.check()
+    S, F = td.S0.clone(), td.F0.clone()
+    D = 1e-4 * torch.diagonal(S) + 1e-6 * torch.diagonal(S).max()
+    nF = float(torch.linalg.norm(F))
+    tm = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", matrixFree=True)
+    for call in range(3):
+        u, _ = tm(th.cuda(), 0.0, vs, ep, **kw)
+        tm.check()
+        assert tm.choleskyInfo["engine"] == "matrix-free" and tm.choleskyInfo["mode"] == ("planning" if call == 0 else "static"), tm.choleskyInfo
+        assert tm.S0 is None
+        assert float(torch.linalg.norm(tm.F0 - F)) < 1e-12 * nF
+        du = u - u_d
+        assert float(torch.linalg.norm(S @ du + D * du)) < 1e-10 * nF, float(torch.linalg.norm(S @ du + D * du)) / nF
+        assert abs(float(tm.solverResidual)) < 1e-11 and abs(float(tm.tdvp_error) - float(td.tdvp_error)) < 1e-10
+        assert abs(float(tm.ElocMean) - float(td.ElocMean)) < 1e-12 * (1 + abs(float(td.ElocMean)))
+        assert abs(float(tm.ElocVar) - float(td.ElocVar)) < 1e-11 * (1 + abs(float(td.ElocVar)))

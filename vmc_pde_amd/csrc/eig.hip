@@ -220,7 +220,10 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
                                                                   const double* __restrict__ cand_val, const int* __restrict__ cand_idx,
                                                                   const double* __restrict__ cand_sum, int nblk, double* __restrict__ AP,
                                                                   PivDesc* __restrict__ desc, int32_t* __restrict__ state,
-                                                                  PivWork* __restrict__ work) {
+                                                                  PivWork* __restrict__ work, int phase, const double* __restrict__ Scol) {
+  // phase 2: selection and panel from the matrix S (the usual step).  The matrix-free form (S never assembled: its columns are formed
+  // from the Jacobian on demand) splits a step: phase 0 = selection only (one workgroup; the caller then forms the chosen columns
+  // Scol[m][i] = S[C_m][i]), phase 1 = the panel from Scol with the selection read back from `desc`.
   __shared__ double cv[PB_MAX_BLOCKS];
   __shared__ int ci[PB_MAX_BLOCKS];
   __shared__ double Wt[PBK][PB];
@@ -231,9 +234,14 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
   const int t = threadIdx.x, lane = t & 63;
   const int slice = __builtin_amdgcn_readfirstlane(t >> 6);
   const int ncand = 2 * nblk;
-  for (int q = t; q < ncand; q += PC_THREADS) { cv[q] = cand_val[q]; ci[q] = cand_idx[q]; }
+  if (phase == 1) {
+    if (t == 0) { s_k = desc->k; s_bsel = desc->bsel; s_done = state[1]; s_sum = 0.0; s_top = desc->top; }
+    if (t < PB) s_C[t] = desc->C[t];
+  } else {
+    for (int q = t; q < ncand; q += PC_THREADS) { cv[q] = cand_val[q]; ci[q] = cand_idx[q]; }
+  }
   __syncthreads();
-  if (slice == 0) {
+  if (phase != 1 && slice == 0) {
     const int k = state[0];
     double sum = 0.0;
     for (int q = lane; q < ncand; q += 64) sum += cand_sum[q];
@@ -285,16 +293,16 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
   __syncthreads();
   if (s_done) return;
   const int k = s_k, bsel = s_bsel;
-  if (blockIdx.x == 0 && t == 0) {
+  if (phase != 1 && blockIdx.x == 0 && t == 0) {
     desc->top = s_top;
     desc->k = k;
     desc->bsel = bsel;
-    for (int m = 0; m < bsel; ++m) desc->C[m] = s_C[m];
+    for (int m = 0; m < PB; ++m) desc->C[m] = (m < bsel) ? s_C[m] : (bsel ? s_C[0] : 0);   // (unused entries: a valid row for the caller's gather)
     if (k == 0) work->d0 = s_top;
     work->trace_left = s_sum;
     if (bsel == 0 && k < max_rank) state[1] = 1;                       // nothing left above the tolerance (a full `max_rank` is not "done")
   }
-  if (bsel == 0) return;
+  if (bsel == 0 || phase == 0) return;
   // ---- panel: A[i][m] = S[C_m][i] - sum_{j < k} L[i][j] L[C_m][j]; wave s forms the columns 2 s, 2 s + 1 for the 64 rows of the workgroup
   // wave s = (quarter jq = s >> 2 of the earlier columns, group cg = s & 3 of eight panel columns): every row of L is loaded by four
   // waves instead of sixteen and a thread's loop is k / 4 long with eight independent sums (2 columns x all of k per wave took 8 us
@@ -333,7 +341,8 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
       for (int c = 0; c < 8; ++c) {
         const int m = 8 * cg + c;
         const double sum = acc[c] + red[0][lane][8 * (cg & 1) + c] + red[1][lane][8 * (cg & 1) + c] + red[2][lane][8 * (cg & 1) + c];
-        AP[(int64_t)m * ldl + i] = (inside && m < bsel) ? S[(int64_t)s_C[m] * lds + i] - sum : 0.0;
+        const double sv = (inside && m < bsel) ? (Scol ? Scol[(int64_t)m * ldl + i] : S[(int64_t)s_C[m] * lds + i]) : 0.0;
+        AP[(int64_t)m * ldl + i] = (inside && m < bsel) ? sv - sum : 0.0;
       }
     }
   }
@@ -475,6 +484,127 @@ __global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double to
     state[0] = k + bacc;
     for (int n = 0; n < bacc; ++n) piv[k + n] = s_C[s_perm[n]];
   }
+}
+
+// ---- matrix-free form: S = J^T J / N - m m^T is never assembled ----------------------------------------------------------------
+// d = the given diagonal; the two largest entries of every 64-row block as candidates (as pivchol_init_kernel with two = 1)
+__global__ __launch_bounds__(PC_ROWS) void pivchol_init_diag_kernel(const double* __restrict__ diag, int P, double* __restrict__ d,
+                                                                    double* __restrict__ cand_val, int* __restrict__ cand_idx,
+                                                                    double* __restrict__ cand_sum, int32_t* __restrict__ state) {
+  const int i = (int)blockIdx.x * PC_ROWS + (int)threadIdx.x;
+  double mine = NEG_INF;
+  if (i < P) {
+    mine = diag[i];
+    d[i] = mine;
+  }
+  double v = mine;
+  int idx = i;
+  double pos = (v > 0.0) ? v : 0.0;
+  wave_argmax(v, idx);
+  pos = wave_sum(pos);
+  double v2 = (i == idx) ? NEG_INF : mine;
+  int idx2 = i;
+  wave_argmax(v2, idx2);
+  if (threadIdx.x == 0) {
+    cand_val[2 * blockIdx.x] = v;
+    cand_idx[2 * blockIdx.x] = idx;
+    cand_sum[2 * blockIdx.x] = pos;
+    cand_val[2 * blockIdx.x + 1] = v2;
+    cand_idx[2 * blockIdx.x + 1] = idx2;
+    cand_sum[2 * blockIdx.x + 1] = 0.0;
+    if (blockIdx.x == 0) { state[0] = 0; state[1] = 0; }
+  }
+}
+
+// Columns of the Gram matrix on demand: part[chunk][m][i] = sum_{n in chunk} JT[C_m][n] JT[i][n] for the PB rows C and all rows i --
+// a skinny GEMM that reads the Jacobian once (HBM-bound: 2.2 GB at the headline size against 1.8e10 flop).  Workgroup = 64 rows i x PB
+// rows C_m over one sample chunk; both operands are staged through the LDS by coalesced row-segment loads, wave w multiplies the
+// rows 16 w .. 16 w + 15 against the 32 candidates (candidates as the MFMA's row operand, so that a lane group writes 16 consecutive
+// i of one candidate's column).
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int CP_ROWS = 64, CP_BK = 32, CP_THREADS = 256, CP_PITCH = CP_BK + 1;
+__global__ __launch_bounds__(CP_THREADS) void colpanel_kernel(const double* __restrict__ JT, int64_t ldj, int64_t n, const int32_t* __restrict__ C,
+                                                              int64_t chunk, double* __restrict__ part, int64_t ldl,
+                                                              const int32_t* __restrict__ state) {
+  if (state && state[1]) return;          // (the factorisation this panel is for has met its criterion: a static plan's spare steps)
+  __shared__ double As[CP_ROWS][CP_PITCH];
+  __shared__ double Bs[PB][CP_PITCH];
+  __shared__ int s_C[PB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < PB) s_C[t] = C[t];
+  __syncthreads();
+  const int i0 = (int)blockIdx.x * CP_ROWS;
+  const int64_t n0 = (int64_t)blockIdx.y * chunk;
+  const int64_t n1 = (n0 + chunk < n) ? (n0 + chunk) : n;
+  const int ar = t >> 2, as = (t & 3) * 8;                 // A: row ar, 8 samples from as
+  const int br = t >> 3, bs = (t & 7) * 4;                 // B: candidate br, 4 samples from bs
+  const double* __restrict__ arow = JT + (int64_t)(i0 + ar) * ldj;
+  const double* __restrict__ brow = JT + (int64_t)s_C[br] * ldj;
+  double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+  const int lr = lane & 15, lk = lane >> 4;
+  typedef double double2v __attribute__((ext_vector_type(2)));
+  double2v va[4], vb[2];
+  // one step's operands: whole 16-byte loads where the step lies inside the chunk (rows are 128-byte aligned, steps 256 bytes), element
+  // by element with zeros past the chunk's end otherwise
+  auto fetch = [&](int64_t nk) {
+    if (nk + CP_BK <= n1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) va[q] = *reinterpret_cast<const double2v*>(arow + nk + as + 2 * q);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) vb[q] = *reinterpret_cast<const double2v*>(brow + nk + bs + 2 * q);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        va[q].x = (nk + as + 2 * q < n1) ? arow[nk + as + 2 * q] : 0.0;
+        va[q].y = (nk + as + 2 * q + 1 < n1) ? arow[nk + as + 2 * q + 1] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        vb[q].x = (nk + bs + 2 * q < n1) ? brow[nk + bs + 2 * q] : 0.0;
+        vb[q].y = (nk + bs + 2 * q + 1 < n1) ? brow[nk + bs + 2 * q + 1] : 0.0;
+      }
+    }
+  };
+  if (n0 < n1) fetch(n0);
+  for (int64_t nk = n0; nk < n1; nk += CP_BK) {
+    __syncthreads();                                       // (the previous step's fragments have been read)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { As[ar][as + 2 * q] = va[q].x; As[ar][as + 2 * q + 1] = va[q].y; }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { Bs[br][bs + 2 * q] = vb[q].x; Bs[br][bs + 2 * q + 1] = vb[q].y; }
+    __syncthreads();
+    if (nk + CP_BK < n1) fetch(nk + CP_BK);                // the next step's loads fly under this step's products
+#pragma unroll
+    for (int k4 = 0; k4 < CP_BK / 4; ++k4) {
+      const double bi = As[16 * wave + lr][4 * k4 + lk];   // the 16 rows i of this wave: the MFMA's column operand
+      const double c0 = Bs[lr][4 * k4 + lk], c1 = Bs[16 + lr][4 * k4 + lk];
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, bi, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, bi, acc1, 0, 0, 0);
+    }
+  }
+  // C/D element q of lane l: row (candidate) = (l >> 4) + 4 q, column (row i) = l & 15
+  double* __restrict__ out = part + (int64_t)blockIdx.y * PB * ldl;
+  const int i = i0 + 16 * wave + lr;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    out[(int64_t)(lk + 4 * q) * ldl + i] = acc0[q];
+    out[(int64_t)(16 + lk + 4 * q) * ldl + i] = acc1[q];
+  }
+}
+
+// Scol[m][i] = (sum over the chunks) / N - mean[i] mean[C_m]   (mean NULL: no centring)
+__global__ void colpanel_reduce_kernel(const double* __restrict__ part, int nchunk, int64_t ldl, int P, const int32_t* __restrict__ C,
+                                       const double* __restrict__ mean, double inv_n, double* __restrict__ Scol,
+                                       const int32_t* __restrict__ state) {
+  if (state && state[1]) return;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)PB * ldl) return;
+  const int m = (int)(e / ldl), i = (int)(e - (int64_t)m * ldl);
+  double sum = 0.0;
+  for (int c = 0; c < nchunk; ++c) sum += part[(int64_t)c * PB * ldl + e];
+  double v = 0.0;
+  if (i < P) v = sum * inv_n - (mean ? mean[i] * mean[C[m]] : 0.0);
+  Scol[e] = v;
 }
 
 constexpr int HQ_THREADS = 1024;
@@ -627,14 +757,92 @@ extern "C" int vmcpde_pivoted_cholesky_blocked(const double* S, int64_t lds, int
   const int diag_flags = env_int("VMCPDE_PIVBLK_DIAG", 0);
   for (int b = 0; b < n_blocks; ++b) {
     hipLaunchKernelGGL(pivblk_panel_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, S, lds, P, tol_rel, max_rank, LT, ldl, cand_val, cand_idx, cand_sum,
-                       nblk, AP, desc, state, work);
+                       nblk, AP, desc, state, work, 2, (const double*)nullptr);
     hipLaunchKernelGGL(pivblk_factor_kernel, dim3(nfac), dim3(PF_ROWS), 0, st, P, tol_rel, LT, ldl, d, cand_val, cand_idx, cand_sum, nblk, AP, desc,
                        piv, state, work, diag_flags);
   }
   // one more panel launch settles `state` after the last factor launch: done if nothing is left above the tolerance, and the trace of
   // the remainder (it selects, writes the descriptor and its panel, which the next call's first launch simply recomputes)
   hipLaunchKernelGGL(pivblk_panel_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, S, lds, P, tol_rel, max_rank, LT, ldl, cand_val, cand_idx, cand_sum, nblk,
-                     AP, desc, state, work);
+                     AP, desc, state, work, 2, (const double*)nullptr);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- matrix-free form (experiment): the same factorisation with the columns of S formed from the Jacobian on demand ----------------
+extern "C" int64_t vmcpde_lowrank_candidates_byte_offset(int32_t P) {     // of the int32[32] candidate rows inside the blocked workspace
+  return (P >= 1) ? (pivchol_ws_doubles(P) * (int64_t)sizeof(double) + 16) : 0;
+}
+
+extern "C" int vmcpde_lowrank_begin(const double* diag, int32_t P, int32_t* state, void* workspace, int64_t workspace_bytes, void* stream) {
+  VMC_REQUIRE(diag && state && workspace && P >= 1, "vmcpde_lowrank_begin: bad argument");
+  const int nblk = (P + PC_ROWS - 1) / PC_ROWS;
+  VMC_REQUIRE(2 * nblk <= PB_MAX_BLOCKS, "vmcpde_lowrank_begin: P <= 32768");
+  VMC_REQUIRE(workspace_bytes >= vmcpde_pivoted_cholesky_blocked_workspace_bytes(P), "vmcpde_lowrank_begin: workspace too small");
+  double* w = static_cast<double*>(workspace);
+  double* d = w + 8;
+  double* cand_val = d + (int64_t)nblk * PC_ROWS;
+  double* cand_sum = cand_val + 2 * nblk;
+  int* cand_idx = reinterpret_cast<int*>(cand_sum + 2 * nblk);
+  hipLaunchKernelGGL(pivchol_init_diag_kernel, dim3(nblk), dim3(PC_ROWS), 0, (hipStream_t)stream, diag, P, d, cand_val, cand_idx, cand_sum, state);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// phase 0 (Scol NULL): choose the step's candidates (their rows: int32[32] at vmcpde_lowrank_candidates_byte_offset in the workspace);
+// phase 1 (Scol = [32][ldl], Scol[m][i] = S[C_m][i]): panel, block factorisation, new columns
+extern "C" int vmcpde_lowrank_step(const double* Scol, int32_t P, double tol_rel, int32_t max_rank, double* LT, int64_t ldl, int32_t* piv,
+                                   int32_t* state, void* workspace, int64_t workspace_bytes, void* stream) {
+  VMC_REQUIRE(LT && piv && state && workspace && P >= 1, "vmcpde_lowrank_step: bad argument");
+  const int nblk = (P + PC_ROWS - 1) / PC_ROWS;
+  VMC_REQUIRE(ldl == (int64_t)nblk * PC_ROWS && max_rank >= 1 && max_rank <= P, "vmcpde_lowrank_step: bad shape");
+  VMC_REQUIRE(workspace_bytes >= vmcpde_pivoted_cholesky_blocked_workspace_bytes(P), "vmcpde_lowrank_step: workspace too small");
+  double* w = static_cast<double*>(workspace);
+  PivWork* work = reinterpret_cast<PivWork*>(w);
+  double* d = w + 8;
+  double* cand_val = d + (int64_t)nblk * PC_ROWS;
+  double* cand_sum = cand_val + 2 * nblk;
+  int* cand_idx = reinterpret_cast<int*>(cand_sum + 2 * nblk);
+  PivDesc* desc = reinterpret_cast<PivDesc*>(w + pivchol_ws_doubles(P));
+  double* AP = w + pivchol_ws_doubles(P) + 64;
+  hipStream_t st = (hipStream_t)stream;
+  if (!Scol) {
+    hipLaunchKernelGGL(pivblk_panel_kernel, dim3(1), dim3(PC_THREADS), 0, st, (const double*)nullptr, (int64_t)0, P, tol_rel, max_rank, LT, ldl, cand_val,
+                       cand_idx, cand_sum, nblk, AP, desc, state, work, 0, (const double*)nullptr);
+  } else {
+    hipLaunchKernelGGL(pivblk_panel_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, (const double*)nullptr, (int64_t)0, P, tol_rel, max_rank, LT, ldl,
+                       cand_val, cand_idx, cand_sum, nblk, AP, desc, state, work, 1, Scol);
+    hipLaunchKernelGGL(pivblk_factor_kernel, dim3((P + PF_ROWS - 1) / PF_ROWS), dim3(PF_ROWS), 0, st, P, tol_rel, LT, ldl, d, cand_val, cand_idx,
+                       cand_sum, nblk, AP, desc, piv, state, work, 0);
+  }
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int64_t vmcpde_gram_columns_workspace_bytes(int32_t P, int64_t n_samples) {
+  if (P < 1 || n_samples < 1) return 0;
+  const int64_t ldl = (int64_t)((P + PC_ROWS - 1) / PC_ROWS) * PC_ROWS;
+  return 32 /* chunks */ * (int64_t)PB * ldl * (int64_t)sizeof(double);
+}
+
+// Scol[m][i] = sum_n JT[rows[m]][n] JT[i][n] / n_total - mean[i] mean[rows[m]] for 32 rows (mean NULL: no centring); one pass over JT
+extern "C" int vmcpde_gram_columns(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, const int32_t* rows32, const double* mean,
+                                   double n_total, double* Scol, int64_t ldl, const int32_t* state, void* workspace, int64_t workspace_bytes,
+                                   void* stream) {
+  VMC_REQUIRE(JT && rows32 && Scol && workspace, "vmcpde_gram_columns: null argument");
+  VMC_REQUIRE(P >= 1 && n_samples >= 1 && ldj >= n_samples && n_total > 0, "vmcpde_gram_columns: bad shape");
+  const int nblk = (P + PC_ROWS - 1) / PC_ROWS;
+  VMC_REQUIRE(ldl == (int64_t)nblk * PC_ROWS, "vmcpde_gram_columns: ldl must be P rounded up to a multiple of 64");
+  VMC_REQUIRE(workspace_bytes >= vmcpde_gram_columns_workspace_bytes(P, n_samples), "vmcpde_gram_columns: workspace too small");
+  int nchunk = 32;
+  int64_t chunk = ((n_samples + nchunk - 1) / nchunk + CP_BK - 1) / CP_BK * CP_BK;
+  nchunk = (int)((n_samples + chunk - 1) / chunk);
+  double* part = static_cast<double*>(workspace);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colpanel_kernel, dim3(nblk, nchunk), dim3(CP_THREADS), 0, st, JT, ldj, n_samples, rows32, chunk, part, ldl, state);
+  const int64_t total = (int64_t)PB * ldl;
+  hipLaunchKernelGGL(colpanel_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, nchunk, ldl, P, rows32, mean, 1.0 / n_total,
+                     Scol, state);
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }

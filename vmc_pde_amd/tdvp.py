@@ -101,6 +101,11 @@ class TDVP:
                                   #   of the same system to ~1e-14).  "auto": lowrank from LOWRANK_CHOL_MIN_P parameters on (where the O(P^3)
                                   #   factorisation costs more than the r dependent block steps) while the rank stays under the cap and
                                   #   trace(R) under 1e-4 min D; dense otherwise (and for the next LOWRANK_RETRY_AFTER calls).
+    matrixFree: bool = False      # EXPERIMENT (opt-in, solver="cholesky", fp64 Jacobian, one rank): S is never assembled.  The pivoted low-rank
+                                  # factor of S = <J^T J> needs only diag(S) and the 32 columns a block step pivots on, which are formed from
+                                  # the Jacobian on demand (csrc/eig.hip::colpanel_kernel, one pass over J per block step), and S0 u for the
+                                  # refinement and the diagnostics is J^T (J u) / N - m (m.u): ~20 passes over J instead of N P^2 flop.
+                                  # `S0` is then not available; a full-rank S (no plan within the rank cap) raises.
     residualBound: float = 1e-6   # Cholesky path: a solver residual above this (or a NaN) is treated as a failed factorisation
     centering: str = "auto"       # "exact": global means before the Gram (an extra pass over J, + one tiny all-reduce when sharded)
                                   # "lagged": previous call's global mean as shift -> one pass, a single all-reduce per step
@@ -131,6 +136,7 @@ class TDVP:
             raise ValueError(f"unknown choleskyEngine {self.choleskyEngine!r}")
         self._chol_backoff = 0
         self._chol_static = None
+        self._mf_plan = None
         self.choleskyInfo = None
         self._lowrank_backoff = 0
         self._lowrank_last_rank = 0
@@ -769,8 +775,156 @@ class TDVP:
         with torch.cuda.device(F.device):
             nat.call("vmcpde_gemv", nat.ptr(Vc), P, P, P, 1, nat.ptr(F.contiguous()), nat.ptr(self.VtF), nat.stream())   # tdvp.py:66
 
+    # ---- EXPERIMENT: the Cholesky-path step without an assembled S ----------------------------------------------------
+    def _solve_matrix_free(self, Eloc, gradients, logProbs, psi):
+        """(S0 + D) u = F as in `_solve_lowrank`, with S0 = J^T J / N - m m^T touched only through its diagonal, the columns the pivoted
+        factorisation asks for and products S0 v.  First call: planning (the host reads the rank and the number of block steps used);
+        afterwards a static plan, checked one call later (as `_solve_lowrank_static`)."""
+        if mpi.get_comm_size() != 1:
+            raise NotImplementedError("matrixFree: single rank only (the column panels would need one small all-reduce per block step)")
+        jt = psi.jt_buffer_of(gradients) if psi is not None and hasattr(psi, "jt_buffer_of") else None
+        if jt is None or jt[0].dtype != global_defs.tReal:
+            raise NotImplementedError("matrixFree needs the engine's own fp64 parameter-major Jacobian buffer")
+        JT, ldj = jt
+        e = Eloc.reshape(-1).contiguous()
+        n, P, device = e.numel(), gradients.shape[-1], e.device
+        Jv = JT[:P, :n]
+        tol = self._lowrank_tol() or LOWRANK_TOL
+        with torch.cuda.device(device):
+            self._check_guard("previous step")
+            cap = max(1, min(LOWRANK_RANK_CAP, P // LOWRANK_RANK_DIVISOR))
+            w = self._lowrank_buffers(P, device, cap)
+            ldl = w["ldl"]
+            if w.get("Scol") is None:
+                w["Scol"] = torch.zeros((32, ldl), dtype=global_defs.tReal, device=device)
+                need = nat.lib().vmcpde_gram_columns_workspace_bytes(P, n)
+                w["gc_ws"] = torch.empty(need // 8, dtype=global_defs.tReal, device=device)
+                w["rowsum"] = torch.empty(P, dtype=global_defs.tReal, device=device)
+                w["rowdot"] = torch.empty(P, dtype=global_defs.tReal, device=device)
+            if w["gc_ws"].numel() * 8 < nat.lib().vmcpde_gram_columns_workspace_bytes(P, n):
+                w["gc_ws"] = torch.empty(nat.lib().vmcpde_gram_columns_workspace_bytes(P, n) // 8, dtype=global_defs.tReal, device=device)
+            with self._Section(self, "gram"):          # (what replaces the S-build: moments, diagonal, and the factorisation's passes over J)
+                Em, E2, Eabs = e.mean(), (e * e).mean(), e.abs().mean()
+                nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, 0, P, n, nat.ptr(e), None, nat.ptr(Em.reshape(1)), nat.ptr(w["rowsum"]),
+                         nat.ptr(w["rowdot"]), nat.stream())
+                mean = w["rowsum"] / n
+                F = w["rowdot"] / n                                  # sum_n (J - m)(E - Em) = sum_n J (E - Em)
+                diagS = torch.linalg.vector_norm(Jv, dim=1).square() / n - mean * mean
+                if self.frozenParameters is not None:
+                    raise NotImplementedError("matrixFree with frozenParameters")
+                dmax = diagS.max()
+                floor = float(self.svdTol) * dmax
+                D = diagS * float(self.diagonalShift) + floor
+                scal = torch.stack([Em, Eabs, E2 - Em * Em, E2, torch.zeros_like(Em), dmax, floor, torch.zeros_like(Em)])
+                cand_ptr = nat.C.c_void_p(w["ws"].data_ptr() + nat.lib().vmcpde_lowrank_candidates_byte_offset(P))   # the step's int32[32] rows
+                wsb, gcb = w["ws"].numel() * 8, w["gc_ws"].numel() * 8
+                plan = self._mf_plan
+                if plan is not None and plan["event"] is not None:
+                    plan["event"].synchronize()
+                    if not int(plan["host"][1]) or int(plan["host"][0]) > plan["rmax"] - 32:
+                        plan = self._mf_plan = None
+                rmax = plan["rmax"] if plan is not None else cap
+
+                def block_step():
+                    nat.call("vmcpde_lowrank_step", None, P, tol, rmax, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]),
+                             wsb, nat.stream())
+                    nat.call("vmcpde_gram_columns", nat.ptr(JT), ldj, P, n, cand_ptr, nat.ptr(mean), float(n), nat.ptr(w["Scol"]), ldl,
+                             nat.ptr(w["state"]), nat.ptr(w["gc_ws"]), gcb, nat.stream())
+                    nat.call("vmcpde_lowrank_step", nat.ptr(w["Scol"]), P, tol, rmax, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]),
+                             nat.ptr(w["ws"]), wsb, nat.stream())
+
+                w["LT"][:rmax].zero_()
+                nat.call("vmcpde_lowrank_begin", nat.ptr(diagS), P, nat.ptr(w["state"]), nat.ptr(w["ws"]), wsb, nat.stream())
+                if plan is None:                                     # planning: run until the criterion is met, reading the state every 4 steps
+                    steps, done = 0, False
+                    while steps < cap:
+                        for _ in range(4):
+                            block_step()
+                        steps += 4
+                        nat.call("vmcpde_lowrank_step", None, P, tol, rmax, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]),
+                                 wsb, nat.stream())           # (a selection settles `state`)
+                        w["state_host"].copy_(w["state"], non_blocking=True)
+                        torch.cuda.current_stream(device).synchronize()
+                        if int(w["state_host"][1]) or int(w["state_host"][0]) >= cap:
+                            done = bool(int(w["state_host"][1]))
+                            break
+                    r = int(w["state_host"][0])
+                    if not done or r < 1:
+                        raise FloatingPointError(f"matrixFree: S is not rank deficient within the cap (rank >= {r} of {P}); use the assembled path")
+                    rmax = _round_up(r + 40, 128)
+                    self._mf_plan = dict(rmax=rmax, nsteps=steps + 1, rank=r, event=None, host=torch.zeros(2, dtype=torch.int32).pin_memory())
+                    mode = "planning"
+                else:
+                    for _ in range(plan["nsteps"]):
+                        block_step()
+                    nat.call("vmcpde_lowrank_step", None, P, tol, rmax, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), wsb,
+                             nat.stream())
+                    plan["host"].copy_(w["state"], non_blocking=True)
+                    if plan["event"] is None:
+                        plan["event"] = torch.cuda.Event()
+                    plan["event"].record()
+                    mode = "static"
+            with self._Section(self, "allreduce"):
+                pass
+            self._replicated = self._Section(self, "replicated")
+            self._replicated.__enter__()
+            rmax = self._mf_plan["rmax"]
+            if w.get("G") is None or w["G"].shape[0] != rmax:
+                need = nat.lib().vmcpde_chol_workspace_bytes(rmax)
+                w["G"] = torch.zeros((rmax, rmax), dtype=global_defs.tReal, device=device)
+                w["G_ws"] = torch.empty(need // 8, dtype=global_defs.tReal, device=device)
+                w["G_info"] = torch.zeros(1, dtype=torch.int32, device=device)
+                w["t2"] = torch.empty(rmax, dtype=global_defs.tReal, device=device)
+            G, gws, t2 = w["G"], w["G_ws"], w["t2"]
+            need = gws.numel() * 8
+            ck = 128 if ldl % 128 == 0 else 64
+            if w.get("Dpad") is None:
+                w["Dpad"] = torch.ones(ldl, dtype=global_defs.tReal, device=device)
+            w["Dpad"][:P] = D
+            Lfull = w["LT"][:rmax]
+            LTr = Lfull[:, :P]
+            A3 = (Lfull / w["Dpad"]).view(rmax, ldl // ck, ck).permute(1, 0, 2)
+            B3 = Lfull.view(rmax, ldl // ck, ck).permute(1, 2, 0)
+            torch.sum(torch.bmm(A3, B3), dim=0, out=G)
+            G.diagonal().add_(1.0)
+            nat.call("vmcpde_cholesky", nat.ptr(G), rmax, rmax, nat.ptr(w["G_info"]), nat.ptr(gws), need, nat.stream())
+
+            def minv(v):
+                y = v / D
+                t1 = LTr @ y
+                nat.call("vmcpde_chol_solve", nat.ptr(G), rmax, rmax, nat.ptr(t1), nat.ptr(t2), nat.ptr(gws), need, nat.stream())
+                return torch.addcdiv(y, LTr.T @ t2, D, value=-1.0)
+
+            def s0(v):                                               # J^T (J v) / N - m (m.v): two passes over J
+                return (Jv @ (v @ Jv)) / n - mean * (mean @ v)
+
+            u = minv(F)
+            u = u + minv(F - s0(u) - D * u)
+            update = u.contiguous()
+            S0u = s0(update)
+            out = torch.empty(4, dtype=global_defs.tReal, device=device)
+            info = torch.zeros(1, dtype=torch.int32, device=device)
+            floor_t = floor.reshape(1).contiguous()
+            nat.call("vmcpde_tdvp_diagnostics", nat.ptr(update), nat.ptr(S0u), nat.ptr(F), nat.ptr(diagS.contiguous()), P,
+                     float(self.diagonalShift) if self.diagonalShift > 1e-10 else 0.0, nat.ptr(floor_t), nat.ptr(scal), nat.ptr(info), nat.ptr(out),
+                     nat.stream())
+            self._replicated.__exit__(None, None, None)
+            self._record_guard(out, True)
+        self.ElocMean, self.ElocMeanAbs, self.ElocVar = scal[0], scal[1], scal[2]
+        self._scal, self._floor = scal, floor_t
+        self.F0, self.S0 = F, None
+        self._lazy = dict(JT=JT, ldj=ldj, P=P, n=n, Ntot=float(n), e=e, logp=logProbs.reshape(-1), b=None, mean=mean, Emean=scal[0], chol_border=False,
+                          owner=psi, gen=psi.workspace_generation(n))
+        self._SExp = self._rhoVar = self._snr = self._S = None
+        self.ev = self.V = self.VtF = None
+        self.cholInfo = info
+        self.choleskyInfo = dict(engine="matrix-free", mode=mode, rmax=rmax, block_steps=self._mf_plan["nsteps"], planned_rank=self._mf_plan["rank"])
+        return update, out[0], out[1]
+
     # ---- tdvp.py:73-94 -------------------------------------------------------------------------------------------
     def solve(self, Eloc, gradients, logProbs, psi=None):
+        if self.matrixFree and self._solver() == "cholesky":
+            return self._solve_matrix_free(Eloc, gradients, logProbs, psi)
         F = self.get_tdvp_equation(Eloc, gradients, logProbs, psi=psi)
         b = self._lazy["b"]
         P = F.numel()
