@@ -522,7 +522,13 @@ __global__ __launch_bounds__(PC_ROWS) void pivchol_init_diag_kernel(const double
 // rows 16 w .. 16 w + 15 against the 32 candidates (candidates as the MFMA's row operand, so that a lane group writes 16 consecutive
 // i of one candidate's column).
 typedef double double4_t __attribute__((ext_vector_type(4)));
+// LDS image of an operand: sample c of row r sits at column (c + 4 r) & 31 of a row of 33 doubles.  A fragment read takes row l & 15,
+// sample 4 k4 + (l >> 4): bank pair (33 r + c + 4 r) mod 32 = 5 r + c -- two lanes per pair over the 64 lanes, the minimum (unrotated,
+// r + c put them on 19 pairs); the stores (row t >> 2, eight samples from 8 (t & 3)) keep 5 r + 8 s + q, also two per pair.
 constexpr int CP_ROWS = 64, CP_BK = 32, CP_THREADS = 256, CP_PITCH = CP_BK + 1;
+__device__ __forceinline__ int cp_col(int row, int c) { return (c + 4 * row) & (CP_BK - 1); }
+constexpr int CP_MAX_CHUNKS = 64;                    // sample chunks (split K) a panel may be formed from
+constexpr int64_t CP_RESIDENT = 256 * 6;             // workgroups of colpanel_kernel the chip holds at once
 __global__ __launch_bounds__(CP_THREADS) void colpanel_kernel(const double* __restrict__ JT, int64_t ldj, int64_t n, const int32_t* __restrict__ C,
                                                               int64_t chunk, double* __restrict__ part, int64_t ldl,
                                                               const int32_t* __restrict__ state) {
@@ -569,15 +575,15 @@ __global__ __launch_bounds__(CP_THREADS) void colpanel_kernel(const double* __re
   for (int64_t nk = n0; nk < n1; nk += CP_BK) {
     __syncthreads();                                       // (the previous step's fragments have been read)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { As[ar][as + 2 * q] = va[q].x; As[ar][as + 2 * q + 1] = va[q].y; }
+    for (int q = 0; q < 4; ++q) { As[ar][cp_col(ar, as + 2 * q)] = va[q].x; As[ar][cp_col(ar, as + 2 * q + 1)] = va[q].y; }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) { Bs[br][bs + 2 * q] = vb[q].x; Bs[br][bs + 2 * q + 1] = vb[q].y; }
+    for (int q = 0; q < 2; ++q) { Bs[br][cp_col(br, bs + 2 * q)] = vb[q].x; Bs[br][cp_col(br, bs + 2 * q + 1)] = vb[q].y; }
     __syncthreads();
     if (nk + CP_BK < n1) fetch(nk + CP_BK);                // the next step's loads fly under this step's products
 #pragma unroll
     for (int k4 = 0; k4 < CP_BK / 4; ++k4) {
-      const double bi = As[16 * wave + lr][4 * k4 + lk];   // the 16 rows i of this wave: the MFMA's column operand
-      const double c0 = Bs[lr][4 * k4 + lk], c1 = Bs[16 + lr][4 * k4 + lk];
+      const double bi = As[16 * wave + lr][cp_col(16 * wave + lr, 4 * k4 + lk)];   // the 16 rows i of this wave: the MFMA's column operand
+      const double c0 = Bs[lr][cp_col(lr, 4 * k4 + lk)], c1 = Bs[16 + lr][cp_col(16 + lr, 4 * k4 + lk)];
       acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, bi, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, bi, acc1, 0, 0, 0);
     }
@@ -822,7 +828,7 @@ extern "C" int vmcpde_lowrank_step(const double* Scol, int32_t P, double tol_rel
 extern "C" int64_t vmcpde_gram_columns_workspace_bytes(int32_t P, int64_t n_samples) {
   if (P < 1 || n_samples < 1) return 0;
   const int64_t ldl = (int64_t)((P + PC_ROWS - 1) / PC_ROWS) * PC_ROWS;
-  return 32 /* chunks */ * (int64_t)PB * ldl * (int64_t)sizeof(double);
+  return CP_MAX_CHUNKS * (int64_t)PB * ldl * (int64_t)sizeof(double);
 }
 
 // Scol[m][i] = sum_n JT[rows[m]][n] JT[i][n] / n_total - mean[i] mean[rows[m]] for 32 rows (mean NULL: no centring); one pass over JT
@@ -834,7 +840,13 @@ extern "C" int vmcpde_gram_columns(const double* JT, int64_t ldj, int32_t P, int
   const int nblk = (P + PC_ROWS - 1) / PC_ROWS;
   VMC_REQUIRE(ldl == (int64_t)nblk * PC_ROWS, "vmcpde_gram_columns: ldl must be P rounded up to a multiple of 64");
   VMC_REQUIRE(workspace_bytes >= vmcpde_gram_columns_workspace_bytes(P, n_samples), "vmcpde_gram_columns: workspace too small");
-  int nchunk = 32;
+  // sample chunks so that the workgroups fill whole rounds of the chip (six 25 KB workgroups per CU: 1536 at a time -- 66 row blocks x
+  // 32 chunks = 2112 left the second round 37 % full), at least ~1024 samples each
+  int nchunk = (int)(CP_RESIDENT / nblk);
+  if (nchunk < 1) nchunk = 1;
+  while (nchunk > 1 && n_samples / nchunk < 1024) --nchunk;
+  if (n_samples / nchunk > 4096 && 2 * nchunk <= CP_MAX_CHUNKS) nchunk = (int)(2 * CP_RESIDENT / nblk);
+  if (nchunk > CP_MAX_CHUNKS) nchunk = CP_MAX_CHUNKS;
   int64_t chunk = ((n_samples + nchunk - 1) / nchunk + CP_BK - 1) / CP_BK * CP_BK;
   nchunk = (int)((n_samples + chunk - 1) / chunk);
   double* part = static_cast<double*>(workspace);
