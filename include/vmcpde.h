@@ -136,6 +136,9 @@ int vmcpde_eloc_stats(const double* eloc, int64_t n_samples, double* sums, void*
  * (tdvp.py:41,44-45 in shifted one-pass form; c may be NULL = 0).  cE is read from cE_dev[0] if non-NULL. */
 int vmcpde_row_moments(const void* JT, int64_t ldj, int32_t jt_f32, int32_t P, int64_t n_samples, const double* eloc,
                        const double* c, const double* cE_dev, double* rowsum, double* rowdot, void* stream);
+/* the same pass with rowsq[p] = sum_n (JT[p][n]-c[p])^2 as a third output (fp64 JT): diag S of the matrix-free step */
+int vmcpde_row_moments_sq(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, const double* eloc, const double* c,
+                          const double* cE_dev, double* rowsum, double* rowdot, double* rowsq, void* stream);
 /* number of 128x128 lower-triangle tiles / doubles of the packed Gram buffer for P parameters */
 int64_t vmcpde_gram_packed_doubles(int32_t P);
 /* bytes of split-K workspace vmcpde_gram needs for (P, n_samples) */

@@ -18,7 +18,8 @@ if os.environ.get("SOLVER", "cholesky") == "eigh":     # the reference's spectra
     tdvp = V.TDVP(svdTol=float(os.environ.get("SVD_TOL", "1e-6")), spectralEngine=os.environ.get("ENGINE", "auto"))
 else:
     tdvp = V.TDVP(diagonalShift=shift, svdTol=float(os.environ.get("SVD_TOL", "1e-6")), solver="cholesky",
-                  int8Gram=os.environ.get("INT8_GRAM", "0") == "1")      # INT8_GRAM=1: the S-build on the int8 matrix pipe (experiment)
+                  int8Gram=os.environ.get("INT8_GRAM", "0") == "1",      # INT8_GRAM=1: the S-build on the int8 matrix pipe (experiment)
+                  matrixFree=os.environ.get("MATRIX_FREE", "0") == "1")  # MATRIX_FREE=1: S never assembled (experiment)
 engines, ranks = {}, []
 stepper = V.FixedStepper(timeStep=1e-4, mode="Heun", maxStep=1e-2, increase_fac=1.3)
 t, n, t0 = 0.0, 0, time.perf_counter()

@@ -98,6 +98,7 @@ _PROTOS = {
     "vmcpde_lowrank_step": (_int, [_vp, _i32, _f64, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "vmcpde_gram_columns_workspace_bytes": (_i64, [_i32, _i64]),
     "vmcpde_gram_columns": (_int, [_vp, _i64, _i32, _i64, _vp, _vp, _f64, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "vmcpde_row_moments_sq": (_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vmcpde_householder_rows": (_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
 }
 

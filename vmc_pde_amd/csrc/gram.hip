@@ -190,13 +190,13 @@ template <typename TIn>
 __global__ __launch_bounds__(256) void row_moments_kernel(const TIn* __restrict__ JT, int64_t ldj, int64_t N,
                                                          const double* __restrict__ e, const double* __restrict__ c,
                                                          const double* __restrict__ cE_dev, double* __restrict__ rowsum,
-                                                         double* __restrict__ rowdot) {
-  __shared__ double sh[2][4];
+                                                         double* __restrict__ rowdot, double* __restrict__ rowsq) {
+  __shared__ double sh[3][4];
   const int p = blockIdx.x;
   const double cp = c ? c[p] : 0.0;
   const double cE = cE_dev ? cE_dev[0] : 0.0;
   const TIn* __restrict__ row = JT + (int64_t)p * ldj;
-  double s = 0, sd = 0;
+  double s = 0, sd = 0, sq = 0;                       // (sq: sum of squares, for the matrix-free step's diag S -- rowsq may be NULL)
   const int64_t N2 = N & ~(int64_t)1;
   for (int64_t i = (int64_t)threadIdx.x * 2; i < N2; i += 512) {
     const typename PairOf<TIn>::type v = *reinterpret_cast<const typename PairOf<TIn>::type*>(row + i);
@@ -204,19 +204,22 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const TIn* __restrict_
     const double a = (double)v.x - cp, b = (double)v.y - cp;
     s += a + b;
     sd += a * (ev.x - cE) + b * (ev.y - cE);
+    sq = fma(a, a, fma(b, b, sq));
   }
   if (threadIdx.x == 0 && N2 < N) {
     const double a = (double)row[N2] - cp;
     s += a;
     sd += a * (e[N2] - cE);
+    sq = fma(a, a, sq);
   }
-  s = wave_sum(s); sd = wave_sum(sd);
+  s = wave_sum(s); sd = wave_sum(sd); sq = wave_sum(sq);
   const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { sh[0][w] = s; sh[1][w] = sd; }
+  if ((threadIdx.x & 63) == 0) { sh[0][w] = s; sh[1][w] = sd; sh[2][w] = sq; }
   __syncthreads();
   if (threadIdx.x == 0) {
     rowsum[p] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
     rowdot[p] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    if (rowsq) rowsq[p] = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
   }
 }
 
@@ -341,10 +344,21 @@ extern "C" int vmcpde_row_moments(const void* JT, int64_t ldj, int32_t jt_f32, i
   VMC_REQUIRE(P >= 1 && n_samples >= 1 && ldj >= n_samples && (ldj % 2) == 0, "bad shape (ldj must be even and >= N)");
   if (jt_f32)
     hipLaunchKernelGGL(row_moments_kernel<float>, dim3(P), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(JT), ldj, n_samples,
-                       eloc, c, cE_dev, rowsum, rowdot);
+                       eloc, c, cE_dev, rowsum, rowdot, (double*)nullptr);
   else
     hipLaunchKernelGGL(row_moments_kernel<double>, dim3(P), dim3(256), 0, (hipStream_t)stream, static_cast<const double*>(JT), ldj, n_samples,
-                       eloc, c, cE_dev, rowsum, rowdot);
+                       eloc, c, cE_dev, rowsum, rowdot, (double*)nullptr);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// the same pass with the row sums of squares as a third output (diag S of the matrix-free step): rowsq[p] = sum_n (JT[p][n] - c[p])^2
+extern "C" int vmcpde_row_moments_sq(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, const double* eloc, const double* c,
+                                     const double* cE_dev, double* rowsum, double* rowdot, double* rowsq, void* stream) {
+  VMC_REQUIRE(JT && eloc && rowsum && rowdot && rowsq, "vmcpde_row_moments_sq: null argument");
+  VMC_REQUIRE(P >= 1 && n_samples >= 1 && ldj >= n_samples && (ldj % 2) == 0, "bad shape (ldj must be even and >= N)");
+  hipLaunchKernelGGL(row_moments_kernel<double>, dim3(P), dim3(256), 0, (hipStream_t)stream, JT, ldj, n_samples, eloc, c, cE_dev, rowsum, rowdot,
+                     rowsq);
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -801,15 +801,16 @@ class TDVP:
                 w["gc_ws"] = torch.empty(need // 8, dtype=global_defs.tReal, device=device)
                 w["rowsum"] = torch.empty(P, dtype=global_defs.tReal, device=device)
                 w["rowdot"] = torch.empty(P, dtype=global_defs.tReal, device=device)
+                w["rowsq"] = torch.empty(P, dtype=global_defs.tReal, device=device)
             if w["gc_ws"].numel() * 8 < nat.lib().vmcpde_gram_columns_workspace_bytes(P, n):
                 w["gc_ws"] = torch.empty(nat.lib().vmcpde_gram_columns_workspace_bytes(P, n) // 8, dtype=global_defs.tReal, device=device)
             with self._Section(self, "gram"):          # (what replaces the S-build: moments, diagonal, and the factorisation's passes over J)
                 Em, E2, Eabs = e.mean(), (e * e).mean(), e.abs().mean()
-                nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, 0, P, n, nat.ptr(e), None, nat.ptr(Em.reshape(1)), nat.ptr(w["rowsum"]),
-                         nat.ptr(w["rowdot"]), nat.stream())
+                nat.call("vmcpde_row_moments_sq", nat.ptr(JT), ldj, P, n, nat.ptr(e), None, nat.ptr(Em.reshape(1)), nat.ptr(w["rowsum"]),
+                         nat.ptr(w["rowdot"]), nat.ptr(w["rowsq"]), nat.stream())       # one pass: sum J, sum J (E - Em), sum J^2
                 mean = w["rowsum"] / n
                 F = w["rowdot"] / n                                  # sum_n (J - m)(E - Em) = sum_n J (E - Em)
-                diagS = torch.linalg.vector_norm(Jv, dim=1).square() / n - mean * mean
+                diagS = w["rowsq"] / n - mean * mean
                 if self.frozenParameters is not None:
                     raise NotImplementedError("matrixFree with frozenParameters")
                 dmax = diagS.max()
