@@ -101,7 +101,7 @@ class TDVP:
                                   #   of the same system to ~1e-14).  "auto": lowrank from LOWRANK_CHOL_MIN_P parameters on (where the O(P^3)
                                   #   factorisation costs more than the r dependent block steps) while the rank stays under the cap and
                                   #   trace(R) under 1e-4 min D; dense otherwise (and for the next LOWRANK_RETRY_AFTER calls).
-    matrixFree: bool = False      # EXPERIMENT (opt-in, solver="cholesky", fp64 Jacobian, one rank): S is never assembled.  The pivoted low-rank
+    matrixFree: bool = False      # EXPERIMENT (opt-in, solver="cholesky", fp64 Jacobian): S is never assembled.  The pivoted low-rank
                                   # factor of S = <J^T J> needs only diag(S) and the 32 columns a block step pivots on, which are formed from
                                   # the Jacobian on demand (csrc/eig.hip::colpanel_kernel, one pass over J per block step), and S0 u for the
                                   # refinement and the diagnostics is J^T (J u) / N - m (m.u): ~20 passes over J instead of N P^2 flop.
@@ -780,8 +780,7 @@ class TDVP:
         """(S0 + D) u = F as in `_solve_lowrank`, with S0 = J^T J / N - m m^T touched only through its diagonal, the columns the pivoted
         factorisation asks for and products S0 v.  First call: planning (the host reads the rank and the number of block steps used);
         afterwards a static plan, checked one call later (as `_solve_lowrank_static`)."""
-        if mpi.get_comm_size() != 1:
-            raise NotImplementedError("matrixFree: single rank only (the column panels would need one small all-reduce per block step)")
+        world = mpi.get_comm_size()      # sharded samples: the O(P) moments, every 32-column panel and every S0 v are summed over the ranks
         jt = psi.jt_buffer_of(gradients) if psi is not None and hasattr(psi, "jt_buffer_of") else None
         if jt is None or jt[0].dtype != global_defs.tReal:
             raise NotImplementedError("matrixFree needs the engine's own fp64 parameter-major Jacobian buffer")
@@ -792,8 +791,8 @@ class TDVP:
         tol = self._lowrank_tol() or LOWRANK_TOL
         with torch.cuda.device(device):
             self._check_guard("previous step")
-            cap = max(1, min(LOWRANK_RANK_CAP, P // LOWRANK_RANK_DIVISOR))
-            w = self._lowrank_buffers(P, device, cap)
+            cap = min(LOWRANK_RANK_CAP, max(P // LOWRANK_RANK_DIVISOR, min(P, 256)))      # (small problems: up to 256 columns)
+            w = self._lowrank_buffers(P, device, _round_up(cap + 40, 128))                  # (rows for the plan's zero padding)
             ldl = w["ldl"]
             if w.get("Scol") is None:
                 w["Scol"] = torch.zeros((32, ldl), dtype=global_defs.tReal, device=device)
@@ -805,19 +804,31 @@ class TDVP:
             if w["gc_ws"].numel() * 8 < nat.lib().vmcpde_gram_columns_workspace_bytes(P, n):
                 w["gc_ws"] = torch.empty(nat.lib().vmcpde_gram_columns_workspace_bytes(P, n) // 8, dtype=global_defs.tReal, device=device)
             with self._Section(self, "gram"):          # (what replaces the S-build: moments, diagonal, and the factorisation's passes over J)
-                Em, E2, Eabs = e.mean(), (e * e).mean(), e.abs().mean()
-                nat.call("vmcpde_row_moments_sq", nat.ptr(JT), ldj, P, n, nat.ptr(e), None, nat.ptr(Em.reshape(1)), nat.ptr(w["rowsum"]),
+                Ntot = float(mpi.globNumSamples) if mpi.globNumSamples else float(n * world)
+                esums = torch.stack([e.sum(), (e * e).sum(), e.abs().sum()])
+                if world > 1:
+                    mpi.allreduce_sum_(esums)
+                Em, E2, Eabs = esums[0] / Ntot, esums[1] / Ntot, esums[2] / Ntot
+                nat.call("vmcpde_row_moments_sq", nat.ptr(JT), ldj, P, n, nat.ptr(e), None, nat.ptr(Em.reshape(1).contiguous()), nat.ptr(w["rowsum"]),
                          nat.ptr(w["rowdot"]), nat.ptr(w["rowsq"]), nat.stream())       # one pass: sum J, sum J (E - Em), sum J^2
-                mean = w["rowsum"] / n
-                F = w["rowdot"] / n                                  # sum_n (J - m)(E - Em) = sum_n J (E - Em)
-                diagS = w["rowsq"] / n - mean * mean
+                if world > 1:
+                    mom = torch.stack([w["rowsum"], w["rowdot"], w["rowsq"]])
+                    mpi.allreduce_sum_(mom)
+                    rowsum, rowdot, rowsq = mom[0], mom[1], mom[2]
+                else:
+                    rowsum, rowdot, rowsq = w["rowsum"], w["rowdot"], w["rowsq"]
+                mean = rowsum / Ntot
+                F = rowdot / Ntot                                    # sum_n (J - m)(E - Em) = sum_n J (E - Em)  (Em is the global mean)
+                diagS = rowsq / Ntot - mean * mean
                 if self.frozenParameters is not None:
                     raise NotImplementedError("matrixFree with frozenParameters")
                 dmax = diagS.max()
                 floor = float(self.svdTol) * dmax
                 D = diagS * float(self.diagonalShift) + floor
                 scal = torch.stack([Em, Eabs, E2 - Em * Em, E2, torch.zeros_like(Em), dmax, floor, torch.zeros_like(Em)])
-                cand_ptr = nat.C.c_void_p(w["ws"].data_ptr() + nat.lib().vmcpde_lowrank_candidates_byte_offset(P))   # the step's int32[32] rows
+                cand_off = nat.lib().vmcpde_lowrank_candidates_byte_offset(P)
+                cand_ptr = nat.C.c_void_p(w["ws"].data_ptr() + cand_off)                       # the step's int32[32] candidate rows
+                cand_view = w["ws"].view(torch.int32)[cand_off // 4:cand_off // 4 + 32]
                 wsb, gcb = w["ws"].numel() * 8, w["gc_ws"].numel() * 8
                 plan = self._mf_plan
                 if plan is not None and plan["event"] is not None:
@@ -829,8 +840,15 @@ class TDVP:
                 def block_step():
                     nat.call("vmcpde_lowrank_step", None, P, tol, rmax, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]),
                              wsb, nat.stream())
-                    nat.call("vmcpde_gram_columns", nat.ptr(JT), ldj, P, n, cand_ptr, nat.ptr(mean), float(n), nat.ptr(w["Scol"]), ldl,
-                             nat.ptr(w["state"]), nat.ptr(w["gc_ws"]), gcb, nat.stream())
+                    if world == 1:
+                        nat.call("vmcpde_gram_columns", nat.ptr(JT), ldj, P, n, cand_ptr, nat.ptr(mean), Ntot, nat.ptr(w["Scol"]), ldl,
+                                 nat.ptr(w["state"]), nat.ptr(w["gc_ws"]), gcb, nat.stream())
+                    else:        # raw local sums, one 1 MB all-reduce, then 1/N and the mean term (every rank chose the same candidates)
+                        nat.call("vmcpde_gram_columns", nat.ptr(JT), ldj, P, n, cand_ptr, None, 1.0, nat.ptr(w["Scol"]), ldl, None,
+                                 nat.ptr(w["gc_ws"]), gcb, nat.stream())
+                        mpi.allreduce_sum_(w["Scol"])
+                        rows = cand_view.long()
+                        w["Scol"][:, :P] = w["Scol"][:, :P] / Ntot - torch.outer(mean[rows], mean)
                     nat.call("vmcpde_lowrank_step", nat.ptr(w["Scol"]), P, tol, rmax, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]),
                              nat.ptr(w["ws"]), wsb, nat.stream())
 
@@ -896,8 +914,11 @@ class TDVP:
                 nat.call("vmcpde_chol_solve", nat.ptr(G), rmax, rmax, nat.ptr(t1), nat.ptr(t2), nat.ptr(gws), need, nat.stream())
                 return torch.addcdiv(y, LTr.T @ t2, D, value=-1.0)
 
-            def s0(v):                                               # J^T (J v) / N - m (m.v): two passes over J
-                return (Jv @ (v @ Jv)) / n - mean * (mean @ v)
+            def s0(v):                                               # J^T (J v) / N - m (m.v): two passes over J (+ a P-vector all-reduce)
+                z = Jv @ (v @ Jv)
+                if world > 1:
+                    mpi.allreduce_sum_(z)
+                return z / Ntot - mean * (mean @ v)
 
             u = minv(F)
             u = u + minv(F - s0(u) - D * u)
@@ -914,7 +935,7 @@ class TDVP:
         self.ElocMean, self.ElocMeanAbs, self.ElocVar = scal[0], scal[1], scal[2]
         self._scal, self._floor = scal, floor_t
         self.F0, self.S0 = F, None
-        self._lazy = dict(JT=JT, ldj=ldj, P=P, n=n, Ntot=float(n), e=e, logp=logProbs.reshape(-1), b=None, mean=mean, Emean=scal[0], chol_border=False,
+        self._lazy = dict(JT=JT, ldj=ldj, P=P, n=n, Ntot=Ntot, e=e, logp=logProbs.reshape(-1), b=None, mean=mean, Emean=scal[0], chol_border=False,
                           owner=psi, gen=psi.workspace_generation(n))
         self._SExp = self._rhoVar = self._snr = self._S = None
         self.ev = self.V = self.VtF = None
