@@ -342,6 +342,23 @@ def test_lowrank_cholesky_solve_matches_the_dense_factorisation(headline_net, mo
     u, _ = tp(th.cuda(), 0.0, vs, ep, **kw)
     tp.check()
     assert tp.choleskyInfo["mode"] == "planning" and tp._chol_static["rmax"] >= 256 and float(tp.solverResidual) < 1e-12
+    # the same failure inside an integrator: the stepper repeats the step once (same state, same step size) and hands back the same
+    # result as with the full factorisation; and a synchronous call (observables on) repairs itself before it returns
+    from vmc_pde_amd import FixedStepper
+    ref_step = FixedStepper(timeStep=1e-9, mode="Heun", maxStep=1e-9, increase_fac=1.0)
+    y_d, _, _ = ref_step.step(0.0, V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine="dense"), th.cuda(), evolutionEq=ep, psi=vs, **{k: v for k, v in kw.items() if k != "timings"}, timings=None)
+    tp._chol_static["rmax"], tp._chol_static["nsteps"] = 128, 4
+    tp._chol_static["host"][0] = 50
+    st = FixedStepper(timeStep=1e-9, mode="Heun", maxStep=1e-9, increase_fac=1.0)
+    y_l, dt_l, _ = st.step(0.0, tp, th.cuda(), evolutionEq=ep, psi=vs, **{k: v for k, v in kw.items() if k != "timings"}, timings=None)
+    assert dt_l == 1e-9 and tp.choleskyInfo["mode"] in ("planning", "static") and tp._chol_static["rmax"] >= 256
+    assert float(torch.linalg.norm((y_l - th.cuda()) - (y_d - th.cuda())) / torch.linalg.norm(y_d - th.cuda())) < 1e-4
+    tp._chol_static["rmax"], tp._chol_static["nsteps"] = 128, 4
+    tp._chol_static["host"][0] = 50
+    u_sync, info_sync = tp(th.cuda(), 0.0, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None, integrals=False)     # observables on: synchronous
+    assert tp.choleskyInfo["mode"] == "planning" and float(tp.solverResidual) < 1e-12 and "entropy" in info_sync
+    du = u_sync - u_d
+    assert float(torch.linalg.norm(S @ du + D * du)) < 1e-11 * nF
     # a floor far below what the factorisation leaves of S: refinement would not contract, the full matrix is factored instead
     tq = V.TDVP(diagonalShift=1e-6, svdTol=1e-12, solver="cholesky")
     uq, _ = tq(th.cuda(), 0.0, vs, ep, **kw)

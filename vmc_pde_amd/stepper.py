@@ -33,6 +33,23 @@ def _accept(f):
         check("stepper: before accepting the step")
 
 
+def _retrying(step_once):
+    """A right-hand side may ask for the step to be repeated (an exception with `retry_step`: `tdvp.StaticPlanOutdated`, raised before the
+    step is accepted when a plan carried over from the previous call no longer fitted -- the engine has dropped it by then).  The
+    steppers do so once, from the same state and step size."""
+    def step(self, t, f, y, normFunction=_default_norm, **rhsArgs):
+        dt0 = self.dt
+        try:
+            return step_once(self, t, f, y, normFunction, **rhsArgs)
+        except FloatingPointError as exc:
+            if not getattr(exc, "retry_step", False):
+                raise
+            self.dt = dt0
+            return step_once(self, t, f, y, normFunction, **rhsArgs)
+    step.__doc__ = step_once.__doc__
+    return step
+
+
 def _heun_increment(rhs, y0, t, h, k_first=None):
     """Heun (explicit trapezoid) increment over [t, t+h] from y0; reuses a known first slope.  Returns (dy, k_first, infos)."""
     infos = []
@@ -57,6 +74,7 @@ class AdaptiveHeun:
         self.tolerance = tol
         self.maxStep = maxStep
 
+    @_retrying
     def step(self, t, f, y, normFunction=_default_norm, **rhsArgs):
         y_start = y.clone()
         dt = self.dt
@@ -88,6 +106,7 @@ class FixedStepper:
         self.mode = mode
         self.increase_fac = increase_fac
 
+    @_retrying
     def step(self, t, f, y, normFunction=_default_norm, **rhsArgs):
         if self.mode not in ('Heun', 'Euler'):
             raise ValueError(self.mode)

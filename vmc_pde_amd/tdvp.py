@@ -72,6 +72,12 @@ def _round_up(v, m):
     return (v + m - 1) // m * m
 
 
+class StaticPlanOutdated(FloatingPointError):
+    """The numerical rank of S outgrew the static plan of the low-rank solve within one call, so that call's update failed the residual
+    guard.  The plan has been dropped: repeating the step (the steppers do, once: `retry_step`) runs a planning call."""
+    retry_step = True
+
+
 @dataclass
 class TDVP:
     useSNR: bool = False
@@ -488,7 +494,8 @@ class TDVP:
                 # factorisation that stops at the pad still refines to ~1e-8: this needs a jump of the rank by a large factor): the
                 # plan is dropped, so a caller that catches this and repeats the step gets a planning call
                 self._chol_static = None
-                raise FloatingPointError(f"low-rank Cholesky solve ({when}): solver residual {resid:.3e} > {self.residualBound:g} -- the "
+                self._mf_plan = None
+                raise StaticPlanOutdated(f"low-rank Cholesky solve ({when}): solver residual {resid:.3e} > {self.residualBound:g} -- the "
                                          f"numerical rank of S outgrew the static plan {self.choleskyInfo}; the next call plans anew "
                                          f"(choleskyEngine='dense' avoids the low-rank route)")
             raise FloatingPointError(f"on-device Cholesky failed ({when}): solver residual {resid:.3e} > {self.residualBound:g} with "
@@ -1113,7 +1120,11 @@ class TDVP:
         if not rhsArgs.get("observables", True):
             return update, {}
 
-        self._check_guard("this step")          # (the host synchronises for the NaN check below anyway)
+        try:
+            self._check_guard("this step")      # (the host synchronises for the NaN check below anyway)
+        except StaticPlanOutdated:              # a synchronous call repairs itself: the same samples through a planning call
+            update, self.solverResidual, self.tdvp_error = self.solve(Eloc, sampleGradients, logProbs, psi=psi)
+            self._check_guard("this step")
         if bool(torch.isnan(update).any()):                                   # tdvp.py:136-141
             print(self.S0)
             print(self.F0)
