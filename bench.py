@@ -231,7 +231,7 @@ def main():
     ap.add_argument("--jacobian", default="f64", choices=["f64", "f32", "f32blocks", "i8sliced", "i8f32"],
                     help="storage type of the per-sample Jacobian (f32 = BASELINE config 5: fp32 storage, fp64 products and sums; "
                          "f32blocks: fp32 MFMA sums over blocks of 128 samples, fp64 across blocks)")
-    ap.add_argument("--solver", default="cholesky", choices=["cholesky", "cholesky-dense", "matrixfree", "eigh", "eigh-dense"],
+    ap.add_argument("--solver", default="cholesky", choices=["cholesky", "cholesky-dense", "matrixfree", "eigh", "eigh-dense", "eigh-matrixfree"],
                     help="cholesky: the headline (north_star's regularised on-device Cholesky solve, by the product's default route: from 4096 "
                          "parameters on a pivoted low-rank factor of S + Woodbury + refinement against the full matrix when S is rank "
                          "deficient); cholesky-dense: the blocked factorisation of the full matrix always; eigh: TDVP() exactly as the reference constructs "
@@ -274,6 +274,7 @@ def main():
     elif args.solver != "cholesky":
         tdvp.solver, tdvp.diagonalShift, tdvp.svdTol = "eigh", 0.0, 1e-11
         tdvp.spectralEngine = "dense" if args.solver == "eigh-dense" else "auto"
+        tdvp.matrixFree = args.solver == "eigh-matrixfree"       # EXPERIMENT: the reference-default solve without an assembled S
     P = vs.numParameters
     n_total = args.samples * world
     kwargs = dict(evolutionEq=eq, psi=vs, nSamplesTDVP=n_total, nSamplesObs=n_total, timings=None, observables=False)

@@ -434,3 +434,31 @@ def test_matrix_free_step_matches_the_assembled_one(headline_net):
         assert abs(float(tm.solverResidual)) < 1e-11 and abs(float(tm.tdvp_error) - float(td.tdvp_error)) < 1e-10
         assert abs(float(tm.ElocMean) - float(td.ElocMean)) < 1e-12 * (1 + abs(float(td.ElocMean)))
         assert abs(float(tm.ElocVar) - float(td.ElocVar)) < 1e-11 * (1 + abs(float(td.ElocVar)))
+
+
+def test_matrix_free_spectral_solve_matches_the_assembled_one(headline_net):
+    """`TDVP(matrixFree=True)` with the reference's default solver: the spectral decomposition from the factor of the never-assembled S
+    (Q1^T S Q1 from one more pass over the Jacobian) against the dense one of the assembled S on the same samples."""
+    import vmc_pde_amd as V
+    varstate, ep, th = headline_net
+    N = 8192
+    vs = varstate(N)
+    kw = dict(nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+    td = V.TDVP(svdTol=1e-6, spectralEngine="dense")
+    u_d, _ = td(th.cuda(), 0.0, vs, ep, **kw)
+    td.check()
+    S, F, ev_d = td.S0.clone(), td.F0.clone(), td.ev.clone()
+    nF, lmax, P = float(torch.linalg.norm(F)), float(ev_d[-1]), S.shape[0]
+    tm = V.TDVP(svdTol=1e-6, matrixFree=True)
+    for call in range(2):
+        u, _ = tm(th.cuda(), 0.0, vs, ep, **kw)
+        tm.check()
+        assert tm.spectralInfo["engine"] == "matrix-free" and tm.S0 is None and 1 <= tm.spectralInfo["rank"] < P // 6
+        assert float((tm.ev - ev_d).abs().max()) < 1e-12 * lmax
+        Vm = tm.V
+        assert float((Vm.T @ Vm - torch.eye(P, dtype=torch.float64, device="cuda")).abs().max()) < 1e-13
+        assert float(torch.linalg.norm(S @ Vm - Vm * tm.ev)) < 1e-11 * lmax
+        assert float(torch.linalg.norm(S @ (u - u_d))) < 1e-9 * nF
+        assert abs(float(tm.solverResidual) - float(td.solverResidual)) < 1e-9 and abs(float(tm.tdvp_error) - float(td.tdvp_error)) < 1e-9
+    with pytest.raises(NotImplementedError, match="diagonalShift"):
+        V.TDVP(svdTol=1e-6, diagonalShift=1e-3, matrixFree=True)(th.cuda(), 0.0, vs, ep, **kw)

@@ -690,11 +690,6 @@ class TDVP:
         # (forced engine: no cap -- the factorisation runs until its criterion is met)
         cap = P if self.spectralEngine == "lowrank" else max(1, min(LOWRANK_RANK_CAP, P // LOWRANK_RANK_DIVISOR))
         w = self._lowrank_buffers(P, device, cap)
-        if w["YT"] is None or w["YT"].shape[0] < cap:
-            w["YT"] = torch.empty((w["LT"].shape[0], w["ldl"]), dtype=global_defs.tReal, device=device)
-            w["tau"] = torch.empty(w["LT"].shape[0], dtype=global_defs.tReal, device=device)
-            w["hq"] = torch.empty(w["LT"].shape[0] + 1, dtype=global_defs.tReal, device=device)
-        ldl, LT, YT, tau = w["ldl"], w["LT"], w["YT"], w["tau"]
         # (a NaN on the diagonal compares as "smaller" in the pivot search and would simply be left out: the trace rides along with the
         # first host read, and a non-finite S goes to the dense path, which reports it as before)
         r, done, d0, left, tr = self._pivoted_factor(S, w, cap, extra=torch.diagonal(S).sum())
@@ -702,22 +697,18 @@ class TDVP:
         if not done or r < 1 or not (left <= LOWRANK_TRACE_BOUND * d0) or not np.isfinite(tr):
             return None
         self._lowrank_last_rank = r
-        nat.call("vmcpde_householder_rows", nat.ptr(LT), ldl, P, r, nat.ptr(YT), nat.ptr(tau), nat.ptr(w["hq"]), nat.stream())
-        Y = YT[:r, :P]                                             # r x P: row k = reflector k
-        Tinv = torch.triu(Y @ Y.T, 1)
-        Tinv.diagonal().copy_(1.0 / tau[:r])                       # T^-1 = strict upper part of Y^T Y + diag(1 / tau)
-        # T itself (r x r, what dlarft forms), then T Y^T as a GEMM: a triangular solve with P right-hand sides makes rocBLAS allocate
-        # a workspace that fails for r in the thousands
-        Tm = torch.linalg.solve_triangular(Tinv, torch.eye(r, dtype=global_defs.tReal, device=device), upper=True)
-        Xn = -(Tm @ Y)                                             # -T Y^T  (r x P);  Q = I - Y T Y^T = I + Y^T... columns: [Q1 | Q2]
-        Q1 = Y.T @ Xn[:, :r]
-        Q1[:r].diagonal().add_(1.0)                                # Q1 = E_1 - Y T Y_1^T  (P x r, orthonormal basis of range(L))
+        Y, Xn, Q1 = self._lowrank_range_basis(w, P, r, device)
         T = Q1.T @ (S @ Q1)
         T = 0.5 * (T + T.T)
         # (the r x r core on one host LAPACK thread takes 1.6 ms against 5.4 ms for syevd's launch chain at r = 238, but the host
         # synchronisation it needs costs the calling loop more than that: 33.0 against 30.2 ms per TDVP call -- measured and dropped)
         wv, W = torch.linalg.eigh(T)                               # r x r (rocSOLVER)
         U = Q1 @ W
+        return self._lowrank_assemble(Y, Xn, U, wv, r, P, device)
+
+    @staticmethod
+    def _lowrank_assemble(Y, Xn, U, wv, r, P, device):
+        """(ev, V) from the Ritz pairs (wv ascending, U = Q1 W) and the compact WY form of Q = [Q1 | Q2] = I + Y^T Xn."""
         # ascending order: the (few, round-off) negative Ritz values, the P - r zeros of the complement, the positive Ritz values.  The
         # complement Q2 = E_2 - Y T Y_2^T is written by its GEMM straight into its column block of V: one pass over P x P instead of
         # four (GEMM, sign, diagonal, column gather: 7 + 2 of the 29 ms of the engine at P = 16 181)
@@ -731,6 +722,25 @@ class TDVP:
             Vn[r:].diagonal().add_(1.0)
         ev = torch.cat([wv[:nneg], torch.zeros(P - r, dtype=global_defs.tReal, device=device), wv[nneg:]])
         return ev, V
+
+    def _lowrank_range_basis(self, w, P, r, device):
+        """Householder QR of the factor in w["LT"][:r] (destroyed): reflectors Y (r x P), Xn = -T Y^T of the compact WY form
+        Q = I + Y^T Xn, and Q1 = Q[:, :r], an orthonormal basis of range(L)."""
+        if w["YT"] is None or w["YT"].shape[0] < r:
+            w["YT"] = torch.empty((w["LT"].shape[0], w["ldl"]), dtype=global_defs.tReal, device=device)
+            w["tau"] = torch.empty(w["LT"].shape[0], dtype=global_defs.tReal, device=device)
+            w["hq"] = torch.empty(w["LT"].shape[0] + 1, dtype=global_defs.tReal, device=device)
+        nat.call("vmcpde_householder_rows", nat.ptr(w["LT"]), w["ldl"], P, r, nat.ptr(w["YT"]), nat.ptr(w["tau"]), nat.ptr(w["hq"]), nat.stream())
+        Y = w["YT"][:r, :P]                                        # r x P: row k = reflector k
+        Tinv = torch.triu(Y @ Y.T, 1)
+        Tinv.diagonal().copy_(1.0 / w["tau"][:r])                  # T^-1 = strict upper part of Y^T Y + diag(1 / tau)
+        # T itself (r x r, what dlarft forms), then T Y^T as a GEMM: a triangular solve with P right-hand sides makes rocBLAS allocate
+        # a workspace that fails for r in the thousands
+        Tm = torch.linalg.solve_triangular(Tinv, torch.eye(r, dtype=global_defs.tReal, device=device), upper=True)
+        Xn = -(Tm @ Y)                                             # -T Y^T  (r x P);  Q = I - Y T Y^T, columns [Q1 | Q2]
+        Q1 = Y.T @ Xn[:, :r]
+        Q1[:r].diagonal().add_(1.0)                                # Q1 = E_1 - Y T Y_1^T  (P x r, orthonormal basis of range(L))
+        return Y, Xn, Q1
 
     # ---- tdvp.py:57-71 -------------------------------------------------------------------------------------------
     def transform_to_eigenbasis(self, S, F, EOdata=None):
@@ -788,6 +798,10 @@ class TDVP:
         factorisation asks for and products S0 v.  First call: planning (the host reads the rank and the number of block steps used);
         afterwards a static plan, checked one call later (as `_solve_lowrank_static`)."""
         world = mpi.get_comm_size()      # sharded samples: the O(P) moments, every 32-column panel and every S0 v are summed over the ranks
+        spectral = self._solver() != "cholesky"
+        if spectral and (self.diagonalShift > 1e-10 or self.useSNR):
+            raise NotImplementedError("matrixFree with the spectral solve: diagonalShift = 0 and useSNR = False only (a shifted S is not rank "
+                                      "deficient; the SNR needs the E~-weighted Gram)")
         jt = psi.jt_buffer_of(gradients) if psi is not None and hasattr(psi, "jt_buffer_of") else None
         if jt is None or jt[0].dtype != global_defs.tReal:
             raise NotImplementedError("matrixFree needs the engine's own fp64 parameter-major Jacobian buffer")
@@ -831,7 +845,7 @@ class TDVP:
                     raise NotImplementedError("matrixFree with frozenParameters")
                 dmax = diagS.max()
                 floor = float(self.svdTol) * dmax
-                D = diagS * float(self.diagonalShift) + floor
+                D = diagS * float(self.diagonalShift) + floor        # (Cholesky-type solve only)
                 scal = torch.stack([Em, Eabs, E2 - Em * Em, E2, torch.zeros_like(Em), dmax, floor, torch.zeros_like(Em)])
                 cand_off = nat.lib().vmcpde_lowrank_candidates_byte_offset(P)
                 cand_ptr = nat.C.c_void_p(w["ws"].data_ptr() + cand_off)                       # the step's int32[32] candidate rows
@@ -878,7 +892,7 @@ class TDVP:
                     if not done or r < 1:
                         raise FloatingPointError(f"matrixFree: S is not rank deficient within the cap (rank >= {r} of {P}); use the assembled path")
                     rmax = _round_up(r + 40, 128)
-                    self._mf_plan = dict(rmax=rmax, nsteps=steps + 1, rank=r, event=None, host=torch.zeros(2, dtype=torch.int32).pin_memory())
+                    self._mf_plan = dict(rmax=rmax, nsteps=steps + 3, rank=r, event=None, host=torch.zeros(2, dtype=torch.int32).pin_memory())
                     mode = "planning"
                 else:
                     for _ in range(plan["nsteps"]):
@@ -894,6 +908,74 @@ class TDVP:
                 pass
             self._replicated = self._Section(self, "replicated")
             self._replicated.__enter__()
+
+            def s0(v):                                               # J^T (J v) / N - m (m.v): two passes over J (+ a P-vector all-reduce)
+                z = Jv @ (v @ Jv)
+                if world > 1:
+                    mpi.allreduce_sum_(z)
+                return z / Ntot - mean * (mean @ v)
+
+            if spectral:
+                # the reference's spectral solve on the same factor: exact rank (one host read), Householder basis Q1 of range(L),
+                # Q1^T S Q1 = (J Q1)^T (J Q1) / N - (Q1^T m)(Q1^T m)^T from ONE more pass over J, Ritz pairs, V = [Q2 | Q1 W]
+                def read_state():
+                    w["state_host"].copy_(w["state"], non_blocking=True)
+                    torch.cuda.current_stream(device).synchronize()
+                    return int(w["state_host"][0]), int(w["state_host"][1])
+
+                r, fin = read_state()
+                extra = 0
+                while not fin and r < rmax and extra < 16:            # (the plan's steps did not suffice for these samples: go on, the host is here anyway)
+                    block_step()
+                    block_step()
+                    nat.call("vmcpde_lowrank_step", None, P, tol, rmax, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), wsb,
+                             nat.stream())
+                    extra += 2
+                    r, fin = read_state()
+                if extra:
+                    self._mf_plan["nsteps"] += extra
+                if not fin or r < 1:
+                    self._mf_plan = None
+                    raise StaticPlanOutdated(f"matrixFree: the factorisation did not finish within its plan (rank {r}); the next call plans anew")
+                self._lowrank_last_rank = r
+                Y, Xn, Q1 = self._lowrank_range_basis(w, P, r, device)
+                Z = Q1.T @ Jv                                        # r x n
+                ckn = 2048 if n % 2048 == 0 else (128 if n % 128 == 0 else 0)
+                if ckn:                                              # (K = n, result r x r: batched over sample chunks to fill the chip)
+                    Z3 = Z.view(r, n // ckn, ckn).permute(1, 0, 2)
+                    Tm = torch.bmm(Z3, Z3.transpose(1, 2)).sum(0)
+                else:
+                    Tm = Z @ Z.T
+                if world > 1:
+                    mpi.allreduce_sum_(Tm)
+                q = Q1.T @ mean
+                Tm = Tm / Ntot - torch.outer(q, q)
+                wv, W = torch.linalg.eigh(0.5 * (Tm + Tm.T))
+                self.ev, self.V = self._lowrank_assemble(Y, Xn, Q1 @ W, wv, r, P, device)
+                self.spectralInfo = dict(engine="matrix-free", mode=mode, rank=r, block_steps=self._mf_plan["nsteps"])
+                Fc = F.contiguous()
+                self.VtF = torch.empty(P, dtype=global_defs.tReal, device=device)
+                nat.call("vmcpde_gemv", nat.ptr(self.V), P, P, P, 1, nat.ptr(Fc), nat.ptr(self.VtF), nat.stream())
+                coef = torch.empty(P, dtype=global_defs.tReal, device=device)
+                nat.call("vmcpde_pinv_coeffs", nat.ptr(self.ev), nat.ptr(self.VtF), None, P, float(self.svdTol), float(self.snrTol), nat.ptr(coef),
+                         nat.stream())
+                update = torch.empty(P, dtype=global_defs.tReal, device=device)
+                nat.call("vmcpde_gemv", nat.ptr(self.V), P, P, P, 0, nat.ptr(coef), nat.ptr(update), nat.stream())
+                S0u = s0(update)
+                out = torch.empty(4, dtype=global_defs.tReal, device=device)
+                nat.call("vmcpde_tdvp_diagnostics", nat.ptr(update), nat.ptr(S0u), nat.ptr(Fc), nat.ptr(diagS.contiguous()), P, 0.0, None, nat.ptr(scal),
+                         None, nat.ptr(out), nat.stream())
+                self._replicated.__exit__(None, None, None)
+                self._record_guard(out, False)
+                self.ElocMean, self.ElocMeanAbs, self.ElocVar = scal[0], scal[1], scal[2]
+                self._scal, self._floor = scal, None
+                self.F0, self.S0 = F, None
+                self._lazy = dict(JT=JT, ldj=ldj, P=P, n=n, Ntot=Ntot, e=e, logp=logProbs.reshape(-1), b=None, mean=mean, Emean=scal[0],
+                                  chol_border=False, owner=psi, gen=psi.workspace_generation(n))
+                self._SExp = self._rhoVar = self._snr = self._S = None
+                self.cholInfo = None
+                return update, out[0], out[1]
+
             rmax = self._mf_plan["rmax"]
             if w.get("G") is None or w["G"].shape[0] != rmax:
                 need = nat.lib().vmcpde_chol_workspace_bytes(rmax)
@@ -921,12 +1003,6 @@ class TDVP:
                 nat.call("vmcpde_chol_solve", nat.ptr(G), rmax, rmax, nat.ptr(t1), nat.ptr(t2), nat.ptr(gws), need, nat.stream())
                 return torch.addcdiv(y, LTr.T @ t2, D, value=-1.0)
 
-            def s0(v):                                               # J^T (J v) / N - m (m.v): two passes over J (+ a P-vector all-reduce)
-                z = Jv @ (v @ Jv)
-                if world > 1:
-                    mpi.allreduce_sum_(z)
-                return z / Ntot - mean * (mean @ v)
-
             u = minv(F)
             u = u + minv(F - s0(u) - D * u)
             update = u.contiguous()
@@ -952,7 +1028,7 @@ class TDVP:
 
     # ---- tdvp.py:73-94 -------------------------------------------------------------------------------------------
     def solve(self, Eloc, gradients, logProbs, psi=None):
-        if self.matrixFree and self._solver() == "cholesky":
+        if self.matrixFree:
             return self._solve_matrix_free(Eloc, gradients, logProbs, psi)
         F = self.get_tdvp_equation(Eloc, gradients, logProbs, psi=psi)
         b = self._lazy["b"]
