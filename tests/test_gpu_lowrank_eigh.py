@@ -427,7 +427,9 @@ def test_matrix_free_step_matches_the_assembled_one(headline_net):
         u, _ = tm(th.cuda(), 0.0, vs, ep, **kw)
         tm.check()
         assert tm.choleskyInfo["engine"] == "matrix-free" and tm.choleskyInfo["mode"] == ("planning" if call == 0 else "static"), tm.choleskyInfo
-        assert tm.S0 is None
+        assert tm._S0 is None and tm._S0_lazy                           # nothing assembled by the call ...
+        if call == 2:                                                   # ... the attribute forms it on first access, from the retained Jacobian
+            assert float((tm.S0 - S).abs().max()) < 1e-12 * float(S.abs().max()) and tm._S0 is not None
         assert float(torch.linalg.norm(tm.F0 - F)) < 1e-12 * nF
         du = u - u_d
         assert float(torch.linalg.norm(S @ du + D * du)) < 1e-10 * nF, float(torch.linalg.norm(S @ du + D * du)) / nF
@@ -453,7 +455,7 @@ def test_matrix_free_spectral_solve_matches_the_assembled_one(headline_net):
     for call in range(2):
         u, _ = tm(th.cuda(), 0.0, vs, ep, **kw)
         tm.check()
-        assert tm.spectralInfo["engine"] == "matrix-free" and tm.S0 is None and 1 <= tm.spectralInfo["rank"] < P // 6
+        assert tm.spectralInfo["engine"] == "matrix-free" and tm._S0 is None and 1 <= tm.spectralInfo["rank"] < P // 6
         assert float((tm.ev - ev_d).abs().max()) < 1e-12 * lmax
         Vm = tm.V
         assert float((Vm.T @ Vm - torch.eye(P, dtype=torch.float64, device="cuda")).abs().max()) < 1e-13

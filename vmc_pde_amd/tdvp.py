@@ -111,7 +111,7 @@ class TDVP:
                                   # factor of S = <J^T J> needs only diag(S) and the 32 columns a block step pivots on, which are formed from
                                   # the Jacobian on demand (csrc/eig.hip::colpanel_kernel, one pass over J per block step), and S0 u for the
                                   # refinement and the diagnostics is J^T (J u) / N - m (m.u): ~20 passes over J instead of N P^2 flop.
-                                  # `S0` is then not available; a full-rank S (no plan within the rank cap) raises.
+                                  # `S0` is then formed on first access; a full-rank S (no plan within the rank cap) raises.
     residualBound: float = 1e-6   # Cholesky path: a solver residual above this (or a NaN) is treated as a failed factorisation
     centering: str = "auto"       # "exact": global means before the Gram (an extra pass over J, + one tiny all-reduce when sharded)
                                   # "lagged": previous call's global mean as shift -> one pass, a single all-reduce per step
@@ -160,6 +160,7 @@ class TDVP:
         self._c_prev = None
         self._lazy = None
         self._SExp = self._rhoVar = self._snr = self._S = None
+        self._S0, self._S0_lazy = None, False
         self.ev = self.V = self.VtF = None
         self._ratio_host = self._ratio_event = None
         self._uncentred_ok = False
@@ -397,26 +398,40 @@ class TDVP:
 
     def _weighted_gram(self, w):
         """(1/N) sum_n w_n^2 O~_n O~_n^T over all ranks from the retained Jacobian (w = logp: tdvp.py:33,47; w = E~: the
-        second moment behind rhoVar, tdvp.py:68-70)."""
+        second moment behind rhoVar, tdvp.py:68-70; w = None: S0 itself, for the `S0` attribute after a matrix-free call)."""
         z = self._lazy
         if z["owner"] is not None and z["owner"].workspace_generation(z["n"]) != z["gen"]:
             raise RuntimeError("SExp / rhoVar / snr are computed lazily from the Jacobian of the last TDVP call, but the VarState "
                                "has evaluated another batch of the same size since (its workspace was overwritten): read these "
                                "attributes before calling psi(...), psi.hessian or psi.evaluate again")
-        b, P = z["b"], z["P"]
-        tmp = torch.zeros(b["npk"], dtype=global_defs.tReal, device=w.device)
-        out = torch.zeros((b["Ppad"], b["Ppad"]), dtype=global_defs.tReal, device=w.device)
-        zero = torch.zeros(P, dtype=global_defs.tReal, device=w.device)
-        with torch.cuda.device(w.device):
-            self._gram(b, z["JT"], z["ldj"], P, z["n"], z["mean"], w.contiguous(), tmp)
+        P, device = z["P"], z["JT"].device
+        b = z["b"] if z["b"] is not None else self._buffers(P, device)     # (a matrix-free call has made none)
+        tmp = torch.zeros(b["npk"], dtype=global_defs.tReal, device=device)
+        out = torch.zeros((b["Ppad"], b["Ppad"]), dtype=global_defs.tReal, device=device)
+        zero = torch.zeros(P, dtype=global_defs.tReal, device=device)
+        with torch.cuda.device(device):
+            self._gram(b, z["JT"], z["ldj"], P, z["n"], z["mean"], None if w is None else w.contiguous(), tmp)
             mpi.allreduce_sum_(tmp)
             nat.call("vmcpde_gram_finalize", nat.ptr(tmp), nat.ptr(zero), None, None, None, None, None, P, z["Ntot"], 0.0, None, nat.ptr(out),
                      b["Ppad"], None, 0, None, None, nat.stream())
         if self.frozenParameters is not None:
-            idx = self._frozen_index(w.device)
+            idx = self._frozen_index(device)
             out[idx, :] = 0.0
             out[:, idx] = 0.0
         return out[:P, :P]
+
+    @property
+    def S0(self):
+        """tdvp.py:46.  After a matrix-free call (which never assembles it) it is formed on first access from the retained Jacobian."""
+        if self._S0 is None and getattr(self, "_S0_lazy", False):
+            self._S0 = self._weighted_gram(None)
+            self._S0_lazy = False
+        return self._S0
+
+    @S0.setter
+    def S0(self, value):
+        self._S0 = value
+        self._S0_lazy = False
 
     @property
     def S(self):
@@ -970,6 +985,7 @@ class TDVP:
                 self.ElocMean, self.ElocMeanAbs, self.ElocVar = scal[0], scal[1], scal[2]
                 self._scal, self._floor = scal, None
                 self.F0, self.S0 = F, None
+                self._S0_lazy = True
                 self._lazy = dict(JT=JT, ldj=ldj, P=P, n=n, Ntot=Ntot, e=e, logp=logProbs.reshape(-1), b=None, mean=mean, Emean=scal[0],
                                   chol_border=False, owner=psi, gen=psi.workspace_generation(n))
                 self._SExp = self._rhoVar = self._snr = self._S = None
@@ -1018,6 +1034,7 @@ class TDVP:
         self.ElocMean, self.ElocMeanAbs, self.ElocVar = scal[0], scal[1], scal[2]
         self._scal, self._floor = scal, floor_t
         self.F0, self.S0 = F, None
+        self._S0_lazy = True
         self._lazy = dict(JT=JT, ldj=ldj, P=P, n=n, Ntot=Ntot, e=e, logp=logProbs.reshape(-1), b=None, mean=mean, Emean=scal[0], chol_border=False,
                           owner=psi, gen=psi.workspace_generation(n))
         self._SExp = self._rhoVar = self._snr = self._S = None
