@@ -65,6 +65,8 @@ typedef struct {
 /* constants of one EvolutionEquation (evolutionEq.py:61-77); unused fields are ignored by `kind` */
 typedef struct {
   int32_t kind;     /* VMCPDE_EQ_* */
+  int32_t coupled;  /* hamiltonian fields: 1 = the ring-coupled H(x, coupled=True) of evolutionEq.py:33-38 (the reference only ever
+                       evaluates the default, 0); sits in what was the alignment gap after `kind`, so the layout is that of ABI 3 */
   double D;         /* diffusion, diffusion_drift */
   double mu;        /* diffusion_drift */
   double m, omega, lam, T, gamma; /* hamiltonian fields; T is also the period of advection_paper */

@@ -400,8 +400,13 @@ def velocity_field_MLPaper(params, coord, t):
 
 
 def velocity_field_hamiltonian(params, coord, t):
-    """evolutionEq.py:30-45 (jax.grad(H) with the default coupled=False)."""
+    """evolutionEq.py:30-45.  The reference evaluates jax.grad(H) with the default coupled=False; the ring-coupled branch
+    (:33-38) is restated too and taken when params carries "coupled": True."""
     def H(x):
+        if params.get("coupled", False):
+            xs, ps = x[0::2], x[1::2]
+            return (params["m"] * params["omega"] ** 2 / 2 * torch.sum((xs - torch.roll(xs, 1)) ** 2)
+                    + torch.sum(ps ** 2) / (2.0 * params["m"]) + params["lam"] * torch.sum(xs ** 4))
         return (params["m"] * params["omega"] ** 2 / 2 * torch.sum(x[0::2] ** 2)
                 + torch.sum(x[1::2] ** 2) / (2.0 * params["m"]) + params["lam"] * torch.sum(x[0::2] ** 4))
     grads = grad(H)(coord)

@@ -218,12 +218,15 @@ def test_mcmc_sampler_stationary_density():
     assert abs(r.mean() - expect) < 0.01 and r.max() <= 1.0 + 1e-12
 
 
-EQS = ["diffusion", "diffusion_drift", "diffusion_anisotropic", "advection_hamiltonian", "advection_hamiltonian_wDiss"]
+EQS = ["diffusion", "diffusion_drift", "diffusion_anisotropic", "advection_hamiltonian", "advection_hamiltonian_wDiss",
+       "advection_hamiltonian+ring", "advection_hamiltonian_wDiss+ring"]
 
 
 @pytest.mark.parametrize("name", EQS)
 def test_rhs_parity(name):
+    """"+ring": the coupled branch of the Hamiltonian (evolutionEq.py:33-38), which the reference defines and never selects."""
     import vmc_pde_amd as V
+    name, _, ring = name.partition("+")
     cfg = (6, 2, (3,), "Gauss", "different_add")
     spec, th, z = _setup(cfg, 50)
     vo = O.VarStateOracle(spec, th)
@@ -236,6 +239,9 @@ def test_rhs_parity(name):
     if "hamiltonian" in name:
         eo.eqParams[name]["params"]["lam"] = 0.1      # BASELINE C2: anharmonic drift
         ep.eqParams[name]["params"]["lam"] = 0.1
+        if ring:
+            eo.eqParams[name]["params"]["coupled"] = True
+            ep.eqParams[name]["params"]["coupled"] = True
     E_o, J_o, lp_o = eo(vo, x, 0.3)
     E_p, J_p, lp_p = ep(vs, x, 0.3)
     assert E_p.shape == (1, 50)

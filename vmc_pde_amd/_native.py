@@ -42,7 +42,7 @@ class ModelDesc(C.Structure):
 
 
 class EqConsts(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("D", C.c_double), ("mu", C.c_double), ("m", C.c_double), ("omega", C.c_double),
+    _fields_ = [("kind", C.c_int32), ("coupled", C.c_int32), ("D", C.c_double), ("mu", C.c_double), ("m", C.c_double), ("omega", C.c_double),
                 ("lam", C.c_double), ("T", C.c_double), ("gamma", C.c_double)]
 
 

@@ -276,11 +276,19 @@ __global__ void rhs_kernel(vmcpde_eq_consts c, int d, const double* __restrict__
     } break;
     case VMCPDE_EQ_ADVECTION_HAMILTONIAN:
     case VMCPDE_EQ_ADVECTION_HAMILTONIAN_WDISS: {
-      // v = kron(I,[[0,1],[-1,0]]) grad H, H = m w^2/2 sum x^2 + sum p^2/(2m) + lam sum x^4 (:30-45, uncoupled)
+      // v = kron(I,[[0,1],[-1,0]]) grad H, H = m w^2/2 sum x^2 + sum p^2/(2m) + lam sum x^4 (:39-42); with c.coupled the
+      // quadratic term is m w^2/2 sum (x_i - x_{i-1})^2 over the ring of positions (:33-38)
       double adv = 0.0;
+      const int np = d / 2;
       for (int i = 0; i + 1 < d; i += 2) {
         const double q = xn[i], p = xn[i + 1];
-        const double dHdq = c.m * c.omega * c.omega * q + 4.0 * c.lam * q * q * q;
+        double lin = q;
+        if (c.coupled) {
+          const int k = i / 2;
+          const double ql = xn[2 * (k == 0 ? np - 1 : k - 1)], qr = xn[2 * (k == np - 1 ? 0 : k + 1)];
+          lin = 2.0 * q - ql - qr;
+        }
+        const double dHdq = c.m * c.omega * c.omega * lin + 4.0 * c.lam * q * q * q;
         const double dHdp = p / c.m;
         adv += gn[i] * dHdp + gn[i + 1] * (-dHdq);
       }

@@ -66,6 +66,7 @@ class EvolutionEquation:
         else:
             p = e["params"]
             c.m, c.omega, c.lam = float(p["m"]), float(p["omega"]), float(p["lam"])
+            c.coupled = int(bool(p.get("coupled", False)))     # evolutionEq.py:33-38; the reference never passes True
             if self.name == "advection_hamiltonian_wDiss":
                 c.T, c.gamma = float(p["T"]), float(p["gamma"])
                 dirs = np.eye(d)[1::2]                         # momentum axes, evolutionEq.py:114
