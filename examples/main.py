@@ -4,7 +4,7 @@
     python examples/main.py [--mode mwe|diffusion|harmonicOsc|harmonicOsc_diff] [--t-end 0.05] [--samples 10000]
 
 Same objects, same call sequence, same printed diagnostics and `infos` keys as the reference; arrays are fp64 torch tensors
-on the GPU.  The `infos` record is written to <wdir>/infos.npz, and -- what the reference lacks -- the parameters are
+on the GPU.  The `infos` record is written to <wdir>/infos.npz (`--infos infos.hdf5`: the reference's HDF5 file, where h5py exists), and -- what the reference lacks -- the parameters are
 checkpointed every step to <wdir>/checkpoint.pt so a run can be resumed with --resume.
 """
 import argparse
@@ -43,7 +43,9 @@ def main():
     ap.add_argument("--diagonal-shift", type=float, default=0.0, help="tdvp.py:50-51: S += shift * diag(S)")
     ap.add_argument("--solver", default="auto", choices=["auto", "eigh", "cholesky"],
                     help="auto/eigh: the reference's spectral pseudo-inverse; cholesky: on-device regularised Cholesky (use with --diagonal-shift)")
-    ap.add_argument("--save-every", type=int, default=1, help="write infos.npz every this many steps (and at the end)")
+    ap.add_argument("--save-every", type=int, default=1, help="write the run record every this many steps (and at the end)")
+    ap.add_argument("--infos", default="infos.npz", help="file name of the run record in --wdir: *.npz (numpy), or *.hdf5 = the reference's "
+                                                         "infos.hdf5, one dataset per key (util.py:29-32; needs h5py)")
     ap.add_argument("--svd-tol", type=float, default=1e-11,
                     help="spectral cut-off / absolute floor; wide networks (P in the thousands) need ~1e-6 with --diagonal-shift 1e-4")
     ap.add_argument("--matrix-free", action="store_true",
@@ -124,9 +126,8 @@ def main():
                     "tdvp": tdvpEq.state_dict()}, tmp)
         os.replace(tmp, ckpt)
         if len(infos["times"]) % args.save_every == 0:
-            util.store_infos(wdir, infos)
-    util.store_infos(wdir, infos)                                                                                                          # main.py:209
-    print("wrote", os.path.join(wdir, "infos.npz"))
+            util.store_infos(wdir, infos, args.infos)
+    print("wrote", util.store_infos(wdir, infos, args.infos))                                                                              # main.py:209
 
 
 if __name__ == "__main__":

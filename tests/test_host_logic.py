@@ -205,3 +205,27 @@ def test_allreduce_payload_of_a_c4_step(lib_built):
         assert npk == nb * (nb + 1) // 2 * 128 * 128
         payload = (npk + 2 * P + 4) * 8
         assert payload == {4155: 73_597_904, 4213: 73_598_832, 16181: 1_065_612_144}[P]
+
+
+def test_store_infos_writes_the_run_record(tmp_path):
+    """util.py:29-32: one array per key, stacked over the steps.  .npz everywhere; the reference's infos.hdf5 where h5py exists, and a
+    loud error -- not a silently different file -- where it is asked for and missing."""
+    from vmc_pde_amd import util
+    infos = {"times": [0.0, 0.1, 0.2], "entropy": [torch.tensor(1.5), torch.tensor(1.25), torch.tensor(1.0)],
+             "ev": [torch.arange(4.0), torch.arange(4.0) + 1, torch.arange(4.0) + 2]}
+    path = util.store_infos(str(tmp_path), infos, "infos.npz")
+    rec = np.load(path)
+    assert path == os.path.join(str(tmp_path), "infos.npz") and sorted(rec.files) == ["entropy", "ev", "times"]
+    assert rec["ev"].shape == (3, 4) and rec["ev"][2, 3] == 5.0 and list(rec["entropy"]) == [1.5, 1.25, 1.0]
+    assert not [f for f in os.listdir(str(tmp_path)) if "tmp" in f]
+    try:
+        import h5py
+    except ImportError:
+        with pytest.raises(ImportError, match="h5py"):
+            util.store_infos(str(tmp_path), infos, "infos.hdf5")
+        assert util.store_infos(str(tmp_path), infos).endswith("infos.npz")
+        return
+    path = util.store_infos(str(tmp_path), infos)
+    assert path.endswith("infos.hdf5")
+    with h5py.File(path, "r") as f:
+        assert sorted(f.keys()) == ["entropy", "ev", "times"] and f["ev"][:].shape == (3, 4) and f["times"][2] == 0.2

@@ -19,15 +19,35 @@ def build_cov_matrix(L_para, L_diag, dim):
     return L @ L.T
 
 
-def store_infos(wdir, infos, name="infos.npz"):
+def store_infos(wdir, infos, name=None):
     """Run record of the driver loop (util.py:29-32): every key of `infos` becomes one array stacked over the steps.
-    Written as .npz -- h5py is not part of the image; `np.load(...)[key]` replaces `h5py.File(...)[key][:]`."""
+    `name` ending in ".hdf5" writes the reference's own file -- one HDF5 dataset per key, what its plotting scripts open
+    (visualization.py:285) -- and needs h5py; ".npz" writes the same arrays with numpy (`np.load(...)[key]` replaces
+    `h5py.File(...)[key][:]`).  Default: "infos.hdf5" where h5py is importable, else "infos.npz" (h5py is not part of this image).
+    Either file replaces the previous one atomically.  Returns the path written."""
     def as_numpy(v):
         return v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    arrays = {key: np.asarray([as_numpy(v) for v in series]) for key, series in infos.items()}
+    h5py = None
+    if name is None or name.endswith((".hdf5", ".h5")):
+        try:
+            import h5py
+        except ImportError:
+            if name is not None:
+                raise ImportError(f"store_infos(name={name!r}) needs h5py; pass a name ending in .npz or install h5py") from None
+    if name is None:
+        name = "infos.hdf5" if h5py is not None else "infos.npz"
     target = os.path.join(wdir, name)
-    tmp = target + ".tmp.npz"          # np.savez appends .npz to names without it
-    np.savez(tmp, **{key: np.asarray([as_numpy(v) for v in series]) for key, series in infos.items()})
+    if h5py is not None:
+        tmp = target + ".tmp"
+        with h5py.File(tmp, "w") as f:
+            for key, value in arrays.items():
+                f.create_dataset(key, data=value)
+    else:
+        tmp = target + ".tmp.npz"          # np.savez appends .npz to names without it
+        np.savez(tmp, **arrays)
     os.replace(tmp, target)
+    return target
 
 
 class Timings:
