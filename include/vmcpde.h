@@ -280,6 +280,15 @@ int64_t vmcpde_pivoted_cholesky_blocked_workspace_bytes(int32_t P);
 int vmcpde_pivoted_cholesky_blocked(const double* S, int64_t lds, int32_t P, double tol_rel, int32_t restart, int32_t n_blocks,
                                     int32_t max_rank, double* LT, int64_t ldl, int32_t* piv, int32_t* state, void* workspace,
                                     int64_t workspace_bytes, void* stream);
+/* Pivot hints for the blocked factorisation (and its matrix-free form below): the pivots piv[0 .. state[0]) of a FINISHED
+ * factorisation of a nearby matrix -- the previous TDVP step's S; the reference's loop solves a slowly moving sequence of them,
+ * tdvp.py:57-94 once per right-hand side -- become the preferred candidates of the factorisations started afterwards in this
+ * workspace: a block step takes the first 32 open entries of the list whose remaining diagonal entry qualifies NOW, always together
+ * with the largest remaining entry, and falls back to the usual choice when the list runs out.  Nothing else changes (pivoting inside
+ * the block, the 1/100 window, the stopping criterion), so S = L L^T + R holds as before whatever the list contains; what changes is how
+ * many candidates survive a block (~13 of 32 chosen by the diagonal alone, most of a hinted block) and with it the number of dependent
+ * block steps.  The list is copied into the workspace (piv may be reused at once) and stays armed until replaced; piv == NULL disarms. */
+int vmcpde_lowrank_hint(const int32_t* piv, const int32_t* state, int32_t P, void* workspace, int64_t workspace_bytes, void* stream);
 /* ---- EXPERIMENT: the same factorisation without an assembled S (matrix-free TDVP step, vmc_pde_amd/tdvp.py `matrixFree`) -------
  * S = J^T J / N - m m^T enters the pivoted factorisation only through its diagonal and the 32 columns a block step pivots on, so the
  * Jacobian is read once per block step instead of N P^2 flop:

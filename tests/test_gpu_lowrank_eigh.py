@@ -142,6 +142,74 @@ def test_blocked_pivoted_cholesky(P, per_decade):
     assert np.linalg.eigvalsh(S - LT2[:, :P].T @ LT2[:, :P]).min() > -1e-13 * d0
 
 
+def test_pivot_hints_change_the_candidates_and_nothing_else():
+    """vmcpde_lowrank_hint: the pivots of a finished factorisation as preferred candidates of the next one, on a nearby matrix -- the
+    same properties of the result in fewer block steps; a useless or hostile list (pivots of an unrelated matrix, rows out of range,
+    repeats) costs steps, never validity; disarmed, the factorisation is bit for bit the unhinted one."""
+    from vmc_pde_amd import _native as nat
+    P, cap = 1500, 600
+    S1 = _graded_psd(P, 12.0, 4096, seed=21)
+    rng = np.random.default_rng(22)
+    E = rng.standard_normal((P, 40)) * np.sqrt(1e-8 * np.diag(S1).max())
+    S2 = S1 + E @ E.T                                                      # a nearby PSD matrix: a rank-40 term at 1e-8 of the scale
+    S3 = _graded_psd(P, 12.0, 4096, seed=99)                                                                 # an unrelated one
+    ldl = (P + 63) // 64 * 64
+    LT = torch.zeros((cap, ldl), dtype=torch.float64, device="cuda")
+    piv = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    wsb = nat.lib().vmcpde_pivoted_cholesky_blocked_workspace_bytes(P)
+    ws = torch.zeros(wsb // 8, dtype=torch.float64, device="cuda")
+
+    def factor(S, hint=None):
+        """hint: None = leave the workspace's list as it is; False = disarm; (piv, state) tensors = arm with them"""
+        Sd = torch.from_numpy(S).cuda()
+        if hint is False:
+            nat.call("vmcpde_lowrank_hint", None, None, P, nat.ptr(ws), wsb, nat.stream())
+        elif hint is not None:
+            nat.call("vmcpde_lowrank_hint", nat.ptr(hint[0]), nat.ptr(hint[1]), P, nat.ptr(ws), wsb, nat.stream())
+        LT.zero_()
+        nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(Sd), P, P, 1e-14, 1, 60, cap, nat.ptr(LT), ldl, nat.ptr(piv), nat.ptr(state), nat.ptr(ws),
+                 wsb, nat.stream())
+        torch.cuda.synchronize()
+        r, done, steps = int(state[0]), int(state[1]), int(ws[:4].view(torch.int32)[7])
+        L = LT[:r, :P].cpu().numpy().T
+        pv = piv[:r].cpu().numpy()
+        d0 = np.diag(S).max()
+        R = S - L @ L.T
+        assert done == 1 and 0 < r < cap and len(set(pv.tolist())) == r and pv.min() >= 0 and pv.max() < P
+        assert np.diag(R).max() < 1.2e-14 * d0 and np.abs(R).max() < 1.2e-14 * d0 and np.diag(R).min() > -1e-14 * d0
+        for k in range(r):
+            assert L[pv[k], k] > 0.0 and np.all(L[pv[k], k + 1:] == 0.0)
+        return r, steps, LT[:r].clone(), piv[:r].clone()
+
+    r1, steps1, LT1, piv1 = factor(S1, hint=False)
+    assert steps1 >= r1 // 20
+    # (these random-basis matrices have no correlated neighbours that collapse inside a block, so the unhinted yield is high already --
+    # the step count of the model's own S is asserted in test_lowrank_cholesky_solve_matches_the_dense_factorisation)
+    r1h, steps1h, _, _ = factor(S1, hint=(piv, state))                    # its own pivots
+    assert abs(r1h - r1) <= max(4, r1 // 20) and steps1h <= steps1, (steps1, steps1h)
+    r2h, steps2h, _, _ = factor(S2, hint=(piv, state))                    # the nearby matrix with the list of the last factorisation
+    r2, steps2, _, _ = factor(S2, hint=False)
+    assert abs(r2h - r2) <= max(4, r2 // 20) and steps2h <= steps2, (steps2, steps2h)
+    # the list of an unrelated matrix: valid result (checked inside), never more than a few steps beyond the unhinted count
+    r3, steps3, _, _ = factor(S3, hint=False)
+    factor(S1, hint=False)
+    r3h, steps3h, _, _ = factor(S3, hint=(piv, state))
+    assert abs(r3h - r3) <= max(4, r3 // 20) and steps3h <= steps3 + max(4, steps3 // 2), (steps3, steps3h)
+    # a hostile list: rows out of range, negative, repeated
+    bad = torch.tensor([5, 5, 5, -3, P, P + 7, 2 ** 30, 17, 17, 0] * 20, dtype=torch.int32, device="cuda")
+    bad_state = torch.tensor([bad.numel(), 1], dtype=torch.int32, device="cuda")
+    rb, stepsb, _, _ = factor(S1, hint=(bad, bad_state))
+    assert abs(rb - r1) <= max(4, r1 // 20)
+    # disarmed: bit for bit the first factorisation
+    r1b, steps1b, LT1b, piv1b = factor(S1, hint=False)
+    assert r1b == r1 and steps1b == steps1 and torch.equal(piv1b, piv1) and torch.equal(LT1b, LT1)
+    # an uninitialised workspace carries no hint (the armed flag is a magic word)
+    ws.view(torch.int32)[4:8] = torch.tensor([12345, 1 << 20, 7, 3], dtype=torch.int32, device="cuda")
+    r1c, _, LT1c, piv1c = factor(S1)
+    assert r1c == r1 and torch.equal(piv1c, piv1) and torch.equal(LT1c, LT1)
+
+
 def test_householder_rows_against_numpy():
     from vmc_pde_amd import _native as nat
     rng = np.random.default_rng(2)
@@ -314,6 +382,8 @@ def test_lowrank_cholesky_solve_matches_the_dense_factorisation(headline_net, mo
     # the calls after the first run in static mode (no host read): same system, same solution; the plan is checked one call later
     tp = out["lowrank"][6]
     assert tp.choleskyInfo["mode"] == "planning" and tp._chol_static is not None and tp._chol_static["rmax"] % 128 == 0
+    steps_hinted = []
+    steps_planned = tp._steps_used(tp._buf_lr[next(iter(tp._buf_lr))]["head_host"])      # the first call had no list
     for rep in range(3):
         u, _ = tp(th.cuda(), 0.0, vs, ep, **kw)
         tp.check()
@@ -321,7 +391,18 @@ def test_lowrank_cholesky_solve_matches_the_dense_factorisation(headline_net, mo
         du = u - u_d
         assert float(torch.linalg.norm(S @ du + D * du)) < 1e-11 * nF and float(tp.solverResidual) < 1e-12
         if rep:
-            assert int(tp._chol_static["host"][1]) == 1 and int(tp._chol_static["host"][0]) == tp.choleskyInfo["planned_rank"]
+            assert int(tp._chol_static["host"][1]) == 1 and abs(int(tp._chol_static["host"][0]) - tp.choleskyInfo["planned_rank"]) <= 8
+            # pivot hints: the previous call's pivots as candidates -- the same matrix here -- take about 2/3 of the unhinted block steps
+            steps_hinted.append(tp._steps_used(tp._chol_static["head"]))
+    assert steps_planned >= 12 and max(steps_hinted) <= (3 * steps_planned) // 4, (steps_planned, steps_hinted)
+    # ... and without them (pivotHints=False) every call takes the unhinted count and returns the same solution
+    tn = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine="lowrank", pivotHints=False)
+    for rep in range(3):
+        un, _ = tn(th.cuda(), 0.0, vs, ep, **kw)
+        tn.check()
+    assert tn.choleskyInfo["mode"] == "static" and tn._steps_used(tn._chol_static["head"]) == steps_planned
+    du = un - u_d
+    assert float(torch.linalg.norm(S @ du + D * du)) < 1e-11 * nF and float(tn.solverResidual) < 1e-12
     # the plan is checked one call later: a rank within 32 columns of the pad makes the next call plan anew
     tp._chol_static["host"][0] = tp._chol_static["rmax"] - 20
     u, _ = tp(th.cuda(), 0.0, vs, ep, **kw)
@@ -332,8 +413,10 @@ def test_lowrank_cholesky_solve_matches_the_dense_factorisation(headline_net, mo
     u, _ = tp(th.cuda(), 0.0, vs, ep, **kw)
     assert tp.choleskyInfo["mode"] == "static"
     tp.check()
+    tp.pivotHints = False            # (four HINTED block steps reach the 128 columns of this plan and a residual just inside the bound)
     tp._chol_static["rmax"], tp._chol_static["nsteps"] = 128, 4
-    tp._chol_static["host"][0] = 50                      # (as if the previous call had fitted this plan)
+    tp._chol_static["host"][0] = 50                      # (as if the previous call had fitted this plan ...
+    tp._chol_static["head"].view(torch.int32)[7] = 1     #  ... in one block step: 1 + 3 to spare)
     u, _ = tp(th.cuda(), 0.0, vs, ep, **kw)
     assert tp.choleskyInfo["mode"] == "static" and tp.choleskyInfo["rmax"] == 128
     with pytest.raises(FloatingPointError, match="outgrew the static plan"):
@@ -349,12 +432,14 @@ def test_lowrank_cholesky_solve_matches_the_dense_factorisation(headline_net, mo
     y_d, _, _ = ref_step.step(0.0, V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine="dense"), th.cuda(), evolutionEq=ep, psi=vs, **{k: v for k, v in kw.items() if k != "timings"}, timings=None)
     tp._chol_static["rmax"], tp._chol_static["nsteps"] = 128, 4
     tp._chol_static["host"][0] = 50
+    tp._chol_static["head"].view(torch.int32)[7] = 1
     st = FixedStepper(timeStep=1e-9, mode="Heun", maxStep=1e-9, increase_fac=1.0)
     y_l, dt_l, _ = st.step(0.0, tp, th.cuda(), evolutionEq=ep, psi=vs, **{k: v for k, v in kw.items() if k != "timings"}, timings=None)
     assert dt_l == 1e-9 and tp.choleskyInfo["mode"] in ("planning", "static") and tp._chol_static["rmax"] >= 256
     assert float(torch.linalg.norm((y_l - th.cuda()) - (y_d - th.cuda())) / torch.linalg.norm(y_d - th.cuda())) < 1e-4
     tp._chol_static["rmax"], tp._chol_static["nsteps"] = 128, 4
     tp._chol_static["host"][0] = 50
+    tp._chol_static["head"].view(torch.int32)[7] = 1
     u_sync, info_sync = tp(th.cuda(), 0.0, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None, integrals=False)     # observables on: synchronous
     assert tp.choleskyInfo["mode"] == "planning" and float(tp.solverResidual) < 1e-12 and "entropy" in info_sync
     du = u_sync - u_d

@@ -21,6 +21,7 @@ else:
                   int8Gram=os.environ.get("INT8_GRAM", "0") == "1",      # INT8_GRAM=1: the S-build on the int8 matrix pipe (experiment)
                   matrixFree=os.environ.get("MATRIX_FREE", "0") == "1")  # MATRIX_FREE=1: S never assembled (experiment)
 engines, ranks = {}, []
+modes, bsteps = {}, []
 stepper = V.FixedStepper(timeStep=1e-4, mode="Heun", maxStep=1e-2, increase_fac=1.3)
 t, n, t0 = 0.0, 0, time.perf_counter()
 next_print = 0.5
@@ -30,6 +31,11 @@ while t < T_END:
     vs.set_parameters(dp)
     t += dt
     n += 1
+    if tdvp.choleskyInfo is not None:
+        key = f"{tdvp.choleskyInfo.get('engine')}/{tdvp.choleskyInfo.get('mode', '-')}"
+        modes[key] = modes.get(key, 0) + 1
+        if "block_steps" in tdvp.choleskyInfo:
+            bsteps.append(tdvp.choleskyInfo["block_steps"])
     if tdvp.spectralInfo is not None:
         engines[tdvp.spectralInfo["engine"]] = engines.get(tdvp.spectralInfo["engine"], 0) + 1
         if "rank" in tdvp.spectralInfo:
@@ -44,3 +50,6 @@ while t < T_END:
         next_print += 0.5
 if engines:
     print(f"spectral engine of the last right-hand side of each step: {engines}; numerical rank {min(ranks) if ranks else '-'} .. {max(ranks) if ranks else '-'}", flush=True)
+if modes:
+    print(f"regularised solve of the last right-hand side of each step: {modes}; block steps launched {min(bsteps) if bsteps else '-'} .. "
+          f"{max(bsteps) if bsteps else '-'} (mean {np.mean(bsteps) if bsteps else 0:.1f}); pivot hints {os.environ.get('VMCPDE_PIVOT_HINTS', '1')}", flush=True)

@@ -27,7 +27,13 @@ constexpr double NEG_INF = -__builtin_huge_val();
 struct PivWork {            // device-side bookkeeping of one factorisation (head of the workspace)
   double d0;                // largest diagonal entry of S: the reference of the stopping criterion
   double trace_left;        // sum of the positive remaining diagonal entries after the last completed step
+  // blocked form only: the pivots of an earlier factorisation as preferred candidates (vmcpde_lowrank_hint)
+  int hint_magic;           // HINT_MAGIC while a hint is armed (anything else: none -- an uninitialised workspace has no hint)
+  int hint_n;               // entries of the hint list
+  int hint_cur;             // entries before this one are pivots already or below the tolerance
+  int steps;                // block steps of this factorisation that added columns
 };
+constexpr int HINT_MAGIC = 0x48494e54;
 
 // (value, index) arg max over a wave, ties to the lower index; every lane returns the result
 __device__ __forceinline__ void wave_argmax(double& v, int& idx) {
@@ -48,7 +54,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 // d = diag(S); per-workgroup candidates (largest entry, its row, sum of the positive entries) into candidate buffer 0
 __global__ __launch_bounds__(PC_ROWS) void pivchol_init_kernel(const double* __restrict__ S, int64_t lds, int P, double* __restrict__ d,
                                                                double* __restrict__ cand_val, int* __restrict__ cand_idx,
-                                                               double* __restrict__ cand_sum, int32_t* __restrict__ state, int two) {
+                                                               double* __restrict__ cand_sum, int32_t* __restrict__ state, int two,
+                                                               PivWork* __restrict__ work) {
   const int i = (int)blockIdx.x * PC_ROWS + (int)threadIdx.x;
   double mine = NEG_INF;
   if (i < P) {
@@ -79,7 +86,11 @@ __global__ __launch_bounds__(PC_ROWS) void pivchol_init_kernel(const double* __r
       cand_sum[2 * blockIdx.x + 1] = 0.0;
     }
   }
-  if (threadIdx.x == 0 && blockIdx.x == 0) { state[0] = 0; state[1] = 0; }
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    state[0] = 0;
+    state[1] = 0;
+    if (work) { work->hint_cur = 0; work->steps = 0; }
+  }
 }
 
 // One step of the pivoted factorisation.  state[0] = columns completed, state[1] = 1 once the stopping criterion has been met (every
@@ -213,6 +224,7 @@ struct PivDesc {             // written by workgroup 0 of the panel launch, read
   double top;                // largest remaining diagonal entry at the start of the step
   int k, bsel;
   int C[PB];
+  int newcur;                // the hint cursor after this step's selection (committed by the factor launch)
 };
 
 __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* __restrict__ S, int64_t lds, int P, double tol_rel, int max_rank,
@@ -220,7 +232,8 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
                                                                   const double* __restrict__ cand_val, const int* __restrict__ cand_idx,
                                                                   const double* __restrict__ cand_sum, int nblk, double* __restrict__ AP,
                                                                   PivDesc* __restrict__ desc, int32_t* __restrict__ state,
-                                                                  PivWork* __restrict__ work, int phase, const double* __restrict__ Scol) {
+                                                                  PivWork* __restrict__ work, int phase, const double* __restrict__ Scol,
+                                                                  const double* __restrict__ d, const int* __restrict__ hint) {
   // phase 2: selection and panel from the matrix S (the usual step).  The matrix-free form (S never assembled: its columns are formed
   // from the Jacobian on demand) splits a step: phase 0 = selection only (one workgroup; the caller then forms the chosen columns
   // Scol[m][i] = S[C_m][i]), phase 1 = the panel from Scol with the selection read back from `desc`.
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
   __shared__ double Wt[PBK][PB];
   __shared__ double red[3][PC_ROWS][17];
   __shared__ int s_C[PB];
-  __shared__ int s_bsel, s_k, s_done;
+  __shared__ int s_bsel, s_k, s_done, s_newcur;
   __shared__ double s_sum, s_top;
   const int t = threadIdx.x, lane = t & 63;
   const int slice = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -259,36 +272,94 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
     wave_argmax(top, topi);
     const double d0 = (k == 0) ? top : work->d0;
     const int room = (max_rank - k < PB) ? (max_rank - k) : PB;
-    int bsel = 0;
+    int bsel = 0, newcur = work->hint_cur;
     if (top > tol_rel * d0 && room > 0) {
-      double thr = fmax(tol_rel * d0, PB_THETA * top);
+      const double floor_v = tol_rel * d0;
+      double thr = fmax(floor_v, PB_THETA * top);
       const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-      for (int tries = 0; tries < 20; ++tries) {
-        int count = 0;
-        for (int q0 = 0; q0 < ncand; q0 += 64) {
-          const int q = q0 + lane;
-          count += __popcll(__ballot(q < ncand && cv[q] >= thr && cv[q] > tol_rel * d0));
+      // (a) a hint list (the pivots of an earlier factorisation of a nearby matrix, in their order): its first open entries that
+      // qualify NOW -- current remaining diagonal >= thr -- are the candidates.  Picked by the remaining diagonal alone, two per
+      // 64-row block, about 13 of 32 candidates survive the block (neighbours collapse once one of them is eliminated); earlier pivots
+      // were each new information given their predecessors and mostly still are.  Only the CHOICE of candidates changes: acceptance
+      // inside the block, the PB_THETA window and the stopping criterion are those of the unhinted step, and the largest remaining
+      // entry is always among the candidates.  The cursor moves past the leading entries that can never qualify again.
+      int nh = 0;
+      bool has_top = false;
+      int hn = (hint && work->hint_magic == HINT_MAGIC) ? work->hint_n : 0;
+      if (hn > P) hn = P;
+      if (hn > 0) {
+        int cur = newcur < 0 ? 0 : newcur;
+        bool lead = true;
+        for (int w0 = cur; w0 < hn && nh < room && w0 < cur + 256; w0 += 64) {
+          const int q = w0 + lane;
+          const int row = (q < hn) ? hint[q] : -1;
+          const bool valid = row >= 0 && row < P;
+          const double dv = valid ? d[row] : NEG_INF;
+          const bool alive = valid && dv > floor_v;
+          const bool take = alive && dv >= thr;
+          const unsigned long long mask = __ballot(take);
+          const int pos = nh + __popcll(mask & below);
+          if (take && pos < room) s_C[pos] = row;
+          has_top = has_top || (__ballot(take && pos < room && row == topi) != 0ull);
+          nh += __popcll(mask);
+          if (lead) {
+            const unsigned long long am = __ballot(alive);
+            const int run = am ? (__ffsll(am) - 1) : 64;
+            newcur = (w0 + run < hn) ? w0 + run : hn;
+            lead = (run == 64);
+          }
         }
-        if (count <= room) break;
-        thr *= 1.333521432163324;                    // 10^(1/8)
+        if (nh > room) nh = room;
+        if (nh > 0 && !has_top) {                   // the largest remaining entry rides along (it replaces the last hint if the step is full)
+          if (nh < room) ++nh;
+          if (lane == 0) s_C[nh - 1] = topi;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      // (b) the rest of the step (all of it without a hint) from the two largest entries of every 64-row block
+      const int room2 = room - nh;
+      unsigned excl = 0;                             // bit qi: candidate qi * 64 + lane is among the hints chosen above
+      if (nh > 0 && room2 > 0) {
+        for (int q0 = 0, qi = 0; q0 < ncand; q0 += 64, ++qi) {
+          const int q = q0 + lane;
+          if (q < ncand) {
+            const int row = ci[q];
+            bool dup = false;
+            for (int j = 0; j < nh; ++j) dup = dup || (s_C[j] == row);
+            if (dup) excl |= 1u << (qi & 31);
+          }
+        }
       }
       int base = 0;
-      for (int q0 = 0; q0 < ncand; q0 += 64) {
-        const int q = q0 + lane;
-        const bool take = q < ncand && cv[q] >= thr && cv[q] > tol_rel * d0;
-        const unsigned long long mask = __ballot(take);
-        const int pos = base + __popcll(mask & below);
-        if (take && pos < room) s_C[pos] = ci[q];
-        base += __popcll(mask);
+      if (room2 > 0) {
+        for (int tries = 0; tries < 20; ++tries) {
+          int count = 0;
+          for (int q0 = 0, qi = 0; q0 < ncand; q0 += 64, ++qi) {
+            const int q = q0 + lane;
+            count += __popcll(__ballot(q < ncand && cv[q] >= thr && cv[q] > floor_v && !((excl >> (qi & 31)) & 1u)));
+          }
+          if (count <= room2) break;
+          thr *= 1.333521432163324;                    // 10^(1/8)
+        }
+        for (int q0 = 0, qi = 0; q0 < ncand; q0 += 64, ++qi) {
+          const int q = q0 + lane;
+          const bool take = q < ncand && cv[q] >= thr && cv[q] > floor_v && !((excl >> (qi & 31)) & 1u);
+          const unsigned long long mask = __ballot(take);
+          const int pos = base + __popcll(mask & below);
+          if (take && pos < room2) s_C[nh + pos] = ci[q];
+          base += __popcll(mask);
+        }
+        if (base > room2) base = room2;
       }
-      bsel = (base < room) ? base : room;
+      bsel = nh + base;
       if (bsel == 0) {                               // (ties that never fit under the rising bound: the largest entry alone)
         if (lane == 0) s_C[0] = topi;
         bsel = 1;
       }
     }
     if (!(top > NEG_INF)) top = 0.0;
-    if (lane == 0) { s_bsel = bsel; s_k = k; s_done = state[1]; s_sum = sum; s_top = top; }
+    if (lane == 0) { s_bsel = bsel; s_k = k; s_done = state[1]; s_sum = sum; s_top = top; s_newcur = newcur; }
   }
   __syncthreads();
   if (s_done) return;
@@ -297,6 +368,7 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
     desc->top = s_top;
     desc->k = k;
     desc->bsel = bsel;
+    desc->newcur = s_newcur;
     for (int m = 0; m < PB; ++m) desc->C[m] = (m < bsel) ? s_C[m] : (bsel ? s_C[0] : 0);   // (unused entries: a valid row for the caller's gather)
     if (k == 0) work->d0 = s_top;
     work->trace_left = s_sum;
@@ -352,7 +424,7 @@ __global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double to
                                                                 double* __restrict__ cand_val, int* __restrict__ cand_idx,
                                                                 double* __restrict__ cand_sum, int nblk, const double* __restrict__ AP,
                                                                 const PivDesc* __restrict__ desc, int32_t* __restrict__ piv,
-                                                                int32_t* __restrict__ state, const PivWork* __restrict__ work, int diag_flags) {
+                                                                int32_t* __restrict__ state, PivWork* __restrict__ work, int diag_flags) {
   // (timing diagnostics, VMCPDE_PIVBLK_DIAG, wrong results: 1 the block's eliminations stop after the first, 2 no row substitution)
   __shared__ double LP[PB][PB + 1];        // row n = the n-th accepted pivot's row of the block factor (columns 0 .. n)
   __shared__ double Lb[PB][PB + 1];        // block factor by candidate: Lb[m][n], n = elimination step
@@ -459,8 +531,12 @@ __global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double to
   }
   double nd = open ? di - ss : NEG_INF;
   if (open) {
+    bool pivot = false;                                          // (a row may be listed twice by a careless hint list: once a pivot, always closed)
     for (int m = 0; m < bsel; ++m)
-      if (s_C[m] == i) nd = s_acc[m] ? NEG_INF : s_left[m];     // a pivot is finished; a dropped candidate keeps what the block left of it
+      if (s_C[m] == i) {
+        if (s_acc[m]) { nd = NEG_INF; pivot = true; }            // a pivot is finished;
+        else if (!pivot) nd = s_left[m];                         // a dropped candidate keeps what the block left of it
+      }
   }
   if (inside) d[i] = nd;
   double v1 = nd;
@@ -483,6 +559,8 @@ __global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double to
   if (blockIdx.x == 0 && t == 0) {
     state[0] = k + bacc;
     for (int n = 0; n < bacc; ++n) piv[k + n] = s_C[s_perm[n]];
+    work->hint_cur = desc->newcur;
+    work->steps += 1;
   }
 }
 
@@ -490,7 +568,8 @@ __global__ __launch_bounds__(PF_ROWS) void pivblk_factor_kernel(int P, double to
 // d = the given diagonal; the two largest entries of every 64-row block as candidates (as pivchol_init_kernel with two = 1)
 __global__ __launch_bounds__(PC_ROWS) void pivchol_init_diag_kernel(const double* __restrict__ diag, int P, double* __restrict__ d,
                                                                     double* __restrict__ cand_val, int* __restrict__ cand_idx,
-                                                                    double* __restrict__ cand_sum, int32_t* __restrict__ state) {
+                                                                    double* __restrict__ cand_sum, int32_t* __restrict__ state,
+                                                                    PivWork* __restrict__ work) {
   const int i = (int)blockIdx.x * PC_ROWS + (int)threadIdx.x;
   double mine = NEG_INF;
   if (i < P) {
@@ -512,7 +591,7 @@ __global__ __launch_bounds__(PC_ROWS) void pivchol_init_diag_kernel(const double
     cand_val[2 * blockIdx.x + 1] = v2;
     cand_idx[2 * blockIdx.x + 1] = idx2;
     cand_sum[2 * blockIdx.x + 1] = 0.0;
-    if (blockIdx.x == 0) { state[0] = 0; state[1] = 0; }
+    if (blockIdx.x == 0) { state[0] = 0; state[1] = 0; work->hint_cur = 0; work->steps = 0; }
   }
 }
 
@@ -686,7 +765,24 @@ int64_t pivchol_ws_doubles(int P) {
   return 8 /* PivWork, padded */ + (int64_t)nwg * PC_ROWS /* d */ + 2 * nwg /* cand_val */ + 2 * nwg /* cand_sum */ + nwg /* cand_idx (2 x int32) */ + 8;
 }
 
-int64_t pivblk_ws_doubles(int P, int64_t ldl) { return pivchol_ws_doubles(P) + 64 /* PivDesc */ + (int64_t)PB * ldl /* panel */; }
+int64_t pivblk_ws_doubles(int P, int64_t ldl) {
+  return pivchol_ws_doubles(P) + 64 /* PivDesc */ + (int64_t)PB * ldl /* panel */ + ldl / 2 + 8 /* hint list: int32[ldl] */;
+}
+inline int* pivblk_hint(double* w, int P, int64_t ldl) { return reinterpret_cast<int*>(w + pivchol_ws_doubles(P) + 64 + (int64_t)PB * ldl); }
+
+// the pivots of a finished factorisation (piv[0 .. state[0])) become the hint list of the workspace; piv == nullptr disarms it
+__global__ void pivblk_hint_kernel(const int32_t* __restrict__ piv, const int32_t* __restrict__ state, int P, int* __restrict__ hint,
+                                   PivWork* __restrict__ work) {
+  int n = piv ? state[0] : 0;
+  if (n < 0) n = 0;
+  if (n > P) n = P;
+  for (int q = (int)(blockIdx.x * blockDim.x + threadIdx.x); q < n; q += (int)(gridDim.x * blockDim.x)) hint[q] = piv[q];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    work->hint_n = n;
+    work->hint_cur = 0;
+    work->hint_magic = n > 0 ? HINT_MAGIC : 0;
+  }
+}
 
 }  // namespace
 }  // namespace vmcpde
@@ -714,7 +810,7 @@ extern "C" int vmcpde_pivoted_cholesky(const double* S, int64_t lds, int32_t P, 
   int* cand_idx = reinterpret_cast<int*>(cand_sum + 2 * nwg);
   hipStream_t st = (hipStream_t)stream;
   if (first_step == 0)
-    hipLaunchKernelGGL(pivchol_init_kernel, dim3(nwg), dim3(PC_ROWS), 0, st, S, lds, P, d, cand_val, cand_idx, cand_sum, state, 0);
+    hipLaunchKernelGGL(pivchol_init_kernel, dim3(nwg), dim3(PC_ROWS), 0, st, S, lds, P, d, cand_val, cand_idx, cand_sum, state, 0, (PivWork*)nullptr);
   for (int s = first_step; s < first_step + n_steps; ++s)
     hipLaunchKernelGGL(pivchol_step_kernel, dim3(nwg), dim3(PC_THREADS), 0, st, S, lds, P, s, tol_rel, LT, ldl, d, cand_val, cand_idx, cand_sum, nwg,
                        piv, state, work);
@@ -757,20 +853,21 @@ extern "C" int vmcpde_pivoted_cholesky_blocked(const double* S, int64_t lds, int
   int* cand_idx = reinterpret_cast<int*>(cand_sum + 2 * nblk);
   PivDesc* desc = reinterpret_cast<PivDesc*>(w + pivchol_ws_doubles(P));
   double* AP = w + pivchol_ws_doubles(P) + 64;
+  const int* hint = pivblk_hint(w, P, ldl);
   hipStream_t st = (hipStream_t)stream;
-  if (restart) hipLaunchKernelGGL(pivchol_init_kernel, dim3(nblk), dim3(PC_ROWS), 0, st, S, lds, P, d, cand_val, cand_idx, cand_sum, state, 1);
+  if (restart) hipLaunchKernelGGL(pivchol_init_kernel, dim3(nblk), dim3(PC_ROWS), 0, st, S, lds, P, d, cand_val, cand_idx, cand_sum, state, 1, work);
   const int nfac = (P + PF_ROWS - 1) / PF_ROWS;
   const int diag_flags = env_int("VMCPDE_PIVBLK_DIAG", 0);
   for (int b = 0; b < n_blocks; ++b) {
     hipLaunchKernelGGL(pivblk_panel_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, S, lds, P, tol_rel, max_rank, LT, ldl, cand_val, cand_idx, cand_sum,
-                       nblk, AP, desc, state, work, 2, (const double*)nullptr);
+                       nblk, AP, desc, state, work, 2, (const double*)nullptr, d, hint);
     hipLaunchKernelGGL(pivblk_factor_kernel, dim3(nfac), dim3(PF_ROWS), 0, st, P, tol_rel, LT, ldl, d, cand_val, cand_idx, cand_sum, nblk, AP, desc,
                        piv, state, work, diag_flags);
   }
   // one more panel launch settles `state` after the last factor launch: done if nothing is left above the tolerance, and the trace of
   // the remainder (it selects, writes the descriptor and its panel, which the next call's first launch simply recomputes)
   hipLaunchKernelGGL(pivblk_panel_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, S, lds, P, tol_rel, max_rank, LT, ldl, cand_val, cand_idx, cand_sum, nblk,
-                     AP, desc, state, work, 2, (const double*)nullptr);
+                     AP, desc, state, work, 2, (const double*)nullptr, d, hint);
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -778,6 +875,16 @@ extern "C" int vmcpde_pivoted_cholesky_blocked(const double* S, int64_t lds, int
 // ---- matrix-free form (experiment): the same factorisation with the columns of S formed from the Jacobian on demand ----------------
 extern "C" int64_t vmcpde_lowrank_candidates_byte_offset(int32_t P) {     // of the int32[32] candidate rows inside the blocked workspace
   return (P >= 1) ? (pivchol_ws_doubles(P) * (int64_t)sizeof(double) + 16) : 0;
+}
+
+extern "C" int vmcpde_lowrank_hint(const int32_t* piv, const int32_t* state, int32_t P, void* workspace, int64_t workspace_bytes, void* stream) {
+  VMC_REQUIRE(workspace && P >= 1 && (piv == nullptr || state != nullptr), "vmcpde_lowrank_hint: bad argument");
+  VMC_REQUIRE(workspace_bytes >= vmcpde_pivoted_cholesky_blocked_workspace_bytes(P), "vmcpde_lowrank_hint: workspace too small");
+  double* w = static_cast<double*>(workspace);
+  const int64_t ldl = (int64_t)((P + PC_ROWS - 1) / PC_ROWS) * PC_ROWS;
+  hipLaunchKernelGGL(pivblk_hint_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, piv, state, P, pivblk_hint(w, P, ldl), reinterpret_cast<PivWork*>(w));
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 extern "C" int vmcpde_lowrank_begin(const double* diag, int32_t P, int32_t* state, void* workspace, int64_t workspace_bytes, void* stream) {
@@ -790,7 +897,7 @@ extern "C" int vmcpde_lowrank_begin(const double* diag, int32_t P, int32_t* stat
   double* cand_val = d + (int64_t)nblk * PC_ROWS;
   double* cand_sum = cand_val + 2 * nblk;
   int* cand_idx = reinterpret_cast<int*>(cand_sum + 2 * nblk);
-  hipLaunchKernelGGL(pivchol_init_diag_kernel, dim3(nblk), dim3(PC_ROWS), 0, (hipStream_t)stream, diag, P, d, cand_val, cand_idx, cand_sum, state);
+  hipLaunchKernelGGL(pivchol_init_diag_kernel, dim3(nblk), dim3(PC_ROWS), 0, (hipStream_t)stream, diag, P, d, cand_val, cand_idx, cand_sum, state, reinterpret_cast<PivWork*>(w));
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -811,13 +918,14 @@ extern "C" int vmcpde_lowrank_step(const double* Scol, int32_t P, double tol_rel
   int* cand_idx = reinterpret_cast<int*>(cand_sum + 2 * nblk);
   PivDesc* desc = reinterpret_cast<PivDesc*>(w + pivchol_ws_doubles(P));
   double* AP = w + pivchol_ws_doubles(P) + 64;
+  const int* hint = pivblk_hint(w, P, ldl);
   hipStream_t st = (hipStream_t)stream;
   if (!Scol) {
     hipLaunchKernelGGL(pivblk_panel_kernel, dim3(1), dim3(PC_THREADS), 0, st, (const double*)nullptr, (int64_t)0, P, tol_rel, max_rank, LT, ldl, cand_val,
-                       cand_idx, cand_sum, nblk, AP, desc, state, work, 0, (const double*)nullptr);
+                       cand_idx, cand_sum, nblk, AP, desc, state, work, 0, (const double*)nullptr, d, hint);
   } else {
     hipLaunchKernelGGL(pivblk_panel_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, (const double*)nullptr, (int64_t)0, P, tol_rel, max_rank, LT, ldl,
-                       cand_val, cand_idx, cand_sum, nblk, AP, desc, state, work, 1, Scol);
+                       cand_val, cand_idx, cand_sum, nblk, AP, desc, state, work, 1, Scol, d, hint);
     hipLaunchKernelGGL(pivblk_factor_kernel, dim3((P + PF_ROWS - 1) / PF_ROWS), dim3(PF_ROWS), 0, st, P, tol_rel, LT, ldl, d, cand_val, cand_idx,
                        cand_sum, nblk, AP, desc, piv, state, work, 0);
   }

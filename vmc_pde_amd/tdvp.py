@@ -18,6 +18,7 @@ What runs underneath (all on the GPU, all fp64):
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -112,6 +113,10 @@ class TDVP:
                                   # the Jacobian on demand (csrc/eig.hip::colpanel_kernel, one pass over J per block step), and S0 u for the
                                   # refinement and the diagnostics is J^T (J u) / N - m (m.u): ~20 passes over J instead of N P^2 flop.
                                   # `S0` is then formed on first access; a full-rank S (no plan within the rank cap) raises.
+    pivotHints: bool = True       # low-rank routes: the pivots of the previous call's factorisation are the preferred candidates of this
+                                  # one (`vmcpde_lowrank_hint`; consecutive S of a trajectory are close).  Only the choice of candidates
+                                  # changes -- acceptance, window and stopping criterion do not --, about 22 instead of 13 columns per block
+                                  # step; a call's result then depends on the call before it at the level of the solve's accuracy (1e-10).
     residualBound: float = 1e-6   # Cholesky path: a solver residual above this (or a NaN) is treated as a failed factorisation
     centering: str = "auto"       # "exact": global means before the Gram (an extra pass over J, + one tiny all-reduce when sharded)
                                   # "lagged": previous call's global mean as shift -> one pass, a single all-reduce per step
@@ -535,7 +540,8 @@ class TDVP:
                      state=torch.zeros(2, dtype=torch.int32, device=device),
                      ws=torch.zeros(nat.lib().vmcpde_pivoted_cholesky_blocked_workspace_bytes(P) // 8, dtype=global_defs.tReal, device=device),
                      state_host=torch.zeros(2, dtype=torch.int32).pin_memory(),
-                     info_host=torch.zeros(3, dtype=global_defs.tReal).pin_memory())
+                     info_host=torch.zeros(3, dtype=global_defs.tReal).pin_memory(),
+                     head_host=torch.zeros(4, dtype=global_defs.tReal).pin_memory())
             self._buf_lr = {key: w}
         return w
 
@@ -560,18 +566,34 @@ class TDVP:
                 tol = max(tol, 2e-15 * r)
         return tol
 
+    def _arm_hints(self, w, P):
+        """Before a factorisation starts in `w`: its previous pivots (still in w["piv"] / w["state"], zero on first use) become the
+        hint list, or the list is disarmed."""
+        on = bool(self.pivotHints) and os.environ.get("VMCPDE_PIVOT_HINTS", "1") != "0"
+        nat.call("vmcpde_lowrank_hint", nat.ptr(w["piv"]) if on else None, nat.ptr(w["state"]) if on else None, P, nat.ptr(w["ws"]),
+                 w["ws"].numel() * 8, nat.stream())
+
+    @staticmethod
+    def _steps_used(ws_head_host):
+        """Block steps that added columns (PivWork::steps, csrc/eig.hip) from a host copy of the first four doubles of the workspace."""
+        return int(ws_head_host.view(torch.int32)[7])
+
     def _pivoted_factor(self, S, w, cap, extra=None):
         """S = L L^T + R by blocked diagonal pivoting (up to 32 columns per pair of launches) into w["LT"]; returns (rank, converged,
         max diag, trace of R, extra's value).  The first call covers the previous call's rank (the spectrum moves slowly along a
         trajectory); the host reads `state` after every call (`extra`: a device scalar copied along)."""
         P, device = S.shape[0], S.device
         done, first = False, True
-        nblocks = (self._lowrank_last_rank + 12) // 13 + 2 if self._lowrank_last_rank else 12      # (a step accepts ~13 columns)
+        self._arm_hints(w, P)
+        # (first launch chain: what the previous factorisation in these buffers used plus a third; an unhinted step accepts ~13 columns)
+        used = self._steps_used(w["head_host"])
+        nblocks = used + max(3, used // 3) if used else ((self._lowrank_last_rank + 12) // 13 + 2 if self._lowrank_last_rank else 12)
         for _ in range(cap // 3 + 8):           # (every step makes progress -- a column, or candidates lowered to what is left of them)
             nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S), S.stride(0), P, self._lowrank_tol() or LOWRANK_TOL, 1 if first else 0, nblocks, cap, nat.ptr(w["LT"]),
                      w["ldl"], nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), w["ws"].numel() * 8, nat.stream())
             w["state_host"].copy_(w["state"], non_blocking=True)
             w["info_host"][:2].copy_(w["ws"][:2], non_blocking=True)
+            w["head_host"].copy_(w["ws"][:4], non_blocking=True)
             if extra is not None and first:
                 w["info_host"][2:3].copy_(extra.reshape(1), non_blocking=True)
             torch.cuda.current_stream(device).synchronize()
@@ -612,6 +634,9 @@ class TDVP:
                 prev_rank, prev_done = int(st["host"][0]), int(st["host"][1])
                 if not prev_done or prev_rank > st["rmax"] - 32:     # (re-plan well before the rank reaches the pad)
                     st = self._chol_static = None
+                else:                                                # what the last factorisation used, and a third (at least 3) to spare
+                    used = self._steps_used(st["head"])
+                    st["nsteps"] = used + max(3, used // 3)
             if st is not None:
                 self._solve_lowrank_static(b, F, P, update, w, D, st)
                 return True
@@ -641,8 +666,10 @@ class TDVP:
         b["info"].zero_()
         rmax = _round_up(r + 40, 128)
         if rmax <= w["LT"].shape[0] and rmax <= cap + 127:
-            self._chol_static = dict(P=P, rmax=rmax, nsteps=r // 11 + 3, nref=nref, rank=r, event=None,
-                                     host=torch.zeros(2, dtype=torch.int32).pin_memory())
+            used = self._steps_used(w["head_host"])
+            self._chol_static = dict(P=P, rmax=rmax, nsteps=used + max(3, used // 3), nref=nref, rank=r, event=None,
+                                     host=torch.zeros(2, dtype=torch.int32).pin_memory(),
+                                     head=torch.zeros(4, dtype=global_defs.tReal).pin_memory())
         return True
 
     def _solve_lowrank_static(self, b, F, P, update, w, D, st):
@@ -658,9 +685,11 @@ class TDVP:
         G, gws, t2, Su = w["G"], w["G_ws"], w["t2"], w["Su"]
         need = gws.numel() * 8
         w["LT"][:rmax].zero_()                                      # columns past the rank: zero, i.e. an identity block in G
+        self._arm_hints(w, P)
         nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S0), S0.stride(0), P, self._lowrank_tol() or LOWRANK_TOL, 1, st["nsteps"], rmax, nat.ptr(w["LT"]), w["ldl"],
                  nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), w["ws"].numel() * 8, nat.stream())
         st["host"].copy_(w["state"], non_blocking=True)             # for the next call
+        st["head"].copy_(w["ws"][:4], non_blocking=True)
         if st["event"] is None:
             st["event"] = torch.cuda.Event()
         st["event"].record()
@@ -871,6 +900,9 @@ class TDVP:
                     plan["event"].synchronize()
                     if not int(plan["host"][1]) or int(plan["host"][0]) > plan["rmax"] - 32:
                         plan = self._mf_plan = None
+                    else:
+                        used = self._steps_used(plan["head"])
+                        plan["nsteps"] = used + max(3, used // 3)
                 rmax = plan["rmax"] if plan is not None else cap
 
                 def block_step():
@@ -889,6 +921,7 @@ class TDVP:
                              nat.ptr(w["ws"]), wsb, nat.stream())
 
                 w["LT"][:rmax].zero_()
+                self._arm_hints(w, P)
                 nat.call("vmcpde_lowrank_begin", nat.ptr(diagS), P, nat.ptr(w["state"]), nat.ptr(w["ws"]), wsb, nat.stream())
                 if plan is None:                                     # planning: run until the criterion is met, reading the state every 4 steps
                     steps, done = 0, False
@@ -907,7 +940,8 @@ class TDVP:
                     if not done or r < 1:
                         raise FloatingPointError(f"matrixFree: S is not rank deficient within the cap (rank >= {r} of {P}); use the assembled path")
                     rmax = _round_up(r + 40, 128)
-                    self._mf_plan = dict(rmax=rmax, nsteps=steps + 3, rank=r, event=None, host=torch.zeros(2, dtype=torch.int32).pin_memory())
+                    self._mf_plan = dict(rmax=rmax, nsteps=steps + 3, rank=r, event=None, host=torch.zeros(2, dtype=torch.int32).pin_memory(),
+                                         head=torch.zeros(4, dtype=global_defs.tReal).pin_memory())
                     mode = "planning"
                 else:
                     for _ in range(plan["nsteps"]):
@@ -915,6 +949,7 @@ class TDVP:
                     nat.call("vmcpde_lowrank_step", None, P, tol, rmax, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), wsb,
                              nat.stream())
                     plan["host"].copy_(w["state"], non_blocking=True)
+                    plan["head"].copy_(w["ws"][:4], non_blocking=True)
                     if plan["event"] is None:
                         plan["event"] = torch.cuda.Event()
                     plan["event"].record()
