@@ -298,6 +298,13 @@ int vmcpde_lowrank_hint(const int32_t* piv, const int32_t* state, int32_t P, voi
  *   vmcpde_gram_columns(..)           Scol[m][i] = sum_n JT[rows[m]][n] JT[i][n] / n_total - mean[i] mean[rows[m]]   ([32][ldl];
  *                                     an fp64-MFMA skinny GEMM, one pass over JT; mean NULL = uncentred)
  *   vmcpde_lowrank_step(Scol, ..)     panel, block factorisation with pivoting, new columns of L (as launches 1-2 of a blocked step) */
+/* With a hint list armed (vmcpde_lowrank_hint) the columns of S at its first n_rows rows can be formed AHEAD of the factorisation in one
+ * pass over the Jacobian (a gather of those rows and one GEMM, the caller's: Sbig[j][i] = S[hint[j]][i], [n_rows][ldl]) and registered
+ * after vmcpde_lowrank_begin: a block step then takes list entries only while any qualifies and reads their columns from Sbig -- no
+ * pass for that step -- and is an ordinary step when none does.  The int32[2] at vmcpde_lowrank_skip_flag_byte_offset() in the
+ * workspace tells vmcpde_gram_columns (as its `state` argument) whether the step just selected needs its columns formed. */
+int vmcpde_lowrank_columns(const double* Sbig, int32_t n_rows, int32_t P, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t vmcpde_lowrank_skip_flag_byte_offset(void);
 int64_t vmcpde_lowrank_candidates_byte_offset(int32_t P);
 int vmcpde_lowrank_begin(const double* diag, int32_t P, int32_t* state, void* workspace, int64_t workspace_bytes, void* stream);
 int vmcpde_lowrank_step(const double* Scol, int32_t P, double tol_rel, int32_t max_rank, double* LT, int64_t ldl, int32_t* piv,

@@ -521,6 +521,19 @@ def test_matrix_free_step_matches_the_assembled_one(headline_net):
         assert abs(float(tm.solverResidual)) < 1e-11 and abs(float(tm.tdvp_error) - float(td.tdvp_error)) < 1e-10
         assert abs(float(tm.ElocMean) - float(td.ElocMean)) < 1e-12 * (1 + abs(float(td.ElocMean)))
         assert abs(float(tm.ElocVar) - float(td.ElocVar)) < 1e-11 * (1 + abs(float(td.ElocVar)))
+        # from the second call on the columns of S at the previous call's pivots are formed AHEAD in one pass over the Jacobian, and the
+        # block steps that take their candidates from that list need no pass of their own (counted by the kernel, read one call later)
+        assert tm.choleskyInfo["columns_ahead"] == (0 if call == 0 else -(-tm._mf_plan.get("prev_rank", tm._mf_plan["rank"]) // 32) * 32)
+        if call == 2:
+            assert tm.choleskyInfo["own_passes_last_call"] <= 2, tm.choleskyInfo
+    # ... without them every block step is a pass of its own (and the result the same)
+    tn = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", matrixFree=True, pivotHints=False)
+    for call in range(3):
+        un, _ = tn(th.cuda(), 0.0, vs, ep, **kw)
+        tn.check()
+    du = un - u_d
+    assert tn.choleskyInfo["columns_ahead"] == 0 and tn.choleskyInfo["own_passes_last_call"] >= 8, tn.choleskyInfo
+    assert float(torch.linalg.norm(S @ du + D * du)) < 1e-10 * nF and abs(float(tn.solverResidual)) < 1e-11
 
 
 def test_matrix_free_spectral_solve_matches_the_assembled_one(headline_net):

@@ -14,6 +14,7 @@
 // This file holds 1 and 2 (the dependent chains); the GEMMs, the triangular solve and the r x r decomposition of 3 are library
 // calls made from the host.  L is kept TRANSPOSED, LT[k][i] = L[i][k] (row k = column k of L, contiguous): every access of the
 // chains is then a contiguous run of a row.
+#include <cstddef>
 #include "common.hpp"
 
 namespace vmcpde {
@@ -32,7 +33,14 @@ struct PivWork {            // device-side bookkeeping of one factorisation (hea
   int hint_n;               // entries of the hint list
   int hint_cur;             // entries before this one are pivots already or below the tolerance
   int steps;                // block steps of this factorisation that added columns
+  // matrix-free form only: the columns of S at the first big_n hint rows, formed ahead of the factorisation in ONE pass over the
+  // Jacobian (vmcpde_lowrank_columns); a step whose candidates all come from the list then needs no pass of its own
+  int pool_steps;           // block steps of this factorisation that were NOT served from those columns
+  int big_n;
+  const double* big;        // [big_n][ldl], row j = column hint[j] of S; nullptr: none registered
+  int skip[2];              // skip[1] != 0: the step just selected needs no columns formed (done, or served from `big`)
 };
+static_assert(sizeof(PivWork) <= 64, "PivWork must fit the workspace head");
 constexpr int HINT_MAGIC = 0x48494e54;
 
 // (value, index) arg max over a wave, ties to the lower index; every lane returns the result
@@ -89,7 +97,7 @@ __global__ __launch_bounds__(PC_ROWS) void pivchol_init_kernel(const double* __r
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     state[0] = 0;
     state[1] = 0;
-    if (work) { work->hint_cur = 0; work->steps = 0; }
+    if (work) { work->hint_cur = 0; work->steps = 0; work->pool_steps = 0; work->big = nullptr; work->big_n = 0; work->skip[0] = 0; work->skip[1] = 0; }
   }
 }
 
@@ -225,7 +233,10 @@ struct PivDesc {             // written by workgroup 0 of the panel launch, read
   int k, bsel;
   int C[PB];
   int newcur;                // the hint cursor after this step's selection (committed by the factor launch)
+  int from_big;              // the step's columns are rows pos[m] of PivWork::big (matrix-free form)
+  int pos[PB];
 };
+static_assert(sizeof(PivDesc) <= 64 * sizeof(double), "PivDesc must fit its slot of the workspace");
 
 __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* __restrict__ S, int64_t lds, int P, double tol_rel, int max_rank,
                                                                   const double* __restrict__ LT, int64_t ldl,
@@ -242,14 +253,15 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
   __shared__ double Wt[PBK][PB];
   __shared__ double red[3][PC_ROWS][17];
   __shared__ int s_C[PB];
-  __shared__ int s_bsel, s_k, s_done, s_newcur;
+  __shared__ int s_bsel, s_k, s_done, s_newcur, s_from_big;
+  __shared__ int s_pos[PB];
   __shared__ double s_sum, s_top;
   const int t = threadIdx.x, lane = t & 63;
   const int slice = __builtin_amdgcn_readfirstlane(t >> 6);
   const int ncand = 2 * nblk;
   if (phase == 1) {
-    if (t == 0) { s_k = desc->k; s_bsel = desc->bsel; s_done = state[1]; s_sum = 0.0; s_top = desc->top; }
-    if (t < PB) s_C[t] = desc->C[t];
+    if (t == 0) { s_k = desc->k; s_bsel = desc->bsel; s_done = state[1]; s_sum = 0.0; s_top = desc->top; s_from_big = desc->from_big; }
+    if (t < PB) { s_C[t] = desc->C[t]; s_pos[t] = desc->pos[t]; }
   } else {
     for (int q = t; q < ncand; q += PC_THREADS) { cv[q] = cand_val[q]; ci[q] = cand_idx[q]; }
   }
@@ -273,6 +285,7 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
     const double d0 = (k == 0) ? top : work->d0;
     const int room = (max_rank - k < PB) ? (max_rank - k) : PB;
     int bsel = 0, newcur = work->hint_cur;
+    bool from_big = false;
     if (top > tol_rel * d0 && room > 0) {
       const double floor_v = tol_rel * d0;
       double thr = fmax(floor_v, PB_THETA * top);
@@ -287,6 +300,10 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
       bool has_top = false;
       int hn = (hint && work->hint_magic == HINT_MAGIC) ? work->hint_n : 0;
       if (hn > P) hn = P;
+      // matrix-free form with the list's columns formed ahead (PivWork::big): a step takes list entries ONLY while any qualifies --
+      // no pass over the Jacobian for it -- and is an ordinary step (largest entry and all) when none does
+      const bool big = work->big != nullptr;
+      if (big && hn > work->big_n) hn = work->big_n;
       if (hn > 0) {
         int cur = newcur < 0 ? 0 : newcur;
         bool lead = true;
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
           const bool take = alive && dv >= thr;
           const unsigned long long mask = __ballot(take);
           const int pos = nh + __popcll(mask & below);
-          if (take && pos < room) s_C[pos] = row;
+          if (take && pos < room) { s_C[pos] = row; s_pos[pos] = q; }
           has_top = has_top || (__ballot(take && pos < room && row == topi) != 0ull);
           nh += __popcll(mask);
           if (lead) {
@@ -310,7 +327,7 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
           }
         }
         if (nh > room) nh = room;
-        if (nh > 0 && !has_top) {                   // the largest remaining entry rides along (it replaces the last hint if the step is full)
+        if (nh > 0 && !has_top && !big) {           // the largest remaining entry rides along (it replaces the last hint if the step is full)
           if (nh < room) ++nh;
           if (lane == 0) s_C[nh - 1] = topi;
         }
@@ -318,7 +335,8 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       // (b) the rest of the step (all of it without a hint) from the two largest entries of every 64-row block
-      const int room2 = room - nh;
+      from_big = big && nh > 0;
+      const int room2 = from_big ? 0 : room - nh;
       unsigned excl = 0;                             // bit qi: candidate qi * 64 + lane is among the hints chosen above
       if (nh > 0 && room2 > 0) {
         for (int q0 = 0, qi = 0; q0 < ncand; q0 += 64, ++qi) {
@@ -359,16 +377,23 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
       }
     }
     if (!(top > NEG_INF)) top = 0.0;
-    if (lane == 0) { s_bsel = bsel; s_k = k; s_done = state[1]; s_sum = sum; s_top = top; s_newcur = newcur; }
+    if (lane == 0) { s_bsel = bsel; s_k = k; s_done = state[1]; s_sum = sum; s_top = top; s_newcur = newcur; s_from_big = from_big ? 1 : 0; }
   }
   __syncthreads();
-  if (s_done) return;
+  if (s_done) {
+    if (phase != 1 && blockIdx.x == 0 && t == 0) work->skip[1] = 1;
+    return;
+  }
   const int k = s_k, bsel = s_bsel;
   if (phase != 1 && blockIdx.x == 0 && t == 0) {
     desc->top = s_top;
     desc->k = k;
     desc->bsel = bsel;
     desc->newcur = s_newcur;
+    desc->from_big = s_from_big;
+    for (int m = 0; m < PB; ++m) desc->pos[m] = (s_from_big && m < bsel) ? s_pos[m] : 0;
+    work->skip[1] = (s_from_big || bsel == 0) ? 1 : 0;
+    if (phase == 0 && bsel > 0 && !s_from_big) work->pool_steps += 1;
     for (int m = 0; m < PB; ++m) desc->C[m] = (m < bsel) ? s_C[m] : (bsel ? s_C[0] : 0);   // (unused entries: a valid row for the caller's gather)
     if (k == 0) work->d0 = s_top;
     work->trace_left = s_sum;
@@ -413,7 +438,8 @@ __global__ __launch_bounds__(PC_THREADS) void pivblk_panel_kernel(const double* 
       for (int c = 0; c < 8; ++c) {
         const int m = 8 * cg + c;
         const double sum = acc[c] + red[0][lane][8 * (cg & 1) + c] + red[1][lane][8 * (cg & 1) + c] + red[2][lane][8 * (cg & 1) + c];
-        const double sv = (inside && m < bsel) ? (Scol ? Scol[(int64_t)m * ldl + i] : S[(int64_t)s_C[m] * lds + i]) : 0.0;
+        const double sv = (inside && m < bsel) ? (s_from_big ? work->big[(int64_t)s_pos[m] * ldl + i]
+                                                             : (Scol ? Scol[(int64_t)m * ldl + i] : S[(int64_t)s_C[m] * lds + i])) : 0.0;
         AP[(int64_t)m * ldl + i] = (inside && m < bsel) ? sv - sum : 0.0;
       }
     }
@@ -591,7 +617,10 @@ __global__ __launch_bounds__(PC_ROWS) void pivchol_init_diag_kernel(const double
     cand_val[2 * blockIdx.x + 1] = v2;
     cand_idx[2 * blockIdx.x + 1] = idx2;
     cand_sum[2 * blockIdx.x + 1] = 0.0;
-    if (blockIdx.x == 0) { state[0] = 0; state[1] = 0; work->hint_cur = 0; work->steps = 0; }
+    if (blockIdx.x == 0) {
+      state[0] = 0; state[1] = 0;
+      work->hint_cur = 0; work->steps = 0; work->pool_steps = 0; work->big = nullptr; work->big_n = 0; work->skip[0] = 0; work->skip[1] = 0;
+    }
   }
 }
 
@@ -883,6 +912,21 @@ extern "C" int vmcpde_lowrank_hint(const int32_t* piv, const int32_t* state, int
   double* w = static_cast<double*>(workspace);
   const int64_t ldl = (int64_t)((P + PC_ROWS - 1) / PC_ROWS) * PC_ROWS;
   hipLaunchKernelGGL(pivblk_hint_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, piv, state, P, pivblk_hint(w, P, ldl), reinterpret_cast<PivWork*>(w));
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void pivblk_columns_kernel(const double* big, int n_rows, PivWork* __restrict__ work) {
+  work->big = n_rows > 0 ? big : nullptr;
+  work->big_n = n_rows > 0 ? n_rows : 0;
+}
+
+extern "C" int64_t vmcpde_lowrank_skip_flag_byte_offset(void) { return (int64_t)offsetof(PivWork, skip); }
+
+extern "C" int vmcpde_lowrank_columns(const double* Sbig, int32_t n_rows, int32_t P, void* workspace, int64_t workspace_bytes, void* stream) {
+  VMC_REQUIRE(workspace && P >= 1 && n_rows >= 0 && n_rows <= P && (Sbig != nullptr || n_rows == 0), "vmcpde_lowrank_columns: bad argument");
+  VMC_REQUIRE(workspace_bytes >= vmcpde_pivoted_cholesky_blocked_workspace_bytes(P), "vmcpde_lowrank_columns: workspace too small");
+  hipLaunchKernelGGL(pivblk_columns_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, Sbig, n_rows, reinterpret_cast<PivWork*>(workspace));
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }

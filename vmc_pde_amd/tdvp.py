@@ -903,14 +903,17 @@ class TDVP:
                     else:
                         used = self._steps_used(plan["head"])
                         plan["nsteps"] = used + max(3, used // 3)
+                        plan["prev_rank"] = int(plan["host"][0])
+                        plan["prev_passes"] = int(plan["head"].view(torch.int32)[8])      # block steps that needed their own pass over J
                 rmax = plan["rmax"] if plan is not None else cap
+                skip_ptr = nat.C.c_void_p(w["ws"].data_ptr() + nat.lib().vmcpde_lowrank_skip_flag_byte_offset())
 
                 def block_step():
                     nat.call("vmcpde_lowrank_step", None, P, tol, rmax, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]),
                              wsb, nat.stream())
                     if world == 1:
                         nat.call("vmcpde_gram_columns", nat.ptr(JT), ldj, P, n, cand_ptr, nat.ptr(mean), Ntot, nat.ptr(w["Scol"]), ldl,
-                                 nat.ptr(w["state"]), nat.ptr(w["gc_ws"]), gcb, nat.stream())
+                                 skip_ptr, nat.ptr(w["gc_ws"]), gcb, nat.stream())      # (skipped when the step is done or served ahead)
                     else:        # raw local sums, one 1 MB all-reduce, then 1/N and the mean term (every rank chose the same candidates)
                         nat.call("vmcpde_gram_columns", nat.ptr(JT), ldj, P, n, cand_ptr, None, 1.0, nat.ptr(w["Scol"]), ldl, None,
                                  nat.ptr(w["gc_ws"]), gcb, nat.stream())
@@ -922,7 +925,28 @@ class TDVP:
 
                 w["LT"][:rmax].zero_()
                 self._arm_hints(w, P)
+                hints_on = bool(self.pivotHints) and os.environ.get("VMCPDE_PIVOT_HINTS", "1") != "0" and os.environ.get("VMCPDE_HINT_COLUMNS", "1") != "0"
+                ahead = 0
+                if plan is not None and hints_on and plan.get("prev_rank", plan["rank"]) > 0:
+                    # the columns of S at the previous call's pivots -- this call's preferred candidates -- in ONE pass over J: gather of
+                    # those rows, a GEMM batched over sample chunks (one library GEMM with K = n runs on a handful of workgroups), the
+                    # mean term; the block steps whose candidates all come from the list then need no pass of their own
+                    ahead = min(_round_up(plan.get("prev_rank", plan["rank"]), 32), rmax)
+                    idx = w["piv"][:ahead].long()               # (read before the factorisation overwrites it: stream order)
+                    JH = Jv[idx]                                 # ahead x n, contiguous
+                    ckn = next((c for c in (4096, 2048, 1024, 128) if n % c == 0), 0)
+                    if ckn:
+                        SH = torch.bmm(JH.view(ahead, n // ckn, ckn).permute(1, 0, 2), Jv.view(P, n // ckn, ckn).permute(1, 2, 0)).sum(0)
+                    else:
+                        SH = JH @ Jv.T
+                    if world > 1:
+                        mpi.allreduce_sum_(SH)
+                    if w.get("Sbig") is None or w["Sbig"].shape[0] < ahead:
+                        w["Sbig"] = torch.zeros((w["LT"].shape[0], ldl), dtype=global_defs.tReal, device=device)
+                    torch.addcmul(SH / Ntot, mean[idx][:, None], mean[None, :], value=-1.0, out=w["Sbig"][:ahead, :P])
                 nat.call("vmcpde_lowrank_begin", nat.ptr(diagS), P, nat.ptr(w["state"]), nat.ptr(w["ws"]), wsb, nat.stream())
+                if ahead:
+                    nat.call("vmcpde_lowrank_columns", nat.ptr(w["Sbig"]), ahead, P, nat.ptr(w["ws"]), wsb, nat.stream())
                 if plan is None:                                     # planning: run until the criterion is met, reading the state every 4 steps
                     steps, done = 0, False
                     while steps < cap:
@@ -941,7 +965,7 @@ class TDVP:
                         raise FloatingPointError(f"matrixFree: S is not rank deficient within the cap (rank >= {r} of {P}); use the assembled path")
                     rmax = _round_up(r + 40, 128)
                     self._mf_plan = dict(rmax=rmax, nsteps=steps + 3, rank=r, event=None, host=torch.zeros(2, dtype=torch.int32).pin_memory(),
-                                         head=torch.zeros(4, dtype=global_defs.tReal).pin_memory())
+                                         head=torch.zeros(5, dtype=global_defs.tReal).pin_memory())
                     mode = "planning"
                 else:
                     for _ in range(plan["nsteps"]):
@@ -949,7 +973,7 @@ class TDVP:
                     nat.call("vmcpde_lowrank_step", None, P, tol, rmax, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), wsb,
                              nat.stream())
                     plan["host"].copy_(w["state"], non_blocking=True)
-                    plan["head"].copy_(w["ws"][:4], non_blocking=True)
+                    plan["head"].copy_(w["ws"][:5], non_blocking=True)
                     if plan["event"] is None:
                         plan["event"] = torch.cuda.Event()
                     plan["event"].record()
@@ -1002,7 +1026,8 @@ class TDVP:
                 Tm = Tm / Ntot - torch.outer(q, q)
                 wv, W = torch.linalg.eigh(0.5 * (Tm + Tm.T))
                 self.ev, self.V = self._lowrank_assemble(Y, Xn, Q1 @ W, wv, r, P, device)
-                self.spectralInfo = dict(engine="matrix-free", mode=mode, rank=r, block_steps=self._mf_plan["nsteps"])
+                self.spectralInfo = dict(engine="matrix-free", mode=mode, rank=r, block_steps=self._mf_plan["nsteps"], columns_ahead=ahead,
+                                         own_passes_last_call=self._mf_plan.get("prev_passes"))
                 Fc = F.contiguous()
                 self.VtF = torch.empty(P, dtype=global_defs.tReal, device=device)
                 nat.call("vmcpde_gemv", nat.ptr(self.V), P, P, P, 1, nat.ptr(Fc), nat.ptr(self.VtF), nat.stream())
@@ -1075,7 +1100,8 @@ class TDVP:
         self._SExp = self._rhoVar = self._snr = self._S = None
         self.ev = self.V = self.VtF = None
         self.cholInfo = info
-        self.choleskyInfo = dict(engine="matrix-free", mode=mode, rmax=rmax, block_steps=self._mf_plan["nsteps"], planned_rank=self._mf_plan["rank"])
+        self.choleskyInfo = dict(engine="matrix-free", mode=mode, rmax=rmax, block_steps=self._mf_plan["nsteps"], planned_rank=self._mf_plan["rank"],
+                                 columns_ahead=ahead, own_passes_last_call=self._mf_plan.get("prev_passes"))
         return update, out[0], out[1]
 
     # ---- tdvp.py:73-94 -------------------------------------------------------------------------------------------
