@@ -562,3 +562,29 @@ def test_matrix_free_spectral_solve_matches_the_assembled_one(headline_net):
         assert abs(float(tm.solverResidual) - float(td.solverResidual)) < 1e-9 and abs(float(tm.tdvp_error) - float(td.tdvp_error)) < 1e-9
     with pytest.raises(NotImplementedError, match="diagonalShift"):
         V.TDVP(svdTol=1e-6, diagonalShift=1e-3, matrixFree=True)(th.cuda(), 0.0, vs, ep, **kw)
+
+
+@pytest.mark.parametrize("P,n,ldj", [(37, 1000, 1000), (300, 4097, 4160), (1031, 8192, 8192), (5, 3, 3)])
+def test_jt_matvec_against_numpy(P, n, ldj):
+    """vmcpde_jt_matvec: y = JT (JT^T v) and z = JT^T v, the S0 v of the matrix-free step (ragged sample counts, odd strides: the
+    scalar-load path; even strides: 16-byte loads)."""
+    from vmc_pde_amd import _native as nat
+    rng = np.random.default_rng(P + n)
+    JT = np.zeros((P, ldj))
+    JT[:, :n] = rng.standard_normal((P, n))
+    JT[:, n:] = np.nan                                  # (pad columns are never read)
+    v = rng.standard_normal(P)
+    for off in (0, 1):                                  # (a base address that is not 16-byte aligned takes the scalar path)
+        buf = torch.zeros(P * ldj + 1, dtype=torch.float64, device="cuda")
+        Jd = buf[off:off + P * ldj].view(P, ldj)
+        Jd.copy_(torch.from_numpy(JT))
+        z = torch.empty(n, dtype=torch.float64, device="cuda")
+        y = torch.empty(P, dtype=torch.float64, device="cuda")
+        need = nat.lib().vmcpde_jt_matvec_workspace_bytes(P, n)
+        ws = torch.empty(need // 8, dtype=torch.float64, device="cuda")
+        nat.call("vmcpde_jt_matvec", nat.ptr(Jd), ldj, P, n, nat.ptr(torch.from_numpy(v).cuda()), nat.ptr(z), nat.ptr(y), nat.ptr(ws), need, nat.stream())
+        torch.cuda.synchronize()
+        z_ref = JT[:, :n].T @ v
+        y_ref = JT[:, :n] @ z_ref
+        assert np.abs(z.cpu().numpy() - z_ref).max() < 1e-13 * np.abs(z_ref).max()
+        assert np.abs(y.cpu().numpy() - y_ref).max() < 1e-13 * np.abs(y_ref).max()

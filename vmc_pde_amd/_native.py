@@ -95,6 +95,8 @@ _PROTOS = {
     "vmcpde_pivoted_cholesky_blocked": (_int, [_vp, _i64, _i32, _f64, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "vmcpde_lowrank_candidates_byte_offset": (_i64, [_i32]),
     "vmcpde_lowrank_hint": (_int, [_vp, _vp, _i32, _vp, _i64, _vp]),
+    "vmcpde_jt_matvec_workspace_bytes": (_i64, [_i32, _i64]),
+    "vmcpde_jt_matvec": (_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "vmcpde_lowrank_columns": (_int, [_vp, _i32, _i32, _vp, _i64, _vp]),
     "vmcpde_lowrank_skip_flag_byte_offset": (_i64, []),
     "vmcpde_lowrank_begin": (_int, [_vp, _i32, _vp, _vp, _i64, _vp]),

@@ -983,11 +983,18 @@ class TDVP:
             self._replicated = self._Section(self, "replicated")
             self._replicated.__enter__()
 
+            need_mv = nat.lib().vmcpde_jt_matvec_workspace_bytes(P, n)
+            if w.get("mv_ws") is None or w["mv_ws"].numel() * 8 < need_mv or w["mv_z"].numel() < n:
+                w["mv_ws"] = torch.empty(need_mv // 8, dtype=global_defs.tReal, device=device)
+                w["mv_z"] = torch.empty(n, dtype=global_defs.tReal, device=device)
+
             def s0(v):                                               # J^T (J v) / N - m (m.v): two passes over J (+ a P-vector all-reduce)
-                z = Jv @ (v @ Jv)
+                y = torch.empty(P, dtype=global_defs.tReal, device=device)
+                nat.call("vmcpde_jt_matvec", nat.ptr(JT), ldj, P, n, nat.ptr(v.contiguous()), nat.ptr(w["mv_z"]), nat.ptr(y), nat.ptr(w["mv_ws"]),
+                         w["mv_ws"].numel() * 8, nat.stream())
                 if world > 1:
-                    mpi.allreduce_sum_(z)
-                return z / Ntot - mean * (mean @ v)
+                    mpi.allreduce_sum_(y)
+                return y / Ntot - mean * (mean @ v)
 
             if spectral:
                 # the reference's spectral solve on the same factor: exact rank (one host read), Householder basis Q1 of range(L),
