@@ -109,9 +109,10 @@ class TDVP:
                                   #   factorisation costs more than the r dependent block steps) while the rank stays under the cap and
                                   #   trace(R) under 1e-4 min D; dense otherwise (and for the next LOWRANK_RETRY_AFTER calls).
     matrixFree: bool = False      # EXPERIMENT (opt-in, solver="cholesky", fp64 Jacobian): S is never assembled.  The pivoted low-rank
-                                  # factor of S = <J^T J> needs only diag(S) and the 32 columns a block step pivots on, which are formed from
-                                  # the Jacobian on demand (csrc/eig.hip::colpanel_kernel, one pass over J per block step), and S0 u for the
-                                  # refinement and the diagnostics is J^T (J u) / N - m (m.u): ~20 passes over J instead of N P^2 flop.
+                                  # factor of S = <J^T J> needs only diag(S) and the columns it pivots on, which are formed from the
+                                  # Jacobian: for the previous call's pivots AHEAD in one pass (pivotHints), 32 at a time on demand otherwise
+                                  # (csrc/eig.hip::colpanel_kernel), and S0 u for the refinement and the diagnostics is J^T (J u) / N - m (m.u)
+                                  # (vmcpde_jt_matvec): ~7 passes over J and a 224-column GEMM instead of N P^2 flop.
                                   # `S0` is then formed on first access; a full-rank S (no plan within the rank cap) raises.
     pivotHints: bool = True       # low-rank routes: the pivots of the previous call's factorisation are the preferred candidates of this
                                   # one (`vmcpde_lowrank_hint`; consecutive S of a trajectory are close).  Only the choice of candidates
