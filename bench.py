@@ -82,6 +82,33 @@ def build_problem(device, workload="C2", seed=1, jacobian_dtype=torch.float64):
     return vs, eq, tdvp, theta
 
 
+def beside_headline(device, args, kwargs, theta, steps=10, warmup=5):
+    """TDVP steps/s of the opt-in experiments (never the headline): same workload, same regularised system, fp64 results (every call
+    draws its own samples, as in the timed loop; parity of each variant with the assembled fp64 path on the SAME samples is
+    tests/test_gpu_lowrank_eigh.py, tests/test_gpu_tdvp.py and tests/test_gpu_gram.py)."""
+    import vmc_pde_amd as V
+    out = {"note": "EXPERIMENTS, opt-in, measured after the timed region of this run; `value` is the assembled fp64 path"}
+    variants = {"matrixfree (S never assembled: TDVP(matrixFree=True), fp64)": dict(matrixFree=True),
+                "int8Gram (error-free sliced S-build on the int8 matrix pipe: TDVP(int8Gram=True))": dict(int8Gram=True)}
+    for name, flags in variants.items():
+        try:
+            tv = V.TDVP(diagonalShift=DIAG_SHIFT, svdTol=SVD_TOL, solver="cholesky", **flags)
+            kw = dict(kwargs)
+            for _ in range(warmup):
+                u, _ = tv(theta, 0.0, **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                u, _ = tv(theta, 0.0, **kw)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            tv.check("beside-headline variant")
+            out[name] = {"steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "steps": steps, "solver_residual": float(tv.solverResidual)}
+        except Exception as exc:        # an experiment that does not apply to this workload (a full-rank S) is reported, not fatal
+            out[name] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
+    return out
+
+
 def measure_mfma_peak(device):
     from vmc_pde_amd import _native as nat
     blocks, iters = 512, 4000      # iters is a multiple of 16 (the kernel's unroll)
@@ -237,6 +264,7 @@ def main():
                          "deficient); cholesky-dense: the blocked factorisation of the full matrix always; eigh: TDVP() exactly as the reference constructs "
                          "it (tdvp.py:21-26: spectral pseudo-inverse, diagonalShift 0, svdTol 1e-11) with the rank-revealing decomposition; "
                          "eigh-dense: the same with rocSOLVER's syevd on the full matrix -- both reported BESIDE the headline")
+    ap.add_argument("--no-beside", action="store_true", help="skip the opt-in experiments measured after the timed region (`beside` in the line)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -394,6 +422,10 @@ def main():
             "rank_stage_ms": [dict(zip(order, r)) for r in per_rank],
             "allreduce_payload_bytes": payload_bytes,
         }
+        if world == 1 and not args.no_beside and args.solver == "cholesky" and args.jacobian == "f64":
+            # AFTER the timed region and not part of `value`: the opt-in experiments on the same problem and the same box, so that the
+            # numbers quoted beside the headline come from this run as well
+            line["beside"] = beside_headline(device, args, kwargs, theta)
         if world == 1 and not args.no_cpu_baseline and args.samples == WORKLOADS[args.workload]["n_samp"]:
             line["cpu_baseline"] = cpu_baseline(theta.cpu(), vs.net.inds_up, vs.net.inds_down, args.workload)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
