@@ -1180,7 +1180,10 @@ class TDVP:
     # ---- state carried from call to call (not in the reference, whose calls are independent) ---------------------
     def state_dict(self):
         """What a call inherits from the previous one: the global means used as the shift of the one-pass moments and the Gram
-        (centering / gramShift "auto").  With it a resumed run repeats the uninterrupted one bit for bit (examples/main.py)."""
+        (centering / gramShift "auto").  With it a resumed run repeats the uninterrupted one bit for bit (examples/main.py) on the
+        dense solve paths.  The low-rank routes (P >= LOWRANK_CHOL_MIN_P / LOWRANK_MIN_P, matrixFree) also inherit a plan and the
+        previous pivots, which are NOT part of this record: a resumed run starts with a planning call and no hint list, and differs
+        from the uninterrupted one at the level of the solve's accuracy (1e-10 |F|) from there on."""
         if self._ratio_event is not None:
             self._ratio_event.synchronize()
             self._uncentred_ok = bool(self._ratio_host[0] < 1e3)
