@@ -588,3 +588,43 @@ def test_jt_matvec_against_numpy(P, n, ldj):
         y_ref = JT[:, :n] @ z_ref
         assert np.abs(z.cpu().numpy() - z_ref).max() < 1e-13 * np.abs(z_ref).max()
         assert np.abs(y.cpu().numpy() - y_ref).max() < 1e-13 * np.abs(y_ref).max()
+
+
+@pytest.mark.parametrize("hidden", [(3,), (6, 6)])
+def test_lowrank_routes_on_small_models(hidden):
+    """A model with fewer parameters than the 128-column pad of the static plan (P = 37 / ~200): the forced low-rank solve and the
+    matrix-free step over several calls (planning, static, hints, columns ahead) against the dense factorisation."""
+    import vmc_pde_amd as V
+    spec = make_spec(2, 2, hidden, latent="Gauss", coupling="no_add", offset=[1.0, 1.0], seed=3)
+    th = random_theta(spec, 3, out_scale=0.05)
+    ep = V.EvolutionEquation(dim=2, name="advection_hamiltonian_wDiss")
+    N = 4096
+    g = torch.Generator().manual_seed(5)
+    z = O.latent_from_normals(spec, th, torch.randn(N, 2, generator=g, dtype=torch.float64), None)
+    vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()))
+    kw = dict(nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+    td = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine="dense")
+    u_d, _ = td(th.cuda(), 0.0, vs, ep, **kw)
+    td.check()
+    S, F = td.S0.clone(), td.F0.clone()
+    P = S.shape[0]
+    assert P < 256
+    D = 1e-4 * torch.diagonal(S) + 1e-6 * torch.diagonal(S).max()
+    nF = float(torch.linalg.norm(F))
+    for flags in (dict(choleskyEngine="lowrank"), dict(matrixFree=True)):
+        tp = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", **flags)
+        modes = []
+        for call in range(4):
+            u, _ = tp(th.cuda(), 0.0, vs, ep, **kw)
+            tp.check()
+            modes.append((tp.choleskyInfo["engine"], tp.choleskyInfo.get("mode")))
+            if tp.choleskyInfo["engine"] == "dense":        # (full rank within the cap: the forced engine hands over, as at any size)
+                break
+            du = u - u_d
+            assert float(torch.linalg.norm(S @ du + D * du)) < 1e-10 * nF, (flags, call, modes)
+            assert abs(float(tp.solverResidual)) < 1e-11
+        assert modes[0][0] in ("lowrank", "matrix-free", "dense"), modes
+        if modes[0][0] == "matrix-free":
+            assert [m for _, m in modes] == ["planning", "static", "static", "static"], modes
+        elif modes[0][0] == "lowrank":      # (the assembled route keeps planning when its buffers -- P rows -- cannot hold the 128-column pad)
+            assert all(m in ("planning", "static") for _, m in modes), modes

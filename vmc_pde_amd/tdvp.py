@@ -686,8 +686,8 @@ class TDVP:
         G, gws, t2, Su = w["G"], w["G_ws"], w["t2"], w["Su"]
         need = gws.numel() * 8
         w["LT"][:rmax].zero_()                                      # columns past the rank: zero, i.e. an identity block in G
-        self._arm_hints(w, P)
-        nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S0), S0.stride(0), P, self._lowrank_tol() or LOWRANK_TOL, 1, st["nsteps"], rmax, nat.ptr(w["LT"]), w["ldl"],
+        self._arm_hints(w, P)                                       # (rmax is the padded size of G; a small P caps the rank below it)
+        nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S0), S0.stride(0), P, self._lowrank_tol() or LOWRANK_TOL, 1, st["nsteps"], min(rmax, P), nat.ptr(w["LT"]), w["ldl"],
                  nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), w["ws"].numel() * 8, nat.stream())
         st["host"].copy_(w["state"], non_blocking=True)             # for the next call
         st["head"].copy_(w["ws"][:4], non_blocking=True)
@@ -910,7 +910,7 @@ class TDVP:
                 skip_ptr = nat.C.c_void_p(w["ws"].data_ptr() + nat.lib().vmcpde_lowrank_skip_flag_byte_offset())
 
                 def block_step():
-                    nat.call("vmcpde_lowrank_step", None, P, tol, rmax, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]),
+                    nat.call("vmcpde_lowrank_step", None, P, tol, min(rmax, P), nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]),
                              wsb, nat.stream())
                     if world == 1:
                         nat.call("vmcpde_gram_columns", nat.ptr(JT), ldj, P, n, cand_ptr, nat.ptr(mean), Ntot, nat.ptr(w["Scol"]), ldl,
@@ -921,10 +921,13 @@ class TDVP:
                         mpi.allreduce_sum_(w["Scol"])
                         rows = cand_view.long()
                         w["Scol"][:, :P] = w["Scol"][:, :P] / Ntot - torch.outer(mean[rows], mean)
-                    nat.call("vmcpde_lowrank_step", nat.ptr(w["Scol"]), P, tol, rmax, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]),
+                    nat.call("vmcpde_lowrank_step", nat.ptr(w["Scol"]), P, tol, min(rmax, P), nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]),
                              nat.ptr(w["ws"]), wsb, nat.stream())
 
-                w["LT"][:rmax].zero_()
+                if plan is None:
+                    w["LT"].zero_()          # (planning: the pad of the plan made below may reach past this call's rank cap)
+                else:
+                    w["LT"][:rmax].zero_()
                 self._arm_hints(w, P)
                 hints_on = bool(self.pivotHints) and os.environ.get("VMCPDE_PIVOT_HINTS", "1") != "0" and os.environ.get("VMCPDE_HINT_COLUMNS", "1") != "0"
                 ahead = 0
@@ -932,7 +935,7 @@ class TDVP:
                     # the columns of S at the previous call's pivots -- this call's preferred candidates -- in ONE pass over J: gather of
                     # those rows, a GEMM batched over sample chunks (one library GEMM with K = n runs on a handful of workgroups), the
                     # mean term; the block steps whose candidates all come from the list then need no pass of their own
-                    ahead = min(_round_up(plan.get("prev_rank", plan["rank"]), 32), rmax)
+                    ahead = min(_round_up(plan.get("prev_rank", plan["rank"]), 32), rmax, P)
                     idx = w["piv"][:ahead].long()               # (read before the factorisation overwrites it: stream order)
                     JH = Jv[idx]                                 # ahead x n, contiguous
                     ckn = next((c for c in (4096, 2048, 1024, 128) if n % c == 0), 0)
@@ -954,7 +957,7 @@ class TDVP:
                         for _ in range(4):
                             block_step()
                         steps += 4
-                        nat.call("vmcpde_lowrank_step", None, P, tol, rmax, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]),
+                        nat.call("vmcpde_lowrank_step", None, P, tol, min(rmax, P), nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]),
                                  wsb, nat.stream())           # (a selection settles `state`)
                         w["state_host"].copy_(w["state"], non_blocking=True)
                         torch.cuda.current_stream(device).synchronize()
@@ -971,7 +974,7 @@ class TDVP:
                 else:
                     for _ in range(plan["nsteps"]):
                         block_step()
-                    nat.call("vmcpde_lowrank_step", None, P, tol, rmax, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), wsb,
+                    nat.call("vmcpde_lowrank_step", None, P, tol, min(rmax, P), nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), wsb,
                              nat.stream())
                     plan["host"].copy_(w["state"], non_blocking=True)
                     plan["head"].copy_(w["ws"][:5], non_blocking=True)
@@ -1010,7 +1013,7 @@ class TDVP:
                 while not fin and r < rmax and extra < 16:            # (the plan's steps did not suffice for these samples: go on, the host is here anyway)
                     block_step()
                     block_step()
-                    nat.call("vmcpde_lowrank_step", None, P, tol, rmax, nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), wsb,
+                    nat.call("vmcpde_lowrank_step", None, P, tol, min(rmax, P), nat.ptr(w["LT"]), ldl, nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), wsb,
                              nat.stream())
                     extra += 2
                     r, fin = read_state()
