@@ -628,3 +628,15 @@ def test_lowrank_routes_on_small_models(hidden):
             assert [m for _, m in modes] == ["planning", "static", "static", "static"], modes
         elif modes[0][0] == "lowrank":      # (the assembled route keeps planning when its buffers -- P rows -- cannot hold the 128-column pad)
             assert all(m in ("planning", "static") for _, m in modes), modes
+    # the reference's spectral solve, matrix-free, on the same small model
+    ts = V.TDVP(svdTol=1e-6, spectralEngine="dense")
+    us, _ = ts(th.cuda(), 0.0, vs, ep, **kw)
+    ts.check()
+    tm = V.TDVP(svdTol=1e-6, matrixFree=True)
+    for call in range(3):
+        um, _ = tm(th.cuda(), 0.0, vs, ep, **kw)
+        tm.check()
+        assert tm.spectralInfo["engine"] == "matrix-free"
+        assert float((tm.ev - ts.ev).abs().max()) < 1e-12 * float(ts.ev[-1])
+        assert float(torch.linalg.norm(S @ (um - us))) < 1e-9 * nF
+
