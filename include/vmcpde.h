@@ -310,7 +310,8 @@ int vmcpde_lowrank_begin(const double* diag, int32_t P, int32_t* state, void* wo
 int vmcpde_lowrank_step(const double* Scol, int32_t P, double tol_rel, int32_t max_rank, double* LT, int64_t ldl, int32_t* piv,
                         int32_t* state, void* workspace, int64_t workspace_bytes, void* stream);
 /* y = JT (JT^T v) over the P x n_samples Jacobian block (row stride ldj): the product S0 v = y / N - m (m.v) of the matrix-free step's
- * refinement and diagnostics, two HBM-bound passes over the Jacobian; z ([dev] n_samples) receives JT^T v. */
+ * refinement and diagnostics, two HBM-bound passes over the Jacobian; z ([dev] n_samples) receives JT^T v.  y == NULL: the first
+ * pass only -- what a quadratic form v^T <w^2 O~ O~^T> v needs (the SExp norm of the adaptive stepper, stepper.py:71 with main.py:24-26). */
 int64_t vmcpde_jt_matvec_workspace_bytes(int32_t P, int64_t n_samples);
 int vmcpde_jt_matvec(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, const double* v, double* z, double* y, void* workspace,
                      int64_t workspace_bytes, void* stream);

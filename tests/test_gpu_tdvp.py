@@ -194,12 +194,20 @@ def test_tdvp_snr_regularised_solve_parity(case, engine):
             continue                                     # numerical null space only
         n_clusters += 1
         r_p, r_o, s_p, s_o = float(rho_p[lo:hi].sum()), float(rho_o[lo:hi].sum()), float(f_p[lo:hi].sum()), float(f_o[lo:hi].sum())
-        assert abs(r_p - r_o) < 1e-8 * abs(r_o), (lo, hi, r_p, r_o)
-        assert abs(s_p - s_o) < 1e-8 * abs(s_o), (lo, hi, s_p, s_o)
-        assert abs(np.sqrt(N * s_p / r_p) / np.sqrt(N * s_o / r_o) - 1) < 1e-8            # the cluster's signal-to-noise ratio
+        # Besides the relative 1e-8: an eigenspace separated by 1e-6 lambda_max is determined to an angle backward-error / gap by ANY
+        # correct decomposition (1e-14 / 1e-6 = 1e-8 rad); a thousandth of that, 1e-11 rad, is allowed as an absolute term -- it moves
+        # a tiny projection |V_c^T F|^2 of a large F by 2 |V_c^T F| |F| x angle and v^T G v by 2 sqrt(G_cc G_max) x angle.  (Without
+        # it the relative bound alone sat at the run-to-run noise of the library kernels for the weakest modes: one red run in five
+        # on mode 196 of the d = 6 case, 1.9e-8 of a projection of 3.7e-8.)
+        tol_s = 1e-8 * abs(s_o) + 2e-11 * np.sqrt(abs(s_o)) * float(nF)
+        tol_r = 1e-8 * abs(r_o) + 2e-11 * np.sqrt(abs(r_o) * float(rho_o.abs().max()))
+        assert abs(r_p - r_o) < tol_r, (lo, hi, r_p, r_o)
+        assert abs(s_p - s_o) < tol_s, (lo, hi, s_p, s_o)
+        tol_q = 1e-8 + 0.5 * (tol_s / abs(s_o) + tol_r / abs(r_o))
+        assert abs(np.sqrt(N * s_p / r_p) / np.sqrt(N * s_o / r_o) - 1) < tol_q            # the cluster's signal-to-noise ratio
         if hi - lo == 1:                                 # an isolated mode: the per-mode quantities themselves (tdvp.py:70-71)
             n_single += 1
-            assert abs(float(snr_p[lo]) / float(snr_o[lo]) - 1) < 1e-8 and abs(float(rho_p[lo]) / float(rho_o[lo]) - 1) < 1e-8
+            assert abs(float(snr_p[lo]) / float(snr_o[lo]) - 1) < tol_q and abs(float(rho_p[lo]) / float(rho_o[lo]) - 1) < tol_r / abs(r_o) + 1e-12
     assert n_clusters >= 5 and n_single >= 5
     # second, loose bound on every significant mode individually (inside a cluster the split between its modes is basis dependent)
     well = ev > 1e-9 * lam
@@ -762,3 +770,63 @@ def test_int8_gram_on_an_fp32_jacobian_config5():
     to = O.TDVPOracle()
     to.rhs(th, 0.1, O.VarStateOracle(spec, th), eo, z)
     assert rel_err(S_b, to.S0) < 1e-6 and rel_err(F_b, to.F0) < 1e-6
+
+
+def test_sexp_operator_is_the_matrix_to_the_norm_function():
+    """`TDVP.SExp_operator()` -- what the steppers pass to the norm function instead of the matrix SExp (stepper.py:71, `v @ S @ v` of
+    main.py:24-26): the quadratic form and the product S v from passes over the retained Jacobian against the dense matrix, the
+    fall-back to the matrix for any other use, and an AdaptiveHeun step through it against one through the matrix."""
+    import vmc_pde_amd as V
+    import vmc_pde_amd.tdvp as T
+    spec = make_spec(4, 3, (7, 5), latent="Gauss", coupling="different_add", seed=6)
+    th = random_theta(spec, 6, out_scale=0.05)
+    vs = make_varstate(spec, th)
+    ep = V.EvolutionEquation(dim=4, name="advection_hamiltonian_wDiss")
+    N = 3000                                                    # (not a multiple of anything: ragged tails of both passes)
+    kw = dict(nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+    tp = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky")
+    tp(th.cuda(), 0.0, vs, ep, **kw)
+    op = tp.SExp_operator()
+    assert isinstance(op, T.GramOperator) and tp._SExp is None  # nothing formed yet
+    g = torch.Generator().manual_seed(3)
+    v = torch.randn(th.numel(), generator=g, dtype=torch.float64).cuda()
+    w = torch.randn(th.numel(), generator=g, dtype=torch.float64).cuda()
+    q1, q2, q3 = v @ op @ v, torch.dot(v, op @ v), torch.matmul(v, op) @ v
+    mixed = v @ op @ w
+    assert tp._SExp is None                                     # still nothing formed
+    S = tp.SExp                                                 # the dense matrix (a weighted Gram), as before
+    ref = float(v @ S @ v)
+    for q in (q1, q2, q3):
+        assert abs(float(q) - ref) < 1e-12 * abs(ref), (float(q), ref)
+    assert abs(float(mixed) - float(v @ S @ w)) < 1e-12 * float(torch.linalg.norm(S)) * float(torch.linalg.norm(v)) * float(torch.linalg.norm(w))
+    assert float(torch.linalg.norm(op @ v - S @ v)) < 1e-12 * float(torch.linalg.norm(S @ v))
+    # every other use is the matrix itself
+    assert torch.equal(op.clone(), S) and torch.equal(op[2:5, 1], S[2:5, 1]) and op.shape == S.shape
+    assert float((op - S).abs().max()) == 0.0 and torch.equal(torch.diagonal(op), torch.diagonal(S))
+    assert torch.is_tensor(tp.SExp_operator())                  # once the matrix exists it is handed out
+
+    class ThroughTheMatrix:                                     # an engine without the operator: the steppers read f.SExp
+        def __init__(self, engine):
+            self.engine = engine
+
+        def __call__(self, *a, **k):
+            return self.engine(*a, **k)
+
+        @property
+        def SExp(self):
+            return self.engine.SExp
+
+        def check(self, *a, **k):
+            return self.engine.check(*a, **k)
+
+    res = []
+    for wrap in (False, True):
+        vs2 = make_varstate(spec, th)
+        te = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky")
+        st = V.AdaptiveHeun(timeStep=1e-3, tol=1e-7, maxStep=1e-1)
+        y, dt, _ = st.step(0.0, ThroughTheMatrix(te) if wrap else te, th.cuda(), normFunction=lambda v, S: v @ S @ v, evolutionEq=ep, psi=vs2, **kw)
+        res.append((y, dt, st.dt, te._SExp is None))
+    (y_a, dt_a, next_a, lazy_a), (y_b, dt_b, next_b, lazy_b) = res
+    assert lazy_a and not lazy_b                                # the operator path never formed the matrix
+    assert abs(dt_a - dt_b) < 1e-10 * dt_b and abs(next_a - next_b) < 1e-10 * next_b      # (step sizes follow the error: equal to its round-off)
+    assert float(torch.linalg.norm(y_a - y_b)) < 1e-9 * float(torch.linalg.norm(y_b - th.cuda()))

@@ -1095,7 +1095,7 @@ extern "C" int64_t vmcpde_jt_matvec_workspace_bytes(int32_t P, int64_t n_samples
 
 extern "C" int vmcpde_jt_matvec(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, const double* v, double* z, double* y, void* workspace,
                                 int64_t workspace_bytes, void* stream) {
-  VMC_REQUIRE(JT && v && z && y && workspace, "vmcpde_jt_matvec: null argument");
+  VMC_REQUIRE(JT && v && z && workspace, "vmcpde_jt_matvec: null argument");     // (y == NULL: z = JT^T v only, one pass)
   VMC_REQUIRE(P >= 1 && n_samples >= 1 && ldj >= n_samples, "vmcpde_jt_matvec: bad shape");
   VMC_REQUIRE(workspace_bytes >= vmcpde_jt_matvec_workspace_bytes(P, n_samples), "vmcpde_jt_matvec: workspace too small");
   const int64_t ldz = (n_samples + 63) / 64 * 64;
@@ -1113,7 +1113,7 @@ extern "C" int vmcpde_jt_matvec(const double* JT, int64_t ldj, int32_t P, int64_
   hipLaunchKernelGGL(matvec_cols_kernel, dim3((unsigned)colblocks, (unsigned)nslice), dim3(MV_THREADS), 0, st, JT, ldj, P, n_samples, v, rows_per_slice,
                      zpart, ldz, vec2);
   hipLaunchKernelGGL(matvec_cols_reduce_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, st, zpart, nslice, ldz, n_samples, z);
-  hipLaunchKernelGGL(matvec_rows_kernel, dim3((unsigned)P), dim3(256), 0, st, JT, ldj, P, n_samples, z, y, vec2);
+  if (y) hipLaunchKernelGGL(matvec_rows_kernel, dim3((unsigned)P), dim3(256), 0, st, JT, ldj, P, n_samples, z, y, vec2);
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -85,7 +85,8 @@ class AdaptiveHeun:
             half_a, _, _ = _heun_increment(rhs, y_start, t, 0.5 * dt, k_first=k0)         # stage 2 (stage 0 reused)
             half_b, _, _ = _heun_increment(rhs, y_start + half_a, t + 0.5 * dt, 0.5 * dt)  # stages 3, 4
             fine = half_a + half_b
-            err = normFunction(fine - coarse, f.SExp)
+            # (an engine that can take the quadratic form v @ S @ v from its Jacobian in one pass hands over an operator, not the matrix)
+            err = normFunction(fine - coarse, f.SExp_operator() if hasattr(f, "SExp_operator") else f.SExp)
             ratio = float(self.tolerance / err)
             used = dt
             dt = min(dt * min(max(self.SAFETY * ratio ** self.EXPONENT, self.SHRINK_MIN), self.GROW_MAX), self.maxStep)

@@ -79,6 +79,81 @@ class StaticPlanOutdated(FloatingPointError):
     retry_step = True
 
 
+class _VecTimesGram:
+    """`v @ S` for a GramOperator S, pending: `(v @ S) @ v` -- how the reference's norm function spells the quadratic form
+    (main.py:24-26) -- is then ONE pass over the Jacobian; anything else turns it into the vector S v."""
+
+    def __init__(self, op, v):
+        self._op, self._v = op, v
+
+    def __matmul__(self, w):
+        if torch.is_tensor(w) and w.dim() == 1 and (w is self._v or (w.data_ptr() == self._v.data_ptr() and w.shape == self._v.shape)):
+            return self._op.quadratic_form(self._v)
+        return self.vector() @ w
+
+    def vector(self):
+        return self._op.matvec(self._v)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        args = tuple(a.vector() if isinstance(a, _VecTimesGram) else a for a in args)
+        return func(*args, **(kwargs or {}))
+
+    def __getattr__(self, name):
+        return getattr(self.vector(), name)
+
+
+class GramOperator:
+    """SExp = <(logp O~)(logp O~)^T> (tdvp.py:47) as the adaptive stepper uses it -- the matrix of a norm, `v @ S @ v` (stepper.py:71,
+    main.py:24-26) -- without forming it: v^T SExp v = (1/N) sum_n (logp_n (J_n - m).v)^2 is one pass over the retained Jacobian
+    (`vmcpde_jt_matvec`, first pass: 0.4 ms at the headline size) where the P x P matrix is a second Gram (17 ms).  `v @ S @ v`,
+    `S @ v` and `torch.dot(v, S @ v)` take the passes; every other use (indexing, arithmetic, `.cpu()`, ...) gets the dense matrix of
+    `TDVP.SExp`, formed on that first use."""
+
+    def __init__(self, tdvp):
+        self._t = tdvp
+
+    def dense(self):
+        return self._t.SExp
+
+    def quadratic_form(self, v):
+        return self._t._sexp_form(v)
+
+    def matvec(self, v):
+        return self._t._sexp_matvec(v)
+
+    def __matmul__(self, v):
+        if torch.is_tensor(v) and v.dim() == 1:
+            return self.matvec(v)
+        return self.dense() @ v
+
+    def __rmatmul__(self, v):
+        if torch.is_tensor(v) and v.dim() == 1:
+            return _VecTimesGram(self, v)
+        return v @ self.dense()
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", "")
+        if name in ("matmul", "__matmul__", "mv") and len(args) == 2 and not kwargs:
+            a, b = args
+            if isinstance(b, GramOperator) and torch.is_tensor(a):
+                return b.__rmatmul__(a)
+            if isinstance(a, GramOperator) and torch.is_tensor(b):
+                return a.__matmul__(b)
+        if name == "__rmatmul__" and len(args) == 2 and not kwargs and isinstance(args[0], GramOperator) and torch.is_tensor(args[1]):
+            return args[0].__rmatmul__(args[1])
+        args = tuple(a.dense() if isinstance(a, GramOperator) else a for a in args)
+        return func(*args, **kwargs)
+
+    def __getattr__(self, name):
+        return getattr(self.dense(), name)
+
+    def __getitem__(self, idx):
+        return self.dense()[idx]
+
+
 @dataclass
 class TDVP:
     useSNR: bool = False
@@ -452,6 +527,54 @@ class TDVP:
         if self._SExp is None:
             self._SExp = self._weighted_gram(self._lazy["logp"])
         return self._SExp
+
+    def SExp_operator(self):
+        """What the steppers hand to the norm function in place of the matrix `SExp`: a GramOperator where the quadratic form can be
+        taken from the retained fp64 Jacobian in one pass, the (lazily formed) matrix itself otherwise or once it exists."""
+        z = getattr(self, "_lazy", None)
+        if self._SExp is not None or z is None or z.get("owner") is None or z["JT"].dtype != global_defs.tReal or \
+                os.environ.get("VMCPDE_SEXP_OPERATOR", "1") == "0":
+            return self.SExp
+        return GramOperator(self)
+
+    def _sexp_pass(self, v):
+        """q_n = logp_n (J_n - m).v for this rank's samples (first pass of `vmcpde_jt_matvec`), and the lazily kept record."""
+        z = self._lazy
+        if z["owner"] is not None and z["owner"].workspace_generation(z["n"]) != z["gen"]:
+            raise RuntimeError("SExp / rhoVar / snr are computed lazily from the Jacobian of the last TDVP call, but the VarState "
+                               "has evaluated another batch of the same size since (its workspace was overwritten): read these "
+                               "attributes before calling psi(...), psi.hessian or psi.evaluate again")
+        P, n, device = z["P"], z["n"], z["JT"].device
+        v = v.to(device=device, dtype=global_defs.tReal).contiguous()
+        if self.frozenParameters is not None:
+            v = v * self._frozen_mask(P, device)
+        need = nat.lib().vmcpde_jt_matvec_workspace_bytes(P, n)
+        w = getattr(self, "_sexp_ws", None)
+        if w is None or w[0].numel() * 8 < need or w[1].numel() < n or w[0].device != device:
+            w = self._sexp_ws = (torch.empty(need // 8, dtype=global_defs.tReal, device=device), torch.empty(n, dtype=global_defs.tReal, device=device))
+        with torch.cuda.device(device):
+            nat.call("vmcpde_jt_matvec", nat.ptr(z["JT"]), z["ldj"], P, n, nat.ptr(v), nat.ptr(w[1]), None, nat.ptr(w[0]), w[0].numel() * 8, nat.stream())
+        return z["logp"].reshape(-1) * (w[1][:n] - torch.dot(z["mean"], v)), v
+
+    def _sexp_form(self, v):
+        """v^T SExp v = (1/N) sum_n q_n^2 (tdvp.py:47 with the centred gradients of :41-42), summed over the ranks."""
+        q, _ = self._sexp_pass(v)
+        tot = torch.dot(q, q).reshape(1)
+        mpi.allreduce_sum_(tot)
+        return tot[0] / self._lazy["Ntot"]
+
+    def _sexp_matvec(self, v):
+        """SExp v = (1/N) sum_n logp_n q_n (J_n - m): a second pass with the weights folded into z."""
+        z = self._lazy
+        q, vv = self._sexp_pass(v)
+        g = (z["logp"].reshape(-1) * q).contiguous()
+        Jv = z["JT"][:z["P"], :z["n"]]
+        y = Jv @ g - z["mean"] * g.sum()
+        mpi.allreduce_sum_(y)
+        y = y / z["Ntot"]
+        if self.frozenParameters is not None:
+            y = y * self._frozen_mask(z["P"], y.device)
+        return y
 
     @property
     def rhoVar(self):
