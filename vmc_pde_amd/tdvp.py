@@ -33,6 +33,23 @@ F32_BLOCK_MIN_SHIFT = 1e-4   # smallest diagonalShift the fp32-block Gram is all
 _BORDER_PIVOT = 1e200    # corner of the bordered matrix: any value above F^T A^-1 F keeps the last pivot positive
 
 
+def _long_k_product(A, B):
+    """A @ B^T for row-major A (m x K) and B (n x K) with a long contraction and a small result: as ONE library GEMM such a shape runs on
+    a handful of workgroups (256 x 256 x 4213: 0.23 ms), as a batched GEMM over chunks of the contraction with the chunk sums added
+    up it fills the chip (0.03 ms).  Rows may be strided (views into padded buffers)."""
+    K = A.shape[1]
+    if K < 1024:
+        return A @ B.T
+    if K % 64:                                         # (a zero pad of the contraction: two small copies)
+        pad = 64 - K % 64
+        A, B = torch.nn.functional.pad(A, (0, pad)), torch.nn.functional.pad(B, (0, pad))
+        K += pad
+    ck = 128 if K % 128 == 0 else 64
+    A3 = A.view(A.shape[0], K // ck, ck).permute(1, 0, 2)
+    B3 = B.view(B.shape[0], K // ck, ck).permute(1, 2, 0)
+    return torch.bmm(A3, B3).sum(0)
+
+
 def _lapack_threads(P):
     """Thread cap for the host eigh: OpenBLAS' default (one thread per hardware thread, 64+) makes a 411 x 411 eigh take 94 ms
     instead of 9 ms with one thread, and a 4213 x 4213 one 5.3 s instead of 1.3 s with 16 (measured on the GPU box's host)."""
@@ -866,7 +883,8 @@ class TDVP:
             return None
         self._lowrank_last_rank = r
         Y, Xn, Q1 = self._lowrank_range_basis(w, P, r, device)
-        T = Q1.T @ (S @ Q1)
+        SQ = S @ Q1
+        T = _long_k_product(Q1.T.contiguous(), SQ.T.contiguous())
         T = 0.5 * (T + T.T)
         # (the r x r core on one host LAPACK thread takes 1.6 ms against 5.4 ms for syevd's launch chain at r = 238, but the host
         # synchronisation it needs costs the calling loop more than that: 33.0 against 30.2 ms per TDVP call -- measured and dropped)
@@ -900,7 +918,8 @@ class TDVP:
             w["hq"] = torch.empty(w["LT"].shape[0] + 1, dtype=global_defs.tReal, device=device)
         nat.call("vmcpde_householder_rows", nat.ptr(w["LT"]), w["ldl"], P, r, nat.ptr(w["YT"]), nat.ptr(w["tau"]), nat.ptr(w["hq"]), nat.stream())
         Y = w["YT"][:r, :P]                                        # r x P: row k = reflector k
-        Tinv = torch.triu(Y @ Y.T, 1)
+        Yp = w["YT"][:r]                                           # (r x ldl: the pad columns are zero)
+        Tinv = torch.triu(_long_k_product(Yp, Yp), 1)
         Tinv.diagonal().copy_(1.0 / w["tau"][:r])                  # T^-1 = strict upper part of Y^T Y + diag(1 / tau)
         # T itself (r x r, what dlarft forms), then T Y^T as a GEMM: a triangular solve with P right-hand sides makes rocBLAS allocate
         # a workspace that fails for r in the thousands
