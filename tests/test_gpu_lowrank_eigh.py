@@ -210,19 +210,22 @@ def test_pivot_hints_change_the_candidates_and_nothing_else():
     assert r1c == r1 and torch.equal(piv1c, piv1) and torch.equal(LT1c, LT1)
 
 
-def test_householder_rows_against_numpy():
+@pytest.mark.parametrize("P,r", [(613, 90), (613, 91), (1500, 2), (700, 1), (17000, 9)])
+def test_householder_rows_against_numpy(P, r):
+    """(two reflectors per launch for an even number of columns, a single-step launch for the odd one out, single steps only beyond
+    16 384 rows)"""
     from vmc_pde_amd import _native as nat
     rng = np.random.default_rng(2)
-    P, r = 613, 90
     L = rng.standard_normal((P, r)) * 10.0 ** (-np.arange(r) / 11.0)              # columns over eight decades
-    L[:, 17] = 0.0
-    L[17, 17] = 0.3                                                                # a column that is (after 17 steps: nearly) a unit vector
+    if r > 17:
+        L[:, 17] = 0.0
+        L[17, 17] = 0.3                                                            # a column that is (after 17 steps: nearly) a unit vector
     ldl = (P + 63) // 64 * 64
     LT = torch.zeros((r, ldl), dtype=torch.float64, device="cuda")
     LT[:, :P] = torch.from_numpy(L.T)
     YT = torch.full((r, ldl), float("nan"), dtype=torch.float64, device="cuda")
     tau = torch.zeros(r, dtype=torch.float64, device="cuda")
-    scratch = torch.zeros(r + 1, dtype=torch.float64, device="cuda")
+    scratch = torch.zeros(2 * r + 2, dtype=torch.float64, device="cuda")
     nat.call("vmcpde_householder_rows", nat.ptr(LT), ldl, P, r, nat.ptr(YT), nat.ptr(tau), nat.ptr(scratch), nat.stream())
     torch.cuda.synchronize()
     Y, t, Rm = YT.cpu().numpy()[:, :P].T, tau.cpu().numpy(), LT.cpu().numpy()[:, :P].T
@@ -230,10 +233,16 @@ def test_householder_rows_against_numpy():
     assert np.all(t > 0.0) and np.all(t <= 2.0)
     # compact WY: Q = I - Y T Y^T with T^-1 = strict upper(Y^T Y) + diag(1 / tau)
     Tinv = np.triu(Y.T @ Y, 1) + np.diag(1.0 / t)
-    Q = np.eye(P) - Y @ np.linalg.solve(Tinv, Y.T)
-    assert np.abs(Q.T @ Q - np.eye(P)).max() < 5e-15
+    if P <= 2000:
+        Q = np.eye(P) - Y @ np.linalg.solve(Tinv, Y.T)
+        assert np.abs(Q.T @ Q - np.eye(P)).max() < 5e-15
+        QtL = Q.T @ L
+    else:                                       # (large P: Q implicitly -- its first r columns, what the engine uses, and Q^T L)
+        Q1 = -Y @ np.linalg.solve(Tinv, Y[:r].T)
+        Q1[:r] += np.eye(r)
+        assert np.abs(Q1.T @ Q1 - np.eye(r)).max() < 5e-15
+        QtL = L - Y @ np.linalg.solve(Tinv.T, Y.T @ L)
     # Q^T L = [R; 0], column by column relative to the column's norm (the factor's columns differ by 1e8 in size)
-    QtL = Q.T @ L
     cn = np.linalg.norm(L, axis=0)
     assert np.abs(QtL[r:] / cn).max() < 1e-14
     # what the kernel leaves in LT: the strict upper part of R (column k itself is never rewritten -- every workgroup of step k reads it)

@@ -863,6 +863,134 @@ __global__ __launch_bounds__(HQ_THREADS) void hqr_step_kernel(double* __restrict
   }
 }
 
+// Two steps per launch: every workgroup derives BOTH reflectors itself -- v_k from column k as above, then column k + 1 with H_k applied,
+// held in registers and never written (all workgroups read the same untouched column k + 1), and v_{k+1} from it -- and applies both
+// to its own column, also through registers: one read and one write of the column, four block sums, half the launch boundaries
+// (a dependent launch costs ~4.7 us, the second reflector's redundant dot product and norm ~1.5).  Workgroup 0 writes the two
+// reflectors; R[k][k + 1], the one entry of column k + 1 that H_k changes above the diagonal, goes to rsup[k + 1] and is copied into
+// LT by a final launch (the column must stay untouched while other workgroups of this launch read it).  A thread holds elements
+// i = k + 1 + t + 1024 e, e < HQ_MAXE (4, 8 or 16 by the number of rows): P <= 16 384.
+constexpr int HQ_MAXE_LIMIT = 16;
+template <int HQ_MAXE>
+__global__ __launch_bounds__(HQ_THREADS) void hqr_pair_kernel(double* __restrict__ LT, int64_t ldl, int P, int k, double* __restrict__ YT,
+                                                              double* __restrict__ tau, double* __restrict__ norm2, double* __restrict__ rsup) {
+  __shared__ double red[HQ_WAVES];
+  __shared__ double s_a2;
+  const int t = threadIdx.x, m = blockIdx.x;
+  const double* __restrict__ x = LT + (int64_t)k * ldl;
+  const double* __restrict__ y = LT + (int64_t)(k + 1) * ldl;
+  const int i0 = k + 1 + t;
+  const int ne = (P - k - 1 + HQ_THREADS - 1) / HQ_THREADS;        // (<= HQ_MAXE, checked by the host)
+  // ---- reflector k
+  double s2;
+  if (k == 0) {
+    s2 = 0.0;
+    for (int i = 1 + t; i < P; i += HQ_THREADS) s2 = fma(x[i], x[i], s2);
+    s2 = block_sum(s2, red);
+  } else {
+    s2 = norm2[k];
+  }
+  const double alpha = x[k];
+  const double nrm2 = fma(alpha, alpha, s2);
+  double tk = 2.0, scale = 0.0;
+  if (nrm2 > 0.0) {
+    const double beta = -copysign(sqrt(nrm2), alpha);
+    tk = (beta - alpha) / beta;
+    scale = 1.0 / (alpha - beta);
+  }
+  // ---- column k + 1 with H_k applied (entries below row k in registers), and reflector k + 1 from it
+  double vx[HQ_MAXE], yr[HQ_MAXE];
+  double dot = (t == 0) ? y[k] : 0.0;
+#pragma unroll
+  for (int e = 0; e < HQ_MAXE; ++e) {
+    const int i = i0 + e * HQ_THREADS;
+    const bool in = e < ne && i < P;
+    vx[e] = in ? x[i] * scale : 0.0;
+    yr[e] = in ? y[i] : 0.0;
+    dot = fma(vx[e], yr[e], dot);
+  }
+  dot = block_sum(dot, red);
+  const double w = tk * dot;
+  const double yk_new = y[k] - w;                                  // R[k][k + 1]
+  double s2b = 0.0;
+#pragma unroll
+  for (int e = 0; e < HQ_MAXE; ++e) {
+    yr[e] = fma(-w, vx[e], yr[e]);
+    if (e > 0 || t > 0) s2b = fma(yr[e], yr[e], s2b);              // (element i = k + 1 is the diagonal: thread 0, e = 0)
+  }
+  if (t == 0) s_a2 = yr[0];
+  s2b = block_sum(s2b, red);                                       // (its barriers publish s_a2)
+  const double alpha2 = s_a2;
+  const double nrm2b = fma(alpha2, alpha2, s2b);
+  double tk2 = 2.0, scale2 = 0.0;
+  if (nrm2b > 0.0) {
+    const double beta2 = -copysign(sqrt(nrm2b), alpha2);
+    tk2 = (beta2 - alpha2) / beta2;
+    scale2 = 1.0 / (alpha2 - beta2);
+  }
+#pragma unroll
+  for (int e = 0; e < HQ_MAXE; ++e) yr[e] = (e == 0 && t == 0) ? 1.0 : yr[e] * scale2;      // now v_{k+1} (zero beyond P)
+  if (m == 0) {
+    double* __restrict__ ya = YT + (int64_t)k * ldl;
+    double* __restrict__ yb = YT + (int64_t)(k + 1) * ldl;
+    for (int i = t; i <= k; i += HQ_THREADS) {
+      ya[i] = (i == k) ? 1.0 : 0.0;
+      yb[i] = 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < HQ_MAXE; ++e) {
+      const int i = i0 + e * HQ_THREADS;
+      if (e < ne && i < (int)ldl) {
+        ya[i] = (i < P) ? vx[e] : 0.0;
+        yb[i] = (i < P) ? yr[e] : 0.0;
+      }
+    }
+    for (int i = i0 + ne * HQ_THREADS; i < (int)ldl; i += HQ_THREADS) { ya[i] = 0.0; yb[i] = 0.0; }   // (pad columns past the last full stride)
+    if (t == 0) { tau[k] = tk; tau[k + 1] = tk2; rsup[k + 1] = yk_new; }
+    return;
+  }
+  // ---- the workgroup's own column c = k + 1 + m: H_k, then H_{k+1}
+  double* __restrict__ z = LT + (int64_t)(k + 1 + m) * ldl;
+  double cr[HQ_MAXE];
+  double d1 = (t == 0) ? z[k] : 0.0;
+#pragma unroll
+  for (int e = 0; e < HQ_MAXE; ++e) {
+    const int i = i0 + e * HQ_THREADS;
+    cr[e] = (e < ne && i < P) ? z[i] : 0.0;
+    d1 = fma(vx[e], cr[e], d1);
+  }
+  d1 = block_sum(d1, red);
+  const double w1 = tk * d1;
+  if (t == 0) z[k] -= w1;
+  double d2 = 0.0;
+#pragma unroll
+  for (int e = 0; e < HQ_MAXE; ++e) {
+    cr[e] = fma(-w1, vx[e], cr[e]);
+    d2 = fma(yr[e], cr[e], d2);
+  }
+  d2 = block_sum(d2, red);
+  const double w2 = tk2 * d2;
+  double next = 0.0;                                                // (m == 1) sum of squares of column k + 2 below ITS diagonal
+#pragma unroll
+  for (int e = 0; e < HQ_MAXE; ++e) {
+    const int i = i0 + e * HQ_THREADS;
+    const double v = fma(-w2, yr[e], cr[e]);
+    if (e < ne && i < P) {
+      z[i] = v;
+      if (i > k + 2) next = fma(v, v, next);
+    }
+  }
+  if (m == 1) {
+    next = block_sum(next, red);
+    if (t == 0) norm2[k + 2] = next;
+  }
+}
+
+__global__ void hqr_commit_kernel(double* __restrict__ LT, int64_t ldl, int npairs, const double* __restrict__ rsup) {
+  const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (q < npairs) LT[(int64_t)(2 * q + 1) * ldl + 2 * q] = rsup[2 * q + 1];
+}
+
 int64_t pivchol_ws_doubles(int P) {
   const int64_t nwg = (P + PC_ROWS - 1) / PC_ROWS;
   return 8 /* PivWork, padded */ + (int64_t)nwg * PC_ROWS /* d */ + 2 * nwg /* cand_val */ + 2 * nwg /* cand_sum */ + nwg /* cand_idx (2 x int32) */ + 8;
@@ -925,8 +1053,20 @@ extern "C" int vmcpde_pivoted_cholesky(const double* S, int64_t lds, int32_t P, 
 extern "C" int vmcpde_householder_rows(double* LT, int64_t ldl, int32_t P, int32_t r, double* YT, double* tau, double* scratch, void* stream) {
   VMC_REQUIRE(LT && YT && tau && scratch, "vmcpde_householder_rows: null argument");
   VMC_REQUIRE(P >= 1 && r >= 1 && r <= P && ldl >= P, "vmcpde_householder_rows: bad shape");
-  for (int k = 0; k < r; ++k)
-    hipLaunchKernelGGL(hqr_step_kernel, dim3(r - k), dim3(HQ_THREADS), 0, (hipStream_t)stream, LT, ldl, P, k, YT, tau, scratch);
+  hipStream_t st = (hipStream_t)stream;
+  double* norm2 = scratch;
+  double* rsup = scratch + r + 1;
+  const bool pairs = P <= HQ_MAXE_LIMIT * HQ_THREADS && env_int("VMCPDE_HQR_PAIRS", 1) != 0;      // two steps per launch (registers hold a column)
+  int k = 0, npairs = 0;
+  if (pairs)
+    for (; k + 1 < r; k += 2, ++npairs) {
+      const dim3 grid(r - k - 1), block(HQ_THREADS);
+      if (P <= 4 * HQ_THREADS) hipLaunchKernelGGL(hqr_pair_kernel<4>, grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rsup);
+      else if (P <= 8 * HQ_THREADS) hipLaunchKernelGGL(hqr_pair_kernel<8>, grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rsup);
+      else hipLaunchKernelGGL(hqr_pair_kernel<16>, grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rsup);
+    }
+  for (; k < r; ++k) hipLaunchKernelGGL(hqr_step_kernel, dim3(r - k), dim3(HQ_THREADS), 0, st, LT, ldl, P, k, YT, tau, norm2);
+  if (npairs) hipLaunchKernelGGL(hqr_commit_kernel, dim3((npairs + 255) / 256), dim3(256), 0, st, LT, ldl, npairs, rsup);
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }
