@@ -322,8 +322,8 @@ int vmcpde_gram_columns(const double* JT, int64_t ldj, int32_t P, int64_t n_samp
 /* Householder QR of the P x r matrix whose columns are the rows of LT (destroyed: the strict upper part of R, the rest is scratch).  YT: [dev] r x ldl,
  * row k = reflector v_k (zeros before k, v_k[k] = 1, zeros from P on); tau: [dev] r, H_k = I - tau_k v_k v_k^T, Q = H_0 ... H_{r-1}
  * = I - Y T Y^T with T^-1 = strict upper part of Y^T Y + diag(1 / tau)  (tau_k is never 0: a column that is already zero below its
- * diagonal gets v = e_k, tau = 2).  Two reflectors per launch while a column fits the registers of a workgroup (P <= 16 384), one
- * otherwise.  scratch: [dev] 2 r + 2 doubles. */
+ * diagonal gets v = e_k, tau = 2).  Two reflectors per launch while their columns fit the registers of a workgroup (P <= 16 384), one
+ * otherwise.  scratch: [dev] 5 r + 5 doubles. */
 int vmcpde_householder_rows(double* LT, int64_t ldl, int32_t P, int32_t r, double* YT, double* tau, double* scratch, void* stream);
 
 #ifdef __cplusplus

@@ -210,11 +210,13 @@ def test_pivot_hints_change_the_candidates_and_nothing_else():
     assert r1c == r1 and torch.equal(piv1c, piv1) and torch.equal(LT1c, LT1)
 
 
-@pytest.mark.parametrize("P,r", [(613, 90), (613, 91), (1500, 2), (700, 1), (17000, 9)])
-def test_householder_rows_against_numpy(P, r):
-    """(two reflectors per launch for an even number of columns, a single-step launch for the odd one out, single steps only beyond
-    16 384 rows)"""
+@pytest.mark.parametrize("P,r", [(613, 90), (613, 91), (5000, 7), (1500, 2), (700, 1), (4097, 4), (9000, 5), (17000, 9)])
+@pytest.mark.parametrize("block", [2, 4])
+def test_householder_rows_against_numpy(P, r, block, monkeypatch):
+    """(two reflectors per launch up to 16 384 rows -- four with VMCPDE_HQR_BLOCK=4 up to 8192, then two for what is left --, a
+    single-step launch for the odd one out and beyond)"""
     from vmc_pde_amd import _native as nat
+    monkeypatch.setenv("VMCPDE_HQR_BLOCK", str(block))
     rng = np.random.default_rng(2)
     L = rng.standard_normal((P, r)) * 10.0 ** (-np.arange(r) / 11.0)              # columns over eight decades
     if r > 17:
@@ -225,7 +227,7 @@ def test_householder_rows_against_numpy(P, r):
     LT[:, :P] = torch.from_numpy(L.T)
     YT = torch.full((r, ldl), float("nan"), dtype=torch.float64, device="cuda")
     tau = torch.zeros(r, dtype=torch.float64, device="cuda")
-    scratch = torch.zeros(2 * r + 2, dtype=torch.float64, device="cuda")
+    scratch = torch.zeros(5 * r + 5, dtype=torch.float64, device="cuda")
     nat.call("vmcpde_householder_rows", nat.ptr(LT), ldl, P, r, nat.ptr(YT), nat.ptr(tau), nat.ptr(scratch), nat.stream())
     torch.cuda.synchronize()
     Y, t, Rm = YT.cpu().numpy()[:, :P].T, tau.cpu().numpy(), LT.cpu().numpy()[:, :P].T

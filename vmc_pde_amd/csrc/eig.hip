@@ -53,10 +53,27 @@ __device__ __forceinline__ void wave_argmax(double& v, int& idx) {
   }
 }
 
+// Sum over the 64 lanes, every lane returns it.  Six DPP steps (quad permutes, row rotations, row broadcasts: ~200 cycles) and a
+// v_readlane of lane 63 instead of six ds_bpermute exchanges (~1100 cycles: __shfl_xor goes through the LDS crossbar on this chip).
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+  v += dpp_move<0xb1>(v);       // quad_perm [1,0,3,2]
+  v += dpp_move<0x4e>(v);       // quad_perm [2,3,0,1]
+  v += dpp_move<0x124>(v);      // row_ror:4
+  v += dpp_move<0x128>(v);      // row_ror:8   -- every lane of a row of 16 holds the row's sum
+  v += dpp_move<0x142>(v);      // row_bcast:15: lane 15 of each row to the next row (rows without a source add 0)
+  v += dpp_move<0x143>(v);      // row_bcast:31: lane 31 to rows 2 and 3 -- lane 63 now holds the sum of all four rows
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 // d = diag(S); per-workgroup candidates (largest entry, its row, sum of the positive entries) into candidate buffer 0
@@ -863,132 +880,166 @@ __global__ __launch_bounds__(HQ_THREADS) void hqr_step_kernel(double* __restrict
   }
 }
 
-// Two steps per launch: every workgroup derives BOTH reflectors itself -- v_k from column k as above, then column k + 1 with H_k applied,
-// held in registers and never written (all workgroups read the same untouched column k + 1), and v_{k+1} from it -- and applies both
-// to its own column, also through registers: one read and one write of the column, four block sums, half the launch boundaries
-// (a dependent launch costs ~4.7 us, the second reflector's redundant dot product and norm ~1.5).  Workgroup 0 writes the two
-// reflectors; R[k][k + 1], the one entry of column k + 1 that H_k changes above the diagonal, goes to rsup[k + 1] and is copied into
-// LT by a final launch (the column must stay untouched while other workgroups of this launch read it).  A thread holds elements
-// i = k + 1 + t + 1024 e, e < HQ_MAXE (4, 8 or 16 by the number of rows): P <= 16 384.
+// NR steps per launch (NR = 2 or 4): every workgroup derives ALL NR reflectors itself -- v_k from column k as above, then for
+// j = 1 .. NR - 1 column k + j with H_k .. H_{k+j-1} applied, held in registers and never written (all workgroups read the same
+// untouched columns), and v_{k+j} from it -- and applies them to its own column, also through registers: one read and one write of
+// the column.  A dependent launch costs ~4.7 us; the redundant part is NR (NR - 1) / 2 dot products and NR - 1 norms of block sums at
+// ~0.35 us each.  Workgroup 0 writes the reflectors; the entries of R above the diagonal INSIDE the block (columns k + 1 .. k + NR - 1,
+// rows k ..) go to rblk and are copied into LT by a final launch -- those columns must stay untouched while other workgroups of this
+// launch read them.  A thread holds elements i = k + 1 + t + 1024 e, e < MAXE (4, 8 or 16 by the number of rows): P <= 16 384.
 constexpr int HQ_MAXE_LIMIT = 16;
-template <int HQ_MAXE>
-__global__ __launch_bounds__(HQ_THREADS) void hqr_pair_kernel(double* __restrict__ LT, int64_t ldl, int P, int k, double* __restrict__ YT,
-                                                              double* __restrict__ tau, double* __restrict__ norm2, double* __restrict__ rsup) {
+constexpr int HQ_RB = 4;                                 // doubles of rblk per column
+template <int NR, int MAXE>
+__global__ __launch_bounds__(HQ_THREADS) void hqr_multi_kernel(double* __restrict__ LT, int64_t ldl, int P, int k, double* __restrict__ YT,
+                                                               double* __restrict__ tau, double* __restrict__ norm2, double* __restrict__ rblk) {
   __shared__ double red[HQ_WAVES];
-  __shared__ double s_a2;
+  __shared__ double s_diag;
   const int t = threadIdx.x, m = blockIdx.x;
-  const double* __restrict__ x = LT + (int64_t)k * ldl;
-  const double* __restrict__ y = LT + (int64_t)(k + 1) * ldl;
   const int i0 = k + 1 + t;
-  const int ne = (P - k - 1 + HQ_THREADS - 1) / HQ_THREADS;        // (<= HQ_MAXE, checked by the host)
-  // ---- reflector k
-  double s2;
-  if (k == 0) {
-    s2 = 0.0;
-    for (int i = 1 + t; i < P; i += HQ_THREADS) s2 = fma(x[i], x[i], s2);
-    s2 = block_sum(s2, red);
-  } else {
-    s2 = norm2[k];
-  }
-  const double alpha = x[k];
-  const double nrm2 = fma(alpha, alpha, s2);
-  double tk = 2.0, scale = 0.0;
-  if (nrm2 > 0.0) {
-    const double beta = -copysign(sqrt(nrm2), alpha);
-    tk = (beta - alpha) / beta;
-    scale = 1.0 / (alpha - beta);
-  }
-  // ---- column k + 1 with H_k applied (entries below row k in registers), and reflector k + 1 from it
-  double vx[HQ_MAXE], yr[HQ_MAXE];
-  double dot = (t == 0) ? y[k] : 0.0;
-#pragma unroll
-  for (int e = 0; e < HQ_MAXE; ++e) {
-    const int i = i0 + e * HQ_THREADS;
-    const bool in = e < ne && i < P;
-    vx[e] = in ? x[i] * scale : 0.0;
-    yr[e] = in ? y[i] : 0.0;
-    dot = fma(vx[e], yr[e], dot);
-  }
-  dot = block_sum(dot, red);
-  const double w = tk * dot;
-  const double yk_new = y[k] - w;                                  // R[k][k + 1]
-  double s2b = 0.0;
-#pragma unroll
-  for (int e = 0; e < HQ_MAXE; ++e) {
-    yr[e] = fma(-w, vx[e], yr[e]);
-    if (e > 0 || t > 0) s2b = fma(yr[e], yr[e], s2b);              // (element i = k + 1 is the diagonal: thread 0, e = 0)
-  }
-  if (t == 0) s_a2 = yr[0];
-  s2b = block_sum(s2b, red);                                       // (its barriers publish s_a2)
-  const double alpha2 = s_a2;
-  const double nrm2b = fma(alpha2, alpha2, s2b);
-  double tk2 = 2.0, scale2 = 0.0;
-  if (nrm2b > 0.0) {
-    const double beta2 = -copysign(sqrt(nrm2b), alpha2);
-    tk2 = (beta2 - alpha2) / beta2;
-    scale2 = 1.0 / (alpha2 - beta2);
-  }
-#pragma unroll
-  for (int e = 0; e < HQ_MAXE; ++e) yr[e] = (e == 0 && t == 0) ? 1.0 : yr[e] * scale2;      // now v_{k+1} (zero beyond P)
-  if (m == 0) {
-    double* __restrict__ ya = YT + (int64_t)k * ldl;
-    double* __restrict__ yb = YT + (int64_t)(k + 1) * ldl;
-    for (int i = t; i <= k; i += HQ_THREADS) {
-      ya[i] = (i == k) ? 1.0 : 0.0;
-      yb[i] = 0.0;
+  const int ne = (P - k - 1 + HQ_THREADS - 1) / HQ_THREADS;        // (<= MAXE, checked by the host)
+  double v[NR][MAXE];             // v[j]: column k + j below row k (first with the earlier reflectors applied, then scaled to v_{k+j})
+  double top[NR];                 // entry of column k + j in row k (only thread 0's copy is used)
+  double tk[NR];
+  // ---- reflector k from column k
+  {
+    const double* __restrict__ x = LT + (int64_t)k * ldl;
+    double s2;
+    if (k == 0) {
+      s2 = 0.0;
+      for (int i = 1 + t; i < P; i += HQ_THREADS) s2 = fma(x[i], x[i], s2);
+      s2 = block_sum(s2, red);
+    } else {
+      s2 = norm2[k];
+    }
+    const double alpha = x[k];
+    const double nrm2 = fma(alpha, alpha, s2);
+    double scale = 0.0;
+    tk[0] = 2.0;
+    if (nrm2 > 0.0) {
+      const double beta = -copysign(sqrt(nrm2), alpha);
+      tk[0] = (beta - alpha) / beta;
+      scale = 1.0 / (alpha - beta);
     }
 #pragma unroll
-    for (int e = 0; e < HQ_MAXE; ++e) {
+    for (int e = 0; e < MAXE; ++e) {
       const int i = i0 + e * HQ_THREADS;
-      if (e < ne && i < (int)ldl) {
-        ya[i] = (i < P) ? vx[e] : 0.0;
-        yb[i] = (i < P) ? yr[e] : 0.0;
-      }
+      v[0][e] = (e < ne && i < P) ? x[i] * scale : 0.0;
     }
-    for (int i = i0 + ne * HQ_THREADS; i < (int)ldl; i += HQ_THREADS) { ya[i] = 0.0; yb[i] = 0.0; }   // (pad columns past the last full stride)
-    if (t == 0) { tau[k] = tk; tau[k + 1] = tk2; rsup[k + 1] = yk_new; }
+    top[0] = 1.0;                 // (v_k[k] = 1: the row-k term of every dot product with v_k is the column's own row-k entry)
+  }
+  // ---- columns k + 1 .. k + NR - 1 with the earlier reflectors applied, and their reflectors
+#pragma unroll
+  for (int j = 1; j < NR; ++j) {
+    const double* __restrict__ y = LT + (int64_t)(k + j) * ldl;
+    top[j] = y[k];
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int i = i0 + e * HQ_THREADS;
+      v[j][e] = (e < ne && i < P) ? y[i] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < j; ++a) {                                   // H_{k+a}: v[a] is zero above row k + a, one at it
+      double dot = (a == 0 && t == 0) ? top[j] : 0.0;
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) dot = fma(v[a][e], v[j][e], dot);
+      dot = block_sum(dot, red);
+      const double w = tk[a] * dot;
+      if (a == 0) top[j] -= w;
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) v[j][e] = fma(-w, v[a][e], v[j][e]);
+    }
+    // what is above the diagonal of column k + j now is final: R[k + a][k + j], a < j (row k: top[j]; row k + a: thread a - 1, e = 0)
+    if (m == 0) {
+      if (t == 0) rblk[(int64_t)(k + j) * HQ_RB + 0] = top[j];
+#pragma unroll
+      for (int a = 1; a < j; ++a)
+        if (t == a - 1) rblk[(int64_t)(k + j) * HQ_RB + a] = v[j][0];
+    }
+    // reflector k + j: diagonal entry = element i = k + j (thread j - 1, e = 0), norm of what lies below it
+    double s2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int i = i0 + e * HQ_THREADS;
+      if (i > k + j) s2 = fma(v[j][e], v[j][e], s2);
+    }
+    __syncthreads();                                                // (s_diag may still be read from the previous column)
+    if (t == j - 1) s_diag = v[j][0];
+    s2 = block_sum(s2, red);                                        // (its barriers publish s_diag)
+    const double alpha = s_diag;
+    const double nrm2 = fma(alpha, alpha, s2);
+    double scale = 0.0;
+    tk[j] = 2.0;
+    if (nrm2 > 0.0) {
+      const double beta = -copysign(sqrt(nrm2), alpha);
+      tk[j] = (beta - alpha) / beta;
+      scale = 1.0 / (alpha - beta);
+    }
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int i = i0 + e * HQ_THREADS;
+      v[j][e] = (i < k + j) ? 0.0 : ((i == k + j) ? 1.0 : v[j][e] * scale);      // (zero beyond P: loaded as zero)
+    }
+  }
+  if (m == 0) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      double* __restrict__ yo = YT + (int64_t)(k + j) * ldl;
+      for (int i = t; i <= k; i += HQ_THREADS) yo[i] = (j == 0 && i == k) ? 1.0 : 0.0;
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) {
+        const int i = i0 + e * HQ_THREADS;
+        if (e < ne && i < (int)ldl) yo[i] = (i < P) ? v[j][e] : 0.0;
+      }
+      for (int i = i0 + ne * HQ_THREADS; i < (int)ldl; i += HQ_THREADS) yo[i] = 0.0;       // (pad columns past the last full stride)
+      if (t == 0) tau[k + j] = tk[j];
+    }
     return;
   }
-  // ---- the workgroup's own column c = k + 1 + m: H_k, then H_{k+1}
-  double* __restrict__ z = LT + (int64_t)(k + 1 + m) * ldl;
-  double cr[HQ_MAXE];
-  double d1 = (t == 0) ? z[k] : 0.0;
+  // ---- the workgroup's own column c = k + NR - 1 + m: H_k .. H_{k+NR-1}
+  double* __restrict__ z = LT + (int64_t)(k + NR - 1 + m) * ldl;
+  double cr[MAXE];
+  double ztop = z[k];
 #pragma unroll
-  for (int e = 0; e < HQ_MAXE; ++e) {
+  for (int e = 0; e < MAXE; ++e) {
     const int i = i0 + e * HQ_THREADS;
     cr[e] = (e < ne && i < P) ? z[i] : 0.0;
-    d1 = fma(vx[e], cr[e], d1);
   }
-  d1 = block_sum(d1, red);
-  const double w1 = tk * d1;
-  if (t == 0) z[k] -= w1;
-  double d2 = 0.0;
 #pragma unroll
-  for (int e = 0; e < HQ_MAXE; ++e) {
-    cr[e] = fma(-w1, vx[e], cr[e]);
-    d2 = fma(yr[e], cr[e], d2);
+  for (int a = 0; a < NR; ++a) {
+    double dot = (a == 0 && t == 0) ? ztop : 0.0;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) dot = fma(v[a][e], cr[e], dot);
+    dot = block_sum(dot, red);
+    const double w = tk[a] * dot;
+    if (a == 0) ztop -= w;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) cr[e] = fma(-w, v[a][e], cr[e]);
   }
-  d2 = block_sum(d2, red);
-  const double w2 = tk2 * d2;
-  double next = 0.0;                                                // (m == 1) sum of squares of column k + 2 below ITS diagonal
+  if (t == 0) z[k] = ztop;
+  double next = 0.0;                                                // (m == 1) sum of squares of column k + NR below ITS diagonal
 #pragma unroll
-  for (int e = 0; e < HQ_MAXE; ++e) {
+  for (int e = 0; e < MAXE; ++e) {
     const int i = i0 + e * HQ_THREADS;
-    const double v = fma(-w2, yr[e], cr[e]);
     if (e < ne && i < P) {
-      z[i] = v;
-      if (i > k + 2) next = fma(v, v, next);
+      z[i] = cr[e];
+      if (i > k + NR) next = fma(cr[e], cr[e], next);
     }
   }
   if (m == 1) {
     next = block_sum(next, red);
-    if (t == 0) norm2[k + 2] = next;
+    if (t == 0) norm2[k + NR] = next;
   }
 }
 
-__global__ void hqr_commit_kernel(double* __restrict__ LT, int64_t ldl, int npairs, const double* __restrict__ rsup) {
+// the entries of R above the diagonal inside the blocks of NR columns starting at k_begin, k_begin + NR, ... (nblocks of them)
+__global__ void hqr_commit_kernel(double* __restrict__ LT, int64_t ldl, int k_begin, int nr, int nblocks, const double* __restrict__ rblk) {
   const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (q < npairs) LT[(int64_t)(2 * q + 1) * ldl + 2 * q] = rsup[2 * q + 1];
+  const int per = nr * HQ_RB;
+  if (q >= nblocks * per) return;
+  const int blk = q / per, j = (q - blk * per) / HQ_RB, a = q % HQ_RB;
+  if (j == 0 || a >= j) return;
+  const int k = k_begin + blk * nr;
+  LT[(int64_t)(k + j) * ldl + (k + a)] = rblk[(int64_t)(k + j) * HQ_RB + a];
 }
 
 int64_t pivchol_ws_doubles(int P) {
@@ -1055,18 +1106,35 @@ extern "C" int vmcpde_householder_rows(double* LT, int64_t ldl, int32_t P, int32
   VMC_REQUIRE(P >= 1 && r >= 1 && r <= P && ldl >= P, "vmcpde_householder_rows: bad shape");
   hipStream_t st = (hipStream_t)stream;
   double* norm2 = scratch;
-  double* rsup = scratch + r + 1;
-  const bool pairs = P <= HQ_MAXE_LIMIT * HQ_THREADS && env_int("VMCPDE_HQR_PAIRS", 1) != 0;      // two steps per launch (registers hold a column)
-  int k = 0, npairs = 0;
-  if (pairs)
-    for (; k + 1 < r; k += 2, ++npairs) {
-      const dim3 grid(r - k - 1), block(HQ_THREADS);
-      if (P <= 4 * HQ_THREADS) hipLaunchKernelGGL(hqr_pair_kernel<4>, grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rsup);
-      else if (P <= 8 * HQ_THREADS) hipLaunchKernelGGL(hqr_pair_kernel<8>, grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rsup);
-      else hipLaunchKernelGGL(hqr_pair_kernel<16>, grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rsup);
+  double* rblk = scratch + r + 1;
+  // several steps per launch while a workgroup's registers hold the columns: two up to 16 384 rows.  (Four -- VMCPDE_HQR_BLOCK=4, up
+  // to 8192 rows -- measured no better than two: 1.05 against 1.01 ms for 203 columns at P = 4213, 1.49 ms with one; the thirteen block
+  // sums of a launch of four, two barriers of sixteen waves each, cost what the two saved launch boundaries do.)
+  const int cap = env_int("VMCPDE_HQR_BLOCK", 2);
+  const dim3 block(HQ_THREADS);
+  int k = 0;
+  if (P <= 8 * HQ_THREADS && cap >= 4) {
+    const int k_begin = k;
+    int nblocks = 0;
+    for (; k + 3 < r; k += 4, ++nblocks) {
+      const dim3 grid(r - k - 3);
+      if (P <= 4 * HQ_THREADS) hipLaunchKernelGGL((hqr_multi_kernel<4, 4>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
+      else hipLaunchKernelGGL((hqr_multi_kernel<4, 8>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
     }
-  for (; k < r; ++k) hipLaunchKernelGGL(hqr_step_kernel, dim3(r - k), dim3(HQ_THREADS), 0, st, LT, ldl, P, k, YT, tau, norm2);
-  if (npairs) hipLaunchKernelGGL(hqr_commit_kernel, dim3((npairs + 255) / 256), dim3(256), 0, st, LT, ldl, npairs, rsup);
+    if (nblocks) hipLaunchKernelGGL(hqr_commit_kernel, dim3((nblocks * 4 * HQ_RB + 255) / 256), dim3(256), 0, st, LT, ldl, k_begin, 4, nblocks, rblk);
+  }
+  if (P <= HQ_MAXE_LIMIT * HQ_THREADS && cap >= 2) {
+    const int k_begin = k;
+    int nblocks = 0;
+    for (; k + 1 < r; k += 2, ++nblocks) {
+      const dim3 grid(r - k - 1);
+      if (P <= 4 * HQ_THREADS) hipLaunchKernelGGL((hqr_multi_kernel<2, 4>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
+      else if (P <= 8 * HQ_THREADS) hipLaunchKernelGGL((hqr_multi_kernel<2, 8>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
+      else hipLaunchKernelGGL((hqr_multi_kernel<2, 16>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
+    }
+    if (nblocks) hipLaunchKernelGGL(hqr_commit_kernel, dim3((nblocks * 2 * HQ_RB + 255) / 256), dim3(256), 0, st, LT, ldl, k_begin, 2, nblocks, rblk);
+  }
+  for (; k < r; ++k) hipLaunchKernelGGL(hqr_step_kernel, dim3(r - k), block, 0, st, LT, ldl, P, k, YT, tau, norm2);
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -915,7 +915,7 @@ class TDVP:
         if w["YT"] is None or w["YT"].shape[0] < r:
             w["YT"] = torch.empty((w["LT"].shape[0], w["ldl"]), dtype=global_defs.tReal, device=device)
             w["tau"] = torch.empty(w["LT"].shape[0], dtype=global_defs.tReal, device=device)
-            w["hq"] = torch.empty(2 * w["LT"].shape[0] + 2, dtype=global_defs.tReal, device=device)
+            w["hq"] = torch.empty(5 * w["LT"].shape[0] + 5, dtype=global_defs.tReal, device=device)
         nat.call("vmcpde_householder_rows", nat.ptr(w["LT"]), w["ldl"], P, r, nat.ptr(w["YT"]), nat.ptr(w["tau"]), nat.ptr(w["hq"]), nat.stream())
         Y = w["YT"][:r, :P]                                        # r x P: row k = reflector k
         Yp = w["YT"][:r]                                           # (r x ldl: the pad columns are zero)
