@@ -87,12 +87,13 @@ def beside_headline(device, args, kwargs, theta, steps=10, warmup=5):
     draws its own samples, as in the timed loop; parity of each variant with the assembled fp64 path on the SAME samples is
     tests/test_gpu_lowrank_eigh.py, tests/test_gpu_tdvp.py and tests/test_gpu_gram.py)."""
     import vmc_pde_amd as V
-    out = {"note": "EXPERIMENTS, opt-in, measured after the timed region of this run; `value` is the assembled fp64 path"}
+    out = {"note": "measured after the timed region of this run; `value` is the assembled fp64 regularised-Cholesky path; the first two are opt-in EXPERIMENTS"}
     variants = {"matrixfree (S never assembled: TDVP(matrixFree=True), fp64)": dict(matrixFree=True),
                 "int8Gram (error-free sliced S-build on the int8 matrix pipe: TDVP(int8Gram=True))": dict(int8Gram=True)}
+    variants["TDVP() as the reference constructs it (tdvp.py:21-26: spectral pseudo-inverse, diagonalShift 0, svdTol 1e-11; not an experiment)"] = None
     for name, flags in variants.items():
         try:
-            tv = V.TDVP(diagonalShift=DIAG_SHIFT, svdTol=SVD_TOL, solver="cholesky", **flags)
+            tv = V.TDVP(diagonalShift=DIAG_SHIFT, svdTol=SVD_TOL, solver="cholesky", **flags) if flags is not None else V.TDVP()
             kw = dict(kwargs)
             for _ in range(warmup):
                 u, _ = tv(theta, 0.0, **kw)
