@@ -229,3 +229,47 @@ def test_store_infos_writes_the_run_record(tmp_path):
     assert path.endswith("infos.hdf5")
     with h5py.File(path, "r") as f:
         assert sorted(f.keys()) == ["entropy", "ev", "times"] and f["ev"][:].shape == (3, 4) and f["times"][2] == 0.2
+
+
+def test_gram_operator_protocol_routes_the_norm_function():
+    """GramOperator (vmc_pde_amd/tdvp.py): what the steppers hand to `normFunction(v, S)` in place of the matrix SExp.  The reference's
+    `v @ S @ v` (main.py:24-26) and its variants must reach the one-pass quadratic form / the two-pass product, everything else the
+    dense matrix -- checked on a stand-in engine that counts which of the three was used."""
+    from vmc_pde_amd.tdvp import GramOperator
+
+    class Engine:
+        def __init__(self, S):
+            self._S, self.used = S, []
+
+        @property
+        def SExp(self):
+            self.used.append("dense")
+            return self._S
+
+        def _sexp_form(self, v):
+            self.used.append("form")
+            return v @ self._S @ v
+
+        def _sexp_matvec(self, v):
+            self.used.append("matvec")
+            return self._S @ v
+
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(7, 7, generator=g, dtype=torch.float64)
+    S = A @ A.T
+    v, w = torch.randn(7, generator=g, dtype=torch.float64), torch.randn(7, generator=g, dtype=torch.float64)
+    ref = float(v @ S @ v)
+    for expr, expect in ((lambda op: v @ op @ v, ["form"]), (lambda op: torch.matmul(v, op) @ v, ["form"]),
+                         (lambda op: torch.dot(v, op @ v), ["matvec"]), (lambda op: torch.dot(v, torch.mv(op, v)), ["matvec"]),
+                         (lambda op: v @ (op @ v), ["matvec"])):
+        e = Engine(S)
+        assert abs(float(expr(GramOperator(e))) - ref) < 1e-12 * abs(ref) and e.used == expect, (e.used, expect)
+    e = Engine(S)
+    assert abs(float(v @ GramOperator(e) @ w) - float(v @ S @ w)) < 1e-12 * abs(ref) and e.used == ["matvec"]      # a different right operand
+    # every other use is the dense matrix
+    for expr in (lambda op: (op - S).abs().max(), lambda op: op[1, 2] - S[1, 2], lambda op: torch.linalg.norm(op) - torch.linalg.norm(S),
+                 lambda op: (op.clone() - S).abs().max(), lambda op: (torch.diagonal(op) - torch.diagonal(S)).abs().max(),
+                 lambda op: (A.T @ op @ A - A.T @ S @ A).abs().max()):
+        e = Engine(S)
+        assert float(expr(GramOperator(e))) == 0.0 and "dense" in e.used and "form" not in e.used
+    assert GramOperator(Engine(S)).shape == S.shape
