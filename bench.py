@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: TDVP steps/s at N_samp = 65 536, N_param ~ 4k (BASELINE.json, config C2).
 
-    python bench.py [--gpus N --steps K --warmup W]        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N --steps K --warmup W] [--workload C2|C3|C4]
+
+N > 1: one rank per GPU over RCCL.  Either under a launcher (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE are read from the environment) or
+plainly as `python bench.py --gpus N`: this process then starts the N ranks itself as fresh child processes
+(vmc_pde_amd/launch.py; the parent never touches the GPU), relays rank 0's JSON line and exits non-zero if any rank does.
+The documented 8-GPU line is `python bench.py --gpus 8 --workload C4` (BASELINE config 4: 262 144 samples = 8 x 32 768, weak).
 
 One "step" = one evaluation of TDVP.__call__ through `update` (tdvp.py:96-128: sample -> Eloc + Jacobian -> S, F ->
 solve; observables excluded) on synthetic inputs: 2-D Fokker-Planck (Kramers equation with anharmonic
@@ -108,6 +114,52 @@ def beside_headline(device, args, kwargs, theta, steps=10, warmup=5):
         except Exception as exc:        # an experiment that does not apply to this workload (a full-rank S) is reported, not fatal
             out[name] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
     return out
+
+
+def collective_record(device, world, rank, backend, payload_bytes, reps=10):
+    """What shows that `world` distinct devices took part in the step's collective (outside the timed region): the communicator's own
+    size, every rank's PCI bus id (C ABI: hipDeviceGetPCIBusId of the device the rank computes on), a one-hot vector summed through
+    the very path the step's all-reduce takes (every rank adds 1 at its own index: all ones = every rank contributed exactly once),
+    and the packed buffer's all-reduce timed alone, back to back after a barrier (its exposed cost when nothing overlaps it)."""
+    import ctypes as C
+    from vmc_pde_amd import _native as nat
+    from vmc_pde_amd import mpi_wrapper as mpi
+    collective = "abi" if (backend == "nccl" and os.environ.get("VMCPDE_COLLECTIVE", "torch") == "abi") else "torch"
+    buf = C.create_string_buffer(64)
+    with torch.cuda.device(device):
+        nat.call("vmcpde_device_bus_id", buf, 64)
+    mine = {"rank": rank, "device_index": device.index, "bus_id": buf.value.decode(), "pid": os.getpid()}
+    if collective == "abi":
+        info = (C.c_int32 * 4)()
+        nat.call("vmcpde_comm_info", mpi.abi_communicator(), info)
+        mine["abi_comm"] = {"count": int(info[0]), "user_rank": int(info[1]), "hip_device": int(info[2]), "rccl_version": int(info[3])}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    onehot = torch.zeros(world, dtype=torch.float64, device=device)
+    onehot[rank] = 1.0
+    mpi.allreduce_sum_(onehot)
+    pack = torch.zeros(payload_bytes // 8, dtype=torch.float64, device=device)
+    for _ in range(2):
+        mpi.allreduce_sum_(pack)
+    dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        mpi.allreduce_sum_(pack)
+    e1.record()
+    torch.cuda.synchronize()
+    alone_ms = e0.elapsed_time(e1) / reps
+    t = torch.tensor([alone_ms], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    alone_ms = float(t.item())
+    bus = [e["bus_id"] for e in everyone]
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collective": collective,
+            "ranks": everyone, "device_bus_ids": bus, "devices_distinct": len(set(bus)) == world,
+            "onehot_sum": [float(v) for v in onehot.cpu()], "every_rank_contributed_once": bool((onehot == 1.0).all()),
+            "allreduce_alone_ms": alone_ms, "allreduce_payload_bytes": payload_bytes,
+            # ring all-reduce: each rank sends and receives 2 (N - 1) / N of the payload
+            "allreduce_bus_GBps": 2.0 * (world - 1) / world * payload_bytes / (alone_ms * 1e-3) / 1e9}
 
 
 def measure_mfma_peak(device):
@@ -266,14 +318,24 @@ def main():
                          "it (tdvp.py:21-26: spectral pseudo-inverse, diagonalShift 0, svdTol 1e-11) with the rank-revealing decomposition; "
                          "eigh-dense: the same with rocSOLVER's syevd on the full matrix -- both reported BESIDE the headline")
     ap.add_argument("--no-beside", action="store_true", help="skip the opt-in experiments measured after the timed region (`beside` in the line)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched ranks (--gpus N > 1 without a launcher): seconds before they are stopped")
     args = ap.parse_args()
 
+    from vmc_pde_amd import launch
+    if args.gpus > 1 and not launch.under_launcher():
+        # not under torch.distributed.run: be the launcher.  N fresh interpreters, one per GPU; this process makes no GPU call before or
+        # after, relays rank 0's record and fails if any rank fails (mpi_wrapper.py:9-11: the reference gets its ranks from mpirun)
+        rc, out = launch.run_ranks([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], args.gpus, timeout=args.launch_timeout,
+                                   relay=lambda line: print(line, end="", flush=True))
+        if rc == 0 and not any(l.lstrip().startswith("{") for l in out.splitlines()):
+            print("bench: the ranks exited cleanly but rank 0 printed no record", file=sys.stderr)
+            rc = 1
+        sys.exit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                 "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f"bench: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     ndev = torch.cuda.device_count()
     local = local % max(ndev, 1)          # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
@@ -348,6 +410,14 @@ def main():
     from vmc_pde_amd import _native as nat
     npk = nat.lib().vmcpde_gram_packed_doubles(P)
     payload_bytes = int((npk + 2 * P + 4) * 8)
+    rccl = collective_record(device, world, rank, backend, payload_bytes) if world > 1 else None
+    # the replicated solve must give every rank the same bits (deterministic kernels on identical reduced inputs)
+    import hashlib
+    upd_host = update.detach().cpu().numpy()
+    digests = [hashlib.sha256(upd_host.tobytes()).hexdigest()]
+    if world > 1:
+        digests = [None] * world
+        dist.all_gather_object(digests, hashlib.sha256(upd_host.tobytes()).hexdigest())
 
     # outside the timed region: per-stage wall times with a device sync at each section boundary (the reference's
     # timing sections, tdvp.py:116-128), and one Heun integrator step = 2 TDVP steps (stepper.py:135-137)
@@ -422,7 +492,21 @@ def main():
             # per-rank HIP-event averages over the timed steps (ms): the Amdahl terms of the multi-GPU step
             "rank_stage_ms": [dict(zip(order, r)) for r in per_rank],
             "allreduce_payload_bytes": payload_bytes,
+            # the last timed step's update: its norm and leading entries (a run with the same total sample count on another number of
+            # ranks draws the same global batch, so these agree to the sums' round-off), and whether every rank holds the same bits
+            "update": {"norm": float(np.linalg.norm(upd_host)), "head": [float(v) for v in upd_host[:8]], "sha256": digests[0],
+                       "identical_on_all_ranks": len(set(digests)) == 1},
         }
+        if world > 1:
+            # the Amdahl terms read off this run: what one GPU would need for the same n_total samples (its own shard's stages x N, the
+            # replicated part once) against this step -- derived from the per-rank HIP-event brackets above, not a separate run
+            sf, gr, ar, rep = (float(np.max([r[i] for r in per_rank])) for i in range(4))
+            line["rccl"] = rccl
+            line["one_gpu_same_samples"] = {"ms_per_step_from_stages": world * (sf + gr) + rep, "this_run_ms_per_step": elapsed / args.steps * 1e3,
+                                            "speedup": (world * (sf + gr) + rep) / (elapsed / args.steps * 1e3),
+                                            "allreduce_bracket_ms_max_rank": ar,
+                                            "note": "N x (sample+flow + gram) + replicated of the slowest rank's brackets; the measured N = 1 "
+                                                    "line of the same workload is `python bench.py --workload " + args.workload + "`"}
         if world == 1 and not args.no_beside and args.solver == "cholesky" and args.jacobian == "f64":
             # AFTER the timed region and not part of `value`: the opt-in experiments on the same problem and the same box, so that the
             # numbers quoted beside the headline come from this run as well

@@ -228,6 +228,14 @@ int vmcpde_allreduce(double* packed, int64_t count, void* comm, void* stream);
 int vmcpde_comm_unique_id(void* id128 /* [host] 128 bytes out */);
 int vmcpde_comm_init_rank(void** comm, int32_t n_ranks, const void* id128, int32_t rank);
 int vmcpde_comm_destroy(void* comm);
+/* What a multi-GPU record must be able to show (ABI 5): that the communicator has the size the job claims and that every rank
+ * sits on a device of its own (global_defs.py:16-24: the reference's rank -> device map).
+ * vmcpde_comm_info: out4[0] = ncclCommCount, out4[1] = ncclCommUserRank, out4[2] = the HIP device the communicator is bound to
+ * (ncclCommCuDevice), out4[3] = the RCCL version code (ncclGetVersion); out4: [host] 4 x int32.
+ * vmcpde_device_bus_id: the PCI bus id ("0000:c5:00.0") of the calling thread's current HIP device, NUL-terminated, into
+ * out[0..len) ([host], len >= 16). */
+int vmcpde_comm_info(void* comm, int32_t* out4);
+int vmcpde_device_bus_id(char* out, int32_t len);
 
 /* diagnostic (no reference counterpart): `blocks` workgroups x 4 waves x `iters` x 8 back-to-back v_mfma_f64_16x16x4_f64
  * (2048 flop each) with operands in registers; out: [dev] blocks*256.  Times the fp64 matrix-pipe peak for the roofline. */

@@ -159,3 +159,41 @@ def test_two_ranks_over_rccl_match_single_rank(collective):
         assert float(torch.linalg.norm(r[0] - u0) / torch.linalg.norm(u0)) < 1e-7
         assert float(torch.linalg.norm(r[3] - u1) / torch.linalg.norm(u1)) < 1e-7
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][3], got[1][3])       # replicated solve: bit-identical
+
+
+def _bench_line(args, extra_env=None, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    env.update(extra_env or {})
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]                       # ONE record on stdout, whatever the ranks print
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks_and_proves_who_took_part():
+    """`python bench.py --gpus 2` outside any launcher (how the driver starts the N = 1 line): the parent spawns the two ranks
+    (vmc_pde_amd/launch.py), rank 0's record is the only line on stdout, it carries the collective's own account of the job, the
+    replicated update is the same bits on both ranks and equals the single-rank update on the same global batch (the sampler indexes
+    draws by global sample id).  Rehearsed over gloo with both ranks on the one GPU (RCCL refuses two ranks on one device); on a
+    multi-GPU node the same command runs backend nccl."""
+    common = ["--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--no-beside"]
+    two = _bench_line(["--gpus", "2", "--samples", "2048", *common], {"VMCPDE_DIST_BACKEND": "gloo"})
+    one = _bench_line(["--gpus", "1", "--samples", "4096", *common])
+    assert two["n_gpus"] == 2 and two["config"]["n_samp_total"] == 4096 and one["config"]["n_samp_total"] == 4096
+    r = two["rccl"]
+    assert r["backend"] == "gloo" and r["world_size"] == 2 and r["collective"] == "torch"
+    assert [e["rank"] for e in r["ranks"]] == [0, 1] and len({e["pid"] for e in r["ranks"]}) == 2
+    assert all(len(b) >= 7 for b in r["device_bus_ids"]) and r["devices_distinct"] is False     # both ranks on the one GPU here
+    assert r["onehot_sum"] == [1.0, 1.0] and r["every_rank_contributed_once"]
+    assert r["allreduce_payload_bytes"] == two["allreduce_payload_bytes"] == one["allreduce_payload_bytes"]
+    assert two["update"]["identical_on_all_ranks"] and len(two["rank_stage_ms"]) == 2
+    u2, u1 = np.asarray(two["update"]["head"]), np.asarray(one["update"]["head"])
+    assert abs(two["update"]["norm"] / one["update"]["norm"] - 1) < 1e-6 and np.linalg.norm(u2 - u1) < 1e-6 * np.linalg.norm(u1)
+    assert two["one_gpu_same_samples"]["ms_per_step_from_stages"] > 0
+    # weak scaling: `value` counts 65 536-sample steps over all ranks
+    assert abs(two["value"] - 2 / (two["ms_per_step"] * 1e-3) * 2048 / 65536) < 1e-9 * two["value"]

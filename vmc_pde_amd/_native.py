@@ -82,6 +82,8 @@ _PROTOS = {
     "vmcpde_comm_unique_id": (_int, [_vp]),
     "vmcpde_comm_init_rank": (_int, [C.POINTER(_vp), _i32, _vp, _i32]),
     "vmcpde_comm_destroy": (_int, [_vp]),
+    "vmcpde_comm_info": (_int, [_vp, C.POINTER(_i32)]),
+    "vmcpde_device_bus_id": (_int, [C.c_char_p, _i32]),
     "vmcpde_bench_mfma_f64": (_int, [_i32, _i32, _vp, _vp]),
     "vmcpde_chol_workspace_bytes": (_i64, [_i32]),
     "vmcpde_cholesky": (_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp]),

@@ -32,6 +32,8 @@ typedef int (*GetUniqueIdFn)(UniqueId*);
 typedef int (*CommInitRankFn)(void**, int, UniqueId, int);
 typedef int (*CommDestroyFn)(void*);
 typedef const char* (*GetErrorStringFn)(int);
+typedef int (*CommIntFn)(void*, int*);
+typedef int (*GetVersionFn)(int*);
 
 struct Rccl {
   AllReduceFn all_reduce = nullptr;
@@ -39,6 +41,8 @@ struct Rccl {
   CommInitRankFn comm_init_rank = nullptr;
   CommDestroyFn comm_destroy = nullptr;
   GetErrorStringFn error_string = nullptr;
+  CommIntFn comm_count = nullptr, comm_user_rank = nullptr, comm_device = nullptr;
+  GetVersionFn get_version = nullptr;
   bool tried = false, ok = false;
 };
 Rccl g_rccl;
@@ -68,6 +72,10 @@ bool load_rccl() {
   g_rccl.comm_init_rank = (CommInitRankFn)lookup(handle, "ncclCommInitRank");
   g_rccl.comm_destroy = (CommDestroyFn)lookup(handle, "ncclCommDestroy");
   g_rccl.error_string = (GetErrorStringFn)lookup(handle, "ncclGetErrorString");
+  g_rccl.comm_count = (CommIntFn)lookup(handle, "ncclCommCount");
+  g_rccl.comm_user_rank = (CommIntFn)lookup(handle, "ncclCommUserRank");
+  g_rccl.comm_device = (CommIntFn)lookup(handle, "ncclCommCuDevice");
+  g_rccl.get_version = (GetVersionFn)lookup(handle, "ncclGetVersion");
   g_rccl.ok = g_rccl.all_reduce && g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.comm_destroy;
   if (!g_rccl.ok) set_error("RCCL is loaded but lacks ncclAllReduce / ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy");
   return g_rccl.ok;
@@ -117,5 +125,31 @@ extern "C" int vmcpde_allreduce(double* packed, int64_t count, void* comm, void*
   if (!load_rccl()) return -3;
   const int rc = g_rccl.all_reduce(packed, packed, (size_t)count, kNcclFloat64, kNcclSum, comm, (hipStream_t)stream);
   if (rc != kNcclSuccess) return fail("ncclAllReduce", rc);
+  return 0;
+}
+
+extern "C" int vmcpde_comm_info(void* comm, int32_t* out4) {
+  VMC_REQUIRE(comm && out4, "vmcpde_comm_info: null argument");
+  if (!load_rccl()) return -3;
+  VMC_REQUIRE(g_rccl.comm_count && g_rccl.comm_user_rank && g_rccl.comm_device && g_rccl.get_version,
+              "RCCL lacks ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion");
+  int v[4] = {0, 0, 0, 0};
+  int rc = g_rccl.comm_count(comm, &v[0]);
+  if (rc != kNcclSuccess) return fail("ncclCommCount", rc);
+  rc = g_rccl.comm_user_rank(comm, &v[1]);
+  if (rc != kNcclSuccess) return fail("ncclCommUserRank", rc);
+  rc = g_rccl.comm_device(comm, &v[2]);
+  if (rc != kNcclSuccess) return fail("ncclCommCuDevice", rc);
+  rc = g_rccl.get_version(&v[3]);
+  if (rc != kNcclSuccess) return fail("ncclGetVersion", rc);
+  for (int i = 0; i < 4; ++i) out4[i] = v[i];
+  return 0;
+}
+
+extern "C" int vmcpde_device_bus_id(char* out, int32_t len) {
+  VMC_REQUIRE(out && len >= 16, "vmcpde_device_bus_id: need a buffer of at least 16 bytes");
+  int dev = 0;
+  VMC_CHECK_HIP(hipGetDevice(&dev));
+  VMC_CHECK_HIP(hipDeviceGetPCIBusId(out, len, dev));
   return 0;
 }

@@ -1258,7 +1258,7 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
     // the right of s + 1, goes to a side stream whose queue is masked to 7 of every 8 CUs, so the latency chain of super-panel s + 1
     // (diagonal blocks, strips, its K = 128 tiles) always finds free CUs and runs UNDER (b) instead of behind it.  (b) of super-panel s
     // must be complete before the last panel of s + 1 touches the first block column of s + 2 (mode-1 strips) and before (b) of s + 1.
-    bool overlap = (W > 1) && env_int("VMCPDE_CHOL_OVERLAP", 1) != 0;
+    bool overlap = (W > 1) && env_int("VMCPDE_CHOL_OVERLAP", 0) != 0;
     hipStream_t bulk = nullptr;
     if (overlap) {
       DeviceCtxLock lock;
