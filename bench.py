@@ -73,7 +73,7 @@ KERNEL_LABEL = {"f64": "gram_dma_kernel (fp64 MFMA syrk, + split-K reduce)",
 OUT_SCALE = 0.1                 # output kernels U(-0.1, 0.1) (the reference's 1e-5 makes J nearly degenerate)
 
 
-def build_problem(device, workload="C2", seed=1, jacobian_dtype=torch.float64):
+def build_problem(device, workload="C2", seed=1, jacobian_dtype=torch.float64, experimental=False):
     import vmc_pde_amd as V
     w = WORKLOADS[workload]
     dim, off = w["dim"], np.asarray(w["offset"])
@@ -84,7 +84,12 @@ def build_problem(device, workload="C2", seed=1, jacobian_dtype=torch.float64):
     vs.set_parameters(theta)
     eq = V.EvolutionEquation(dim=dim, name=EQ)
     eq.eqParams[EQ]["params"]["lam"] = w.get("lam", LAM)
-    tdvp = V.TDVP(diagonalShift=DIAG_SHIFT, svdTol=SVD_TOL, solver="cholesky", fuseMoments=os.environ.get("VMCPDE_FUSE_MOMENTS", "1") != "0")
+    # (the product class; the opt-in experiments -- --jacobian i8sliced / i8f32, --solver matrixfree / eigh-matrixfree -- are a subclass
+    # of it in vmc_pde_amd/experimental and are reported beside the headline, never as it)
+    cls = V.TDVP
+    if experimental:
+        from vmc_pde_amd.experimental import TDVP as cls
+    tdvp = cls(diagonalShift=DIAG_SHIFT, svdTol=SVD_TOL, solver="cholesky", fuseMoments=os.environ.get("VMCPDE_FUSE_MOMENTS", "1") != "0")
     return vs, eq, tdvp, theta
 
 
@@ -93,13 +98,14 @@ def beside_headline(device, args, kwargs, theta, steps=10, warmup=5):
     draws its own samples, as in the timed loop; parity of each variant with the assembled fp64 path on the SAME samples is
     tests/test_gpu_lowrank_eigh.py, tests/test_gpu_tdvp.py and tests/test_gpu_gram.py)."""
     import vmc_pde_amd as V
+    from vmc_pde_amd.experimental import TDVP as XTDVP
     out = {"note": "measured after the timed region of this run; `value` is the assembled fp64 regularised-Cholesky path; the first two are opt-in EXPERIMENTS"}
     variants = {"matrixfree (S never assembled: TDVP(matrixFree=True), fp64)": dict(matrixFree=True),
                 "int8Gram (error-free sliced S-build on the int8 matrix pipe: TDVP(int8Gram=True))": dict(int8Gram=True)}
     variants["TDVP() as the reference constructs it (tdvp.py:21-26: spectral pseudo-inverse, diagonalShift 0, svdTol 1e-11; not an experiment)"] = None
     for name, flags in variants.items():
         try:
-            tv = V.TDVP(diagonalShift=DIAG_SHIFT, svdTol=SVD_TOL, solver="cholesky", **flags) if flags is not None else V.TDVP()
+            tv = XTDVP(diagonalShift=DIAG_SHIFT, svdTol=SVD_TOL, solver="cholesky", **flags) if flags is not None else V.TDVP()
             kw = dict(kwargs)
             for _ in range(warmup):
                 u, _ = tv(theta, 0.0, **kw)
@@ -352,7 +358,9 @@ def main():
     from vmc_pde_amd import mpi_wrapper as mpi
     if not args.samples:
         args.samples = WORKLOADS[args.workload]["n_samp"]
-    vs, eq, tdvp, theta = build_problem(device, args.workload, jacobian_dtype=torch.float64 if args.jacobian in ("f64", "i8sliced") else torch.float32)
+    experimental = args.jacobian in ("i8sliced", "i8f32") or args.solver in ("matrixfree", "eigh-matrixfree")
+    vs, eq, tdvp, theta = build_problem(device, args.workload, jacobian_dtype=torch.float64 if args.jacobian in ("f64", "i8sliced") else torch.float32,
+                                        experimental=experimental)
     if args.jacobian in ("i8sliced", "i8f32"):      # experiments, reported BESIDE the fp64 headline, never instead of it
         tdvp.int8Gram = True
     if args.jacobian == "f32blocks":     # fp32 accumulation inside 128-sample blocks is not exactly PSD: needs the stronger shift
@@ -365,7 +373,8 @@ def main():
     elif args.solver != "cholesky":
         tdvp.solver, tdvp.diagonalShift, tdvp.svdTol = "eigh", 0.0, 1e-11
         tdvp.spectralEngine = "dense" if args.solver == "eigh-dense" else "auto"
-        tdvp.matrixFree = args.solver == "eigh-matrixfree"       # EXPERIMENT: the reference-default solve without an assembled S
+        if args.solver == "eigh-matrixfree":
+            tdvp.matrixFree = True                               # EXPERIMENT: the reference-default solve without an assembled S
     P = vs.numParameters
     n_total = args.samples * world
     kwargs = dict(evolutionEq=eq, psi=vs, nSamplesTDVP=n_total, nSamplesObs=n_total, timings=None, observables=False)

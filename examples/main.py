@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--svd-tol", type=float, default=1e-11,
                     help="spectral cut-off / absolute floor; wide networks (P in the thousands) need ~1e-6 with --diagonal-shift 1e-4")
     ap.add_argument("--matrix-free", action="store_true",
-                    help="EXPERIMENT: TDVP(matrixFree=True) -- S is never assembled (needs a rank-deficient S: large networks in low dimension)")
+                    help="EXPERIMENT: vmc_pde_amd.experimental.TDVP(matrixFree=True) -- S is never assembled (needs a rank-deficient S: large networks in low dimension)")
     ap.add_argument("--no-integrals", action="store_true",
                     help="skip the three small-ball integrals (tdvp.py:152-162; the reference evaluates them on every call and its "
                          "published records hold them, so they are on by default)")
@@ -72,7 +72,11 @@ def main():
 
     dt, maxStep = 1e-7, 1e-2                                                                                                               # main.py:108-118
     myStepper = stepper.FixedStepper(timeStep=dt, mode='Heun', maxStep=maxStep, increase_fac=1.3)
-    tdvpEq = tdvp.TDVP(diagonalShift=args.diagonal_shift, svdTol=args.svd_tol, solver=args.solver, matrixFree=args.matrix_free)
+    if args.matrix_free:
+        from vmc_pde_amd.experimental import TDVP as ExperimentalTDVP
+        tdvpEq = ExperimentalTDVP(diagonalShift=args.diagonal_shift, svdTol=args.svd_tol, solver=args.solver, matrixFree=True)
+    else:
+        tdvpEq = tdvp.TDVP(diagonalShift=args.diagonal_shift, svdTol=args.svd_tol, solver=args.solver)
     timings = util.Timings()
     evolutionEq = evolutionEq_mod.EvolutionEquation(dim=dim, name=m["evolution_type"])
     nSamplesTDVP = nSamplesObs = args.samples

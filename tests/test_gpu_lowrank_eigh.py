@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from oracle import vmc_oracle as O
+from vmc_pde_amd.experimental import TDVP as XTDVP      # the two opt-in experiments (matrixFree, int8Gram) live in a subclass
 from helpers import make_spec, random_theta, make_varstate, FixedSampler
 
 pytestmark = pytest.mark.gpu
@@ -483,7 +484,7 @@ def test_low_precision_gram_variants_keep_the_dense_solve(headline_net):
     g = torch.Generator().manual_seed(9)
     z = O.latent_from_normals(spec, th, torch.randn(N, 2, generator=g, dtype=torch.float64), None)
     vs32 = make_varstate(spec, th, sampler=FixedSampler(z.cuda()), jacobian_dtype=torch.float32)
-    tp = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", int8Gram=True)
+    tp = XTDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", int8Gram=True)
     seen = []
     for _ in range(5):
         tp(th.cuda(), 0.0, vs32, ep, **kw)
@@ -492,7 +493,7 @@ def test_low_precision_gram_variants_keep_the_dense_solve(headline_net):
         assert float(tp.solverResidual) < 1e-10
     assert seen[-1] == (4, None, "dense") and seen[-2][2] == "dense", seen
     vs64 = varstate(N)
-    t6 = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", int8Gram=True)
+    t6 = XTDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", int8Gram=True)
     for _ in range(5):
         t6(th.cuda(), 0.0, vs64, ep, **kw)
         t6.check()
@@ -518,7 +519,7 @@ def test_matrix_free_step_matches_the_assembled_one(headline_net):
     S, F = td.S0.clone(), td.F0.clone()
     D = 1e-4 * torch.diagonal(S) + 1e-6 * torch.diagonal(S).max()
     nF = float(torch.linalg.norm(F))
-    tm = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", matrixFree=True)
+    tm = XTDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", matrixFree=True)
     for call in range(3):
         u, _ = tm(th.cuda(), 0.0, vs, ep, **kw)
         tm.check()
@@ -538,7 +539,7 @@ def test_matrix_free_step_matches_the_assembled_one(headline_net):
         if call == 2:
             assert tm.choleskyInfo["own_passes_last_call"] <= 2, tm.choleskyInfo
     # ... without them every block step is a pass of its own (and the result the same)
-    tn = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", matrixFree=True, pivotHints=False)
+    tn = XTDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", matrixFree=True, pivotHints=False)
     for call in range(3):
         un, _ = tn(th.cuda(), 0.0, vs, ep, **kw)
         tn.check()
@@ -560,7 +561,7 @@ def test_matrix_free_spectral_solve_matches_the_assembled_one(headline_net):
     td.check()
     S, F, ev_d = td.S0.clone(), td.F0.clone(), td.ev.clone()
     nF, lmax, P = float(torch.linalg.norm(F)), float(ev_d[-1]), S.shape[0]
-    tm = V.TDVP(svdTol=1e-6, matrixFree=True)
+    tm = XTDVP(svdTol=1e-6, matrixFree=True)
     for call in range(2):
         u, _ = tm(th.cuda(), 0.0, vs, ep, **kw)
         tm.check()
@@ -572,7 +573,7 @@ def test_matrix_free_spectral_solve_matches_the_assembled_one(headline_net):
         assert float(torch.linalg.norm(S @ (u - u_d))) < 1e-9 * nF
         assert abs(float(tm.solverResidual) - float(td.solverResidual)) < 1e-9 and abs(float(tm.tdvp_error) - float(td.tdvp_error)) < 1e-9
     with pytest.raises(NotImplementedError, match="diagonalShift"):
-        V.TDVP(svdTol=1e-6, diagonalShift=1e-3, matrixFree=True)(th.cuda(), 0.0, vs, ep, **kw)
+        XTDVP(svdTol=1e-6, diagonalShift=1e-3, matrixFree=True)(th.cuda(), 0.0, vs, ep, **kw)
 
 
 @pytest.mark.parametrize("P,n,ldj", [(37, 1000, 1000), (300, 4097, 4160), (1031, 8192, 8192), (5, 3, 3)])
@@ -643,7 +644,7 @@ def test_lowrank_routes_on_small_models(hidden):
     ts = V.TDVP(svdTol=1e-6, spectralEngine="dense")
     us, _ = ts(th.cuda(), 0.0, vs, ep, **kw)
     ts.check()
-    tm = V.TDVP(svdTol=1e-6, matrixFree=True)
+    tm = XTDVP(svdTol=1e-6, matrixFree=True)
     for call in range(3):
         um, _ = tm(th.cuda(), 0.0, vs, ep, **kw)
         tm.check()

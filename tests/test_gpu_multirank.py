@@ -35,7 +35,11 @@ def _problem():
 
 
 def _two_calls(V, vs, eq, solver_kw):
-    tdvp = V.TDVP(**solver_kw)
+    if solver_kw.get("matrixFree"):
+        from vmc_pde_amd.experimental import TDVP as cls        # (the matrix-free experiment is a subclass of the product class)
+    else:
+        cls = V.TDVP
+    tdvp = cls(**solver_kw)
     th0 = vs.get_parameters()
     u0, _ = tdvp(th0, 0.0, vs, eq, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
     none = torch.zeros(1, 1, dtype=th0.dtype, device=th0.device)          # (the matrix-free variant has no S0)

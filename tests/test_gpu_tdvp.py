@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from oracle import vmc_oracle as O
+from vmc_pde_amd.experimental import TDVP as XTDVP      # the two opt-in experiments (matrixFree, int8Gram) live in a subclass
 from helpers import make_spec, random_theta, make_varstate, FixedSampler, rel_err
 
 pytestmark = pytest.mark.gpu
@@ -679,7 +680,7 @@ def test_int8_gram_option_reproduces_the_fp64_step():
     res = {}
     for flag in (False, True):
         vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()))
-        tp = V.TDVP(diagonalShift=1e-4, svdTol=1e-8, solver="cholesky", int8Gram=flag)
+        tp = XTDVP(diagonalShift=1e-4, svdTol=1e-8, solver="cholesky", int8Gram=flag)
         kw = dict(nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
         tp(th.cuda(), 0.1, vs, ep, **kw)                      # first call: exact centring, sets up the lagged means
         upd, _ = tp(th.cuda(), 0.1, vs, ep, **kw)             # second call: uncentred Gram with the appended rows
@@ -725,7 +726,7 @@ def test_int8_gram_falls_back_on_heavy_tailed_rows():
     largest row max / row rms of each int8 call and falls back to the fp64 kernel (with one warning) from the next call on."""
     import vmc_pde_amd as V
     from vmc_pde_amd import mpi_wrapper as mpi
-    tp = V.TDVP(int8Gram=True, svdTol=1e-10)                # limit sqrt(0.1 * 1e-10 / 4e-15) = 50: Gaussian rows (~8) pass, a one-outlier row (~sqrt(N)) does not
+    tp = XTDVP(int8Gram=True, svdTol=1e-10)                # limit sqrt(0.1 * 1e-10 / 4e-15) = 50: Gaussian rows (~8) pass, a one-outlier row (~sqrt(N)) does not
     N, P = 40000, 40
     mpi.globNumSamples = N                              # (what TDVP.__call__ sets, tdvp.py:99; get_tdvp_equation divides by it)
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -755,7 +756,7 @@ def test_int8_gram_on_an_fp32_jacobian_config5():
     res = {}
     for flag in (False, True):
         vs = make_varstate(spec, th, sampler=FixedSampler(z.cuda()), jacobian_dtype=torch.float32)
-        tp = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", int8Gram=flag)
+        tp = XTDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", int8Gram=flag)
         kw = dict(nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
         tp(th.cuda(), 0.1, vs, ep, **kw)
         upd, _ = tp(th.cuda(), 0.1, vs, ep, **kw)

@@ -5,7 +5,7 @@ import torch, bench
 import vmc_pde_amd as V
 dev = torch.device("cuda", 0)
 wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
-vs, eq, tdvp, theta = bench.build_problem(dev, wl)
+vs, eq, tdvp, theta = bench.build_problem(dev, wl, experimental=True)
 tdvp.int8Gram = True
 N = bench.WORKLOADS[wl]["n_samp"]
 kw = dict(evolutionEq=eq, psi=vs, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)

@@ -6,7 +6,7 @@ import torch, bench
 for wl in sys.argv[1:] or ["C2", "C4"]:
     out = {}
     for flag in (False, True):
-        vs, eq, tdvp, theta = bench.build_problem(torch.device("cuda", 0), wl)
+        vs, eq, tdvp, theta = bench.build_problem(torch.device("cuda", 0), wl, experimental=True)
         tdvp.int8Gram = flag
         N = bench.WORKLOADS[wl]["n_samp"]
         kw = dict(evolutionEq=eq, psi=vs, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)

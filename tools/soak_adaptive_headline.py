@@ -15,7 +15,8 @@ def run(engine, matrix_free=False):
     sampler = V.Sampler(key=7, dim=dim, name="Gauss", mcmc_info={"offset": offset, "bound": 0.25})
     vs = V.VarState(sampler, dim, 1, 4, network_args={"intmediate": HID, "offset": offset, "latentSpaceName": "Gauss", "dim": dim})
     eq = V.EvolutionEquation(dim=dim, name="advection_hamiltonian_wDiss")
-    tdvp = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine=engine, matrixFree=matrix_free)
+    from vmc_pde_amd.experimental import TDVP as XTDVP
+    tdvp = XTDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine=engine, matrixFree=matrix_free)
     stepper = V.AdaptiveHeun(timeStep=1e-4, tol=TOL, maxStep=1e-2)
     t, dts, modes, thetas = 0.0, [], {}, []
     calls = [0]

@@ -1,0 +1,385 @@
+"""The pivoted low-rank factor of S and the two solve routes built on it (reference: vmc_fluids/tdvp.py:57-94).
+
+S = <J^T J> of these models is numerically rank deficient (238 of 4213 eigenvalues above 1e-16 lambda_max at the headline size), so
+both of the reference's systems can be solved from S = L L^T + R with a P x r factor (csrc/eig.hip: blocked pivoted Cholesky):
+  * `_solve_lowrank` / `_solve_lowrank_static`: solver="cholesky" -- (S + D) u = F through the Woodbury identity and iterative
+    refinement against the full matrix;
+  * `_eigh_lowrank`: solver="eigh" -- (ev, V) of tdvp.py:57-64 from a Householder basis of range(L) and a Rayleigh-Ritz step.
+`LowRankRoutes` is mixed into `tdvp.TDVP`, which decides when a route applies and falls back to the dense factorisations.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from . import global_defs
+
+
+def _long_k_product(A, B):
+    """A @ B^T for row-major A (m x K) and B (n x K) with a long contraction and a small result: as ONE library GEMM such a shape runs on
+    a handful of workgroups (256 x 256 x 4213: 0.23 ms), as a batched GEMM over chunks of the contraction with the chunk sums added
+    up it fills the chip (0.03 ms).  Rows may be strided (views into padded buffers)."""
+    K = A.shape[1]
+    if K < 1024:
+        return A @ B.T
+    if K % 64:                                         # (a zero pad of the contraction: two small copies)
+        pad = 64 - K % 64
+        A, B = torch.nn.functional.pad(A, (0, pad)), torch.nn.functional.pad(B, (0, pad))
+        K += pad
+    ck = 128 if K % 128 == 0 else 64
+    A3 = A.view(A.shape[0], K // ck, ck).permute(1, 0, 2)
+    B3 = B.view(B.shape[0], K // ck, ck).permute(1, 2, 0)
+    return torch.bmm(A3, B3).sum(0)
+
+
+
+LOWRANK_MIN_P = 1024        # spectralEngine="auto": the rank-revealing decomposition from this many parameters on (below, syevd takes < 25 ms)
+LOWRANK_RANK_CAP = 768      # ... while the numerical rank stays below this and below P / LOWRANK_RANK_DIVISOR: its chains are r dependent
+LOWRANK_RANK_DIVISOR = 6    #   launches of O(P r) work each, and the r x r core goes to syevd
+LOWRANK_TOL = 1e-14         # pivoting stops when the largest remaining diagonal entry is <= this x max diag(S).  The downdated diagonal of a row
+                            #   carries round-off of ~5 eps S_ii, and a pivot p turns noise n into a column of size n / sqrt(p): pivots must
+                            #   stay an order of magnitude above 1e-15 max diag (with 1e-16 the last columns added 4e-13 max diag to L L^T on
+                            #   a 700 x 700 test matrix; LAPACK's dpstrf stops at P eps max diag = 9e-13 here).  max diag <= lambda_max, so
+                            #   everything dropped lies below the reference's hard cut-off at 1e-14 lambda_max (tdvp.py:82)
+LOWRANK_TRACE_BOUND = 1e-11 # accept only if the trace of the remainder (an upper bound of its norm; <= (P - r) LOWRANK_TOL by construction: 1.1e-12
+                            #   at P = 16 181) is below this x max diag(S)
+LOWRANK_SVDTOL_FRACTION = 0.1  # spectral route: ... and below this x svdTol x (a lower bound of lambda_max).  What the factorisation drops is
+                            #   reported as exact zeros; the reference keeps every mode above its hard cut at 1e-14 lambda_max and weights it by
+                            #   1 / (1 + (svdTol lambda_max / lambda)^6) (tdvp.py:82-85): a dropped mode below 0.1 svdTol lambda_max had a weight
+                            #   below 1e-6, a smaller svdTol sends the call to the dense decomposition
+LOWRANK_CHOL_MIN_P = 4096   # choleskyEngine="auto": the low-rank solve from this many parameters on.  P = 4213: 1.3 ms against 2.1 ms for the blocked
+                            #   factorisation of the full matrix (which scales as P^3: 0.8 ms at 3072) -- in the static mode, i.e. without a host
+                            #   read in the step; with one (planning mode) 2.5 ms.  P = 16 181: 7 against 38 ms
+LOWRANK_SOLVE_RHO = 1e-4    # low-rank Cholesky solve: largest trace(R) / min D accepted (the contraction factor of its iterative refinement)
+LOWRANK_RETRY_AFTER = 50    # "auto": calls on the dense path after one whose rank exceeded the cap, before the next attempt
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class StaticPlanOutdated(FloatingPointError):
+    """The numerical rank of S outgrew the static plan of the low-rank solve within one call, so that call's update failed the residual
+    guard.  The plan has been dropped: repeating the step (the steppers do, once: `retry_step`) runs a planning call."""
+    retry_step = True
+
+
+
+class LowRankRoutes:
+    """Mix-in of `tdvp.TDVP`: state `_chol_static` (the static plan of the Cholesky route), `_lowrank_last_rank`, `_buf_lr` (factor,
+    pivot list and workspace per (P, device)); reads `svdTol`, `diagonalShift`, `pivotHints`, `choleskyEngine`, `spectralEngine`,
+    `_floor`, `_uncentred_ok`, `_ratio_prev`; writes `choleskyInfo` / `spectralInfo`."""
+
+    # ---- the pivoted Cholesky factor of S shared by the rank-revealing spectral decomposition and the low-rank Cholesky solve ----
+    def _lowrank_buffers(self, P, device, cap):
+        key = ("lowrank", P, str(device))
+        w = self._buf_lr.get(key) if hasattr(self, "_buf_lr") else None
+        if w is None or w["LT"].shape[0] < cap:
+            ldl = _round_up(P, 64)
+            w = dict(ldl=ldl,
+                     LT=torch.empty((cap, ldl), dtype=global_defs.tReal, device=device),
+                     YT=None, tau=None, hq=None,
+                     piv=torch.zeros(cap, dtype=torch.int32, device=device),
+                     state=torch.zeros(2, dtype=torch.int32, device=device),
+                     ws=torch.zeros(nat.lib().vmcpde_pivoted_cholesky_blocked_workspace_bytes(P) // 8, dtype=global_defs.tReal, device=device),
+                     state_host=torch.zeros(2, dtype=torch.int32).pin_memory(),
+                     info_host=torch.zeros(3, dtype=global_defs.tReal).pin_memory(),
+                     head_host=torch.zeros(4, dtype=global_defs.tReal).pin_memory())
+            self._buf_lr = {key: w}
+            saved = getattr(self, "_lr_restore", None)           # a resumed run: the pivot list and step count of the interrupted one
+            if saved is not None and saved["P"] == P and saved["piv"].numel() <= cap:
+                w["piv"][:saved["piv"].numel()] = saved["piv"].to(device)
+                w["state"].copy_(saved["state"].to(device))
+                w["head_host"].copy_(saved["head"])
+            self._lr_restore = None
+        return w
+
+    def _lowrank_tol(self):
+        """Pivoting tolerance of the low-rank routes for THIS call's S, or None when they do not apply: the factorisation must stop
+        above the noise of S.  An fp64-accumulated Gram (fp64 or fp32 Jacobian storage) is exact to round-off: LOWRANK_TOL.  fp32 block
+        sums (2e-8) bury everything below ~1e-8 max diag in noise -- such an S has no usable numerical rank, so that variant keeps the
+        dense paths.  A function of values fixed before the call's first launch (`_ratio_prev` is the PREVIOUS call's mean^2 / var
+        figure, read after its event at the top of get_tdvp_equation): every launch of a factorisation, and every rank, sees the same."""
+        if self.f32BlockGram:
+            return None
+        tol = LOWRANK_TOL
+        r = getattr(self, "_ratio_prev", None)
+        if self._uncentred_ok and r is not None and r == r:
+            # the uncentred Gram subtracts N m m^T afterwards: relative noise ~ eps * max_p mean_p^2 / var_p (the figure the engine
+            # watches to stay below 1e3; 1.3e-4 for the headline network)
+            tol = max(tol, 2e-15 * r)
+        return tol
+
+    def _arm_hints(self, w, P):
+        """Before a factorisation starts in `w`: its previous pivots (still in w["piv"] / w["state"], zero on first use) become the
+        hint list, or the list is disarmed."""
+        on = bool(self.pivotHints) and os.environ.get("VMCPDE_PIVOT_HINTS", "1") != "0"
+        nat.call("vmcpde_lowrank_hint", nat.ptr(w["piv"]) if on else None, nat.ptr(w["state"]) if on else None, P, nat.ptr(w["ws"]),
+                 w["ws"].numel() * 8, nat.stream())
+
+    @staticmethod
+    def _steps_used(ws_head_host):
+        """Block steps that added columns (PivWork::steps, csrc/eig.hip) from a host copy of the first four doubles of the workspace."""
+        return int(ws_head_host.view(torch.int32)[7])
+
+    def _pivoted_factor(self, S, w, cap, extra=None):
+        """S = L L^T + R by blocked diagonal pivoting (up to 32 columns per pair of launches) into w["LT"]; returns (rank, converged,
+        max diag, trace of R, extra's values).  The first call covers the previous call's rank (the spectrum moves slowly along a
+        trajectory); the host reads `state` after every call (`extra`: a function returning up to two device scalars, evaluated behind
+        the first launch chain and copied along with that read)."""
+        P, device = S.shape[0], S.device
+        done, first = False, True
+        tol = self._lowrank_tol() or LOWRANK_TOL                   # one value for every launch of this factorisation
+        self._arm_hints(w, P)
+        # (first launch chain: what the previous factorisation in these buffers used plus a third; an unhinted step accepts ~13 columns)
+        used = self._steps_used(w["head_host"])
+        nblocks = used + max(3, used // 3) if used else ((self._lowrank_last_rank + 12) // 13 + 2 if self._lowrank_last_rank else 12)
+        if w["info_host"].numel() < 4:
+            w["info_host"] = torch.zeros(4, dtype=global_defs.tReal).pin_memory()
+        n_extra = 0
+        for _ in range(cap // 3 + 8):           # (every step makes progress -- a column, or candidates lowered to what is left of them)
+            nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S), S.stride(0), P, tol, 1 if first else 0, nblocks, cap, nat.ptr(w["LT"]),
+                     w["ldl"], nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), w["ws"].numel() * 8, nat.stream())
+            w["state_host"].copy_(w["state"], non_blocking=True)
+            w["info_host"][:2].copy_(w["ws"][:2], non_blocking=True)
+            w["head_host"].copy_(w["ws"][:4], non_blocking=True)
+            if extra is not None and first:
+                ex = extra().reshape(-1)
+                n_extra = ex.numel()
+                w["info_host"][2:2 + n_extra].copy_(ex, non_blocking=True)
+            torch.cuda.current_stream(device).synchronize()
+            first, nblocks = False, 3
+            if int(w["state_host"][1]):
+                done = True
+                break
+            if int(w["state_host"][0]) >= cap:
+                break
+        r = int(w["state_host"][0])
+        done = done or r == P                                       # full rank: every row was a pivot, nothing is left
+        return (r, done, float(w["info_host"][0]), float(w["info_host"][1]), *[float(w["info_host"][2 + i]) for i in range(n_extra)])
+
+    # ---- solver="cholesky" through the low-rank factor ----------------------------------------------------------------
+    def _solve_lowrank(self, b, F, P, update):
+        """(S0 + D) u = F with D = diagonalShift diag(S0) + floor I > 0 and S0 = L L^T + R:  M = D + L L^T is inverted by the Woodbury
+        identity, M^-1 v = D^-1 v - D^-1 L G^-1 L^T D^-1 v with G = I + L^T D^-1 L (r x r, Cholesky), and u <- u + M^-1 (F - (S0 + D) u)
+        with the TRUE S0 removes what R (|M^-1 R| <= trace(R) / min D) and the identity's cancellation left.  False: not applicable
+        (rank above the cap, D not positive, R too large) -- the caller factors the full matrix.
+
+        Two modes.  PLANNING (first call, and whenever the plan no longer fits): the host reads the rank after the factorisation and
+        sizes everything by it.  STATIC (the calls after): the rank is padded to the plan's rmax with zero columns of L -- G gets an
+        identity block there --, the factorisation runs a fixed number of block steps (those after the criterion return at once), and
+        the host reads nothing: `state` is copied asynchronously and looked at by the NEXT call, which re-plans if the factorisation
+        did not finish or the rank came close to rmax.  A call whose factorisation stopped short still refines against the full
+        matrix, and its solver residual is measured and guarded like every other (`residualBound`)."""
+        device = F.device
+        S0 = b["S"][:P, :P]
+        cap = P if self.choleskyEngine == "lowrank" else max(1, min(LOWRANK_RANK_CAP, P // LOWRANK_RANK_DIVISOR))
+        w = self._lowrank_buffers(P, device, cap)
+        D = b["diagS"] * float(self.diagonalShift)
+        if self._floor is not None:
+            D = D + self._floor
+        st = self._chol_static
+        if st is not None and st["P"] == P and st["rmax"] <= w["LT"].shape[0]:
+            if st["event"] is not None:                 # the previous static call's factorisation: finished, with room to spare?
+                st["event"].synchronize()
+                prev_rank, prev_done = int(st["host"][0]), int(st["host"][1])
+                if not prev_done or prev_rank > st["rmax"] - 32:     # (re-plan well before the rank reaches the pad)
+                    st = self._chol_static = None
+                else:                                                # what the last factorisation used, and a third (at least 3) to spare
+                    used = self._steps_used(st["head"])
+                    st["nsteps"] = used + max(3, used // 3)
+            if st is not None:
+                self._solve_lowrank_static(b, F, P, update, w, D, st)
+                return True
+        r, done, d0, left, dmin = self._pivoted_factor(S0, w, cap, extra=lambda: D.min())
+        rho = left / dmin if dmin > 0 else float("inf")
+        self.choleskyInfo = dict(engine="lowrank", mode="planning", rank=r, cap=cap, max_diag=d0, trace_left=left, min_shift=dmin, converged=done)
+        if not done or r < 1 or not (rho <= LOWRANK_SOLVE_RHO):
+            return False
+        self._lowrank_last_rank = r
+        LTr = w["LT"][:r, :P]
+        Ls = LTr / D                                                # L^T D^-1  (r x P)
+        G = Ls @ LTr.T
+        G.diagonal().add_(1.0)
+        Gc = torch.linalg.cholesky(G)
+
+        def minv(v):
+            t = torch.cholesky_solve((Ls @ v)[:, None], Gc)[:, 0]
+            return v / D - Ls.T @ t
+
+        u = minv(F)
+        Su = torch.empty(P, dtype=global_defs.tReal, device=device)
+        nref = 1 if rho <= 1e-6 else 2             # (error after j refinements ~ rho^(j+1); the residual is measured either way)
+        for _ in range(nref):
+            nat.call("vmcpde_gemv", nat.ptr(b["S"]), b["Ppad"], P, P, 0, nat.ptr(u), nat.ptr(Su), nat.stream())
+            u = u + minv(F - Su - D * u)
+        update.copy_(u)
+        b["info"].zero_()
+        rmax = _round_up(r + 40, 128)
+        if rmax <= w["LT"].shape[0] and rmax <= cap + 127:
+            used = self._steps_used(w["head_host"])
+            self._chol_static = dict(P=P, rmax=rmax, nsteps=used + max(3, used // 3), nref=nref, rank=r, event=None,
+                                     host=torch.zeros(2, dtype=torch.int32).pin_memory(),
+                                     head=torch.zeros(4, dtype=global_defs.tReal).pin_memory())
+        return True
+
+    def _solve_lowrank_static(self, b, F, P, update, w, D, st):
+        device, rmax = F.device, st["rmax"]
+        S0 = b["S"][:P, :P]
+        if w.get("G") is None or w["G"].shape[0] != rmax:
+            need = nat.lib().vmcpde_chol_workspace_bytes(rmax)
+            w["G"] = torch.zeros((rmax, rmax), dtype=global_defs.tReal, device=device)
+            w["G_ws"] = torch.empty(need // 8, dtype=global_defs.tReal, device=device)
+            w["G_info"] = torch.zeros(1, dtype=torch.int32, device=device)
+            w["t2"] = torch.empty(rmax, dtype=global_defs.tReal, device=device)
+            w["Su"] = torch.empty(P, dtype=global_defs.tReal, device=device)
+        G, gws, t2, Su = w["G"], w["G_ws"], w["t2"], w["Su"]
+        need = gws.numel() * 8
+        w["LT"][:rmax].zero_()                                      # columns past the rank: zero, i.e. an identity block in G
+        self._arm_hints(w, P)                                       # (rmax is the padded size of G; a small P caps the rank below it)
+        nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S0), S0.stride(0), P, self._lowrank_tol() or LOWRANK_TOL, 1, st["nsteps"], min(rmax, P), nat.ptr(w["LT"]), w["ldl"],
+                 nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), w["ws"].numel() * 8, nat.stream())
+        st["host"].copy_(w["state"], non_blocking=True)             # for the next call
+        st["head"].copy_(w["ws"][:4], non_blocking=True)
+        if st["event"] is None:
+            st["event"] = torch.cuda.Event()
+        st["event"].record()
+        LTr = w["LT"][:rmax, :P]
+        # G = I + L^T D^-1 L, contraction length P, result only rmax x rmax: as ONE library GEMM the 256 x 256 x 4213 shape runs on 8
+        # workgroups (0.23 ms; the engine's own weighted syrk path 0.17 ms) -- as a batched GEMM over column chunks of 128 (the zero pad
+        # of the rows of LT included) it fills the chip, and the chunk sums are added up
+        ldl = w["ldl"]
+        ck = 128 if ldl % 128 == 0 else 64
+        if w.get("Dpad") is None:
+            w["Dpad"] = torch.ones(ldl, dtype=global_defs.tReal, device=device)
+        w["Dpad"][:P] = D
+        Lfull = w["LT"][:rmax]                                      # rmax x ldl, pad columns zero
+        A3 = (Lfull / w["Dpad"]).view(rmax, ldl // ck, ck).permute(1, 0, 2)
+        B3 = Lfull.view(rmax, ldl // ck, ck).permute(1, 2, 0)
+        torch.sum(torch.bmm(A3, B3), dim=0, out=G)
+        G.diagonal().add_(1.0)
+        nat.call("vmcpde_cholesky", nat.ptr(G), rmax, rmax, nat.ptr(w["G_info"]), nat.ptr(gws), need, nat.stream())
+
+        def minv(v):
+            y = v / D
+            t1 = LTr @ y
+            nat.call("vmcpde_chol_solve", nat.ptr(G), rmax, rmax, nat.ptr(t1), nat.ptr(t2), nat.ptr(gws), need, nat.stream())
+            return torch.addcdiv(y, LTr.T @ t2, D, value=-1.0)
+
+        u = minv(F)
+        for _ in range(st["nref"]):
+            nat.call("vmcpde_gemv", nat.ptr(b["S"]), b["Ppad"], P, P, 0, nat.ptr(u), nat.ptr(Su), nat.stream())
+            u = u + minv(F - Su - D * u)
+        update.copy_(u)
+        b["info"].zero_()
+        self.choleskyInfo = dict(engine="lowrank", mode="static", rmax=rmax, block_steps=st["nsteps"], refinements=st["nref"],
+                                 planned_rank=st["rank"])
+
+    # ---- tdvp.py:57-64 for a numerically rank-deficient S -----------------------------------------------------------
+    def _eigh_lowrank(self, S):
+        """(ev ascending, V) of the symmetric positive semi-definite S from a pivoted Cholesky factor (csrc/eig.hip), or None when the
+        numerical rank exceeds the cap (the caller then takes the dense path).  S = L L^T + R with trace(R) <= (P - r) LOWRANK_TOL max diag;
+        L = Q1 R1 by Householder reflectors, Q = [Q1 | Q2] = I - Y T Y^T; Q1^T S Q1 = W diag(w) W^T; ev = sort([w, 0 ... 0]),
+        V = [Q1 W | Q2] in the same order.  What is not in csrc/eig.hip is library GEMM / TRSM and the r x r decomposition."""
+        P, device = S.shape[0], S.device
+        # (forced engine: no cap -- the factorisation runs until its criterion is met)
+        cap = P if self.spectralEngine == "lowrank" else max(1, min(LOWRANK_RANK_CAP, P // LOWRANK_RANK_DIVISOR))
+        w = self._lowrank_buffers(P, device, cap)
+        # (a NaN on the diagonal compares as "smaller" in the pivot search and would simply be left out: the trace rides along with the
+        # first host read, and a non-finite S goes to the dense path, which reports it as before)
+        # lambda_max from below, for the svdTol gate: the trace over the rank, and |L e_1|^2 = |S[:, p_1]|^2 / S[p_1, p_1] (the first column of
+        # the factor is complete after the first block step) -- both <= lambda_max(L L^T) <= lambda_max(S)
+        r, done, d0, left, tr, col1 = self._pivoted_factor(S, w, cap, extra=lambda: torch.stack([torch.diagonal(S).sum(), (w["LT"][0, :P] ** 2).sum()]))
+        lam_lb = max(d0, tr / max(r, 1), col1) if np.isfinite(tr) and np.isfinite(col1) else d0
+        self.spectralInfo = dict(engine="lowrank", rank=r, cap=cap, max_diag=d0, trace_left=left, converged=done, lambda_max_lower_bound=lam_lb)
+        if not done or r < 1 or not (left <= LOWRANK_TRACE_BOUND * d0) or not np.isfinite(tr):
+            return None
+        if not (left <= LOWRANK_SVDTOL_FRACTION * float(self.svdTol) * lam_lb):
+            # the reference would still give the dropped modes a visible weight with this svdTol (tdvp.py:82-85): dense decomposition
+            self.spectralInfo["rejected"] = "trace_left above %g x svdTol x lambda_max" % LOWRANK_SVDTOL_FRACTION
+            return None
+        self._lowrank_last_rank = r
+        Y, Xn, Q1 = self._lowrank_range_basis(w, P, r, device)
+        SQ = S @ Q1
+        T = _long_k_product(Q1.T.contiguous(), SQ.T.contiguous())
+        T = 0.5 * (T + T.T)
+        # (the r x r core on one host LAPACK thread takes 1.6 ms against 5.4 ms for syevd's launch chain at r = 238, but the host
+        # synchronisation it needs costs the calling loop more than that: 33.0 against 30.2 ms per TDVP call -- measured and dropped)
+        wv, W = torch.linalg.eigh(T)                               # r x r (rocSOLVER)
+        U = Q1 @ W
+        return self._lowrank_assemble(Y, Xn, U, wv, r, P, device)
+
+    @staticmethod
+    def _lowrank_assemble(Y, Xn, U, wv, r, P, device):
+        """(ev, V) from the Ritz pairs (wv ascending, U = Q1 W) and the compact WY form of Q = [Q1 | Q2] = I + Y^T Xn."""
+        # ascending order: the (few, round-off) negative Ritz values, the P - r zeros of the complement, the positive Ritz values.  The
+        # complement Q2 = E_2 - Y T Y_2^T is written by its GEMM straight into its column block of V: one pass over P x P instead of
+        # four (GEMM, sign, diagonal, column gather: 7 + 2 of the 29 ms of the engine at P = 16 181)
+        nneg = int((wv < 0).sum())
+        V = torch.empty((P, P), dtype=global_defs.tReal, device=device)
+        V[:, :nneg] = U[:, :nneg]
+        V[:, nneg + P - r:] = U[:, nneg:]
+        if P > r:
+            Vn = V[:, nneg:nneg + P - r]
+            torch.mm(Y.T, Xn[:, r:], out=Vn)
+            Vn[r:].diagonal().add_(1.0)
+        ev = torch.cat([wv[:nneg], torch.zeros(P - r, dtype=global_defs.tReal, device=device), wv[nneg:]])
+        return ev, V
+
+    def _lowrank_range_basis(self, w, P, r, device):
+        """Householder QR of the factor in w["LT"][:r] (destroyed): reflectors Y (r x P), Xn = -T Y^T of the compact WY form
+        Q = I + Y^T Xn, and Q1 = Q[:, :r], an orthonormal basis of range(L)."""
+        if w["YT"] is None or w["YT"].shape[0] < r:
+            w["YT"] = torch.empty((w["LT"].shape[0], w["ldl"]), dtype=global_defs.tReal, device=device)
+            w["tau"] = torch.empty(w["LT"].shape[0], dtype=global_defs.tReal, device=device)
+            w["hq"] = torch.empty(5 * w["LT"].shape[0] + 5, dtype=global_defs.tReal, device=device)
+        nat.call("vmcpde_householder_rows", nat.ptr(w["LT"]), w["ldl"], P, r, nat.ptr(w["YT"]), nat.ptr(w["tau"]), nat.ptr(w["hq"]), nat.stream())
+        Y = w["YT"][:r, :P]                                        # r x P: row k = reflector k
+        Yp = w["YT"][:r]                                           # (r x ldl: the pad columns are zero)
+        Tinv = torch.triu(_long_k_product(Yp, Yp), 1)
+        Tinv.diagonal().copy_(1.0 / w["tau"][:r])                  # T^-1 = strict upper part of Y^T Y + diag(1 / tau)
+        # T itself (r x r, what dlarft forms), then T Y^T as a GEMM: a triangular solve with P right-hand sides makes rocBLAS allocate
+        # a workspace that fails for r in the thousands
+        Tm = torch.linalg.solve_triangular(Tinv, torch.eye(r, dtype=global_defs.tReal, device=device), upper=True)
+        Xn = -(Tm @ Y)                                             # -T Y^T  (r x P);  Q = I - Y T Y^T, columns [Q1 | Q2]
+        Q1 = Y.T @ Xn[:, :r]
+        Q1[:r].diagonal().add_(1.0)                                # Q1 = E_1 - Y T Y_1^T  (P x r, orthonormal basis of range(L))
+        return Y, Xn, Q1
+
+
+    # ---- what the routes inherit from the previous call (for TDVP.state_dict) -----------------------------------------
+    def _lowrank_state_dict(self):
+        """The static plan of the Cholesky route (rmax, block steps, refinements, the previous call's rank / done / step count) and the
+        pivot list with its length -- the candidates of the next factorisation (`vmcpde_lowrank_hint`).  With them the first call of a
+        resumed run IS the next static call of the interrupted one, bit for bit."""
+        out = {"last_rank": int(self._lowrank_last_rank), "chol_backoff": int(self._chol_backoff), "lowrank_backoff": int(self._lowrank_backoff)}
+        w = next(iter(self._buf_lr.values())) if getattr(self, "_buf_lr", None) else None
+        if w is not None:
+            torch.cuda.current_stream(w["piv"].device).synchronize()         # (the asynchronous host copies of the last call have landed)
+            out["factor"] = {"P": int(next(iter(self._buf_lr))[1]), "piv": w["piv"].detach().cpu().clone(), "state": w["state"].detach().cpu().clone(),
+                             "head": w["head_host"].clone()}
+        st = self._chol_static
+        if st is not None:
+            if st["event"] is not None:
+                st["event"].synchronize()
+            out["chol_static"] = {k: st[k] for k in ("P", "rmax", "nsteps", "nref", "rank")}
+            out["chol_static"].update(host=st["host"].clone(), head=st["head"].clone(), called=st["event"] is not None)
+        return out
+
+    def _lowrank_load_state(self, st):
+        self._lowrank_last_rank = int(st.get("last_rank", 0))
+        self._chol_backoff, self._lowrank_backoff = int(st.get("chol_backoff", 0)), int(st.get("lowrank_backoff", 0))
+        self._buf_lr = {}
+        self._lr_restore = st.get("factor")
+        plan = st.get("chol_static")
+        self._chol_static = None
+        if plan is not None:
+            ev = None
+            if plan["called"]:                      # (the record of the interrupted run's last static call is already on the host)
+                ev = torch.cuda.Event()
+                ev.record()
+            self._chol_static = dict(P=plan["P"], rmax=plan["rmax"], nsteps=plan["nsteps"], nref=plan["nref"], rank=plan["rank"], event=ev,
+                                     host=plan["host"].clone().pin_memory(), head=plan["head"].clone().pin_memory())

@@ -111,6 +111,18 @@ def allreduce_sum_(buf: torch.Tensor) -> torch.Tensor:
     return buf
 
 
+def allreduce_max_(buf: torch.Tensor) -> torch.Tensor:
+    """In-place maximum over ranks of a small device buffer (a figure every rank must decide on alike)."""
+    if _on() and dist.get_world_size() > 1:
+        if buf.is_cuda and dist.get_backend() == "gloo":
+            tmp = buf.cpu()
+            dist.all_reduce(tmp, op=dist.ReduceOp.MAX)
+            buf.copy_(tmp)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.MAX)
+    return buf
+
+
 def global_sum(data):
     """mpi_wrapper.py:129-163: sum over the device and batch axes and over ranks."""
     res = data.sum(dim=(0, 1))
