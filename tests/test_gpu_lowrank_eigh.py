@@ -624,7 +624,7 @@ def test_lowrank_routes_on_small_models(hidden):
     D = 1e-4 * torch.diagonal(S) + 1e-6 * torch.diagonal(S).max()
     nF = float(torch.linalg.norm(F))
     for flags in (dict(choleskyEngine="lowrank"), dict(matrixFree=True)):
-        tp = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", **flags)
+        tp = XTDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", **flags)     # (the product class with both experiments off for the first)
         modes = []
         for call in range(4):
             u, _ = tp(th.cuda(), 0.0, vs, ep, **kw)
