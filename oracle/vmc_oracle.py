@@ -62,6 +62,11 @@ class NetSpec:
     different_add: bool = False
     no_add: bool = True
     global_change: bool = False   # net.py:72: per-block affine map y -> global_scale * y + global_offset
+    dense_dtype: str = "float64"  # flax 0.3.6 `nn.Dense` as called at net.py:53-61 has its own `dtype` (default float32) and casts
+                                  # inputs, kernel and bias to it even under jax_enable_x64 (main.py:2).  "float32" restates that reading:
+                                  # every conditioner MLP end to end in fp32, its output promoted when it meets the fp64 coordinates
+                                  # (net.py:94-109).  "float64" (default) is the reading the product implements; which one the published
+                                  # records support is tested in tests/test_oracle_published_run.py and recorded in DESIGN.md section 2.
 
     @property
     def depth(self) -> int:
@@ -180,12 +185,15 @@ def student_t_logpdf(x, S, mu, dist_params):
             - (nu + p) / 2 * torch.log(1 + x @ torch.linalg.inv(S) @ x / nu))
 
 
-def single_trafo(p: Dict[str, torch.Tensor], prefix: str, n_hidden: int, x: torch.Tensor, alpha: float = 10.0):
-    """net.py:53-61: tanh MLP, output alpha*tanh(Dense)."""
+def single_trafo(p: Dict[str, torch.Tensor], prefix: str, n_hidden: int, x: torch.Tensor, alpha: float = 10.0, dense_dtype: str = "float64"):
+    """net.py:53-61: tanh MLP, output alpha*tanh(Dense).  dense_dtype="float32": every nn.Dense casts inputs, kernel and bias to fp32
+    (NetSpec.dense_dtype); the casts are differentiable, so the autodiff derivatives are those of the fp32 computation."""
+    cast = (lambda v: v.to(torch.float32)) if dense_dtype == "float32" else (lambda v: v)
+    out_dtype = x.dtype
     for k in range(n_hidden):
-        x = torch.tanh(x @ p[f"{prefix}/Dense_{k}/kernel"] + p[f"{prefix}/Dense_{k}/bias"])
+        x = torch.tanh(cast(x) @ cast(p[f"{prefix}/Dense_{k}/kernel"]) + cast(p[f"{prefix}/Dense_{k}/bias"]))
     k = n_hidden
-    return alpha * torch.tanh(x @ p[f"{prefix}/Dense_{k}/kernel"] + p[f"{prefix}/Dense_{k}/bias"])
+    return (alpha * torch.tanh(cast(x) @ cast(p[f"{prefix}/Dense_{k}/kernel"]) + cast(p[f"{prefix}/Dense_{k}/bias"]))).to(out_dtype)
 
 
 def single_block(spec: NetSpec, p, b: int, x: torch.Tensor, inv: bool):
@@ -196,10 +204,10 @@ def single_block(spec: NetSpec, p, b: int, x: torch.Tensor, inv: bool):
     up, dn = spec.inds_up[b], spec.inds_down[b]
     nh = len(spec.intmediate)
     pre = f"myINN/blocks_{b}"
-    s1 = lambda v: single_trafo(p, f"{pre}/s1", nh, v)
-    s2 = lambda v: single_trafo(p, f"{pre}/s2", nh, v)
-    t1 = lambda v: single_trafo(p, f"{pre}/t1", nh, v)
-    t2 = lambda v: single_trafo(p, f"{pre}/t2", nh, v)
+    s1 = lambda v: single_trafo(p, f"{pre}/s1", nh, v, dense_dtype=spec.dense_dtype)
+    s2 = lambda v: single_trafo(p, f"{pre}/s2", nh, v, dense_dtype=spec.dense_dtype)
+    t1 = lambda v: single_trafo(p, f"{pre}/t1", nh, v, dense_dtype=spec.dense_dtype)
+    t2 = lambda v: single_trafo(p, f"{pre}/t2", nh, v, dense_dtype=spec.dense_dtype)
     if not inv:
         u1, u2 = x[up], x[dn]
         s2_u2 = s2(u2)

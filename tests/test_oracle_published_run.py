@@ -81,6 +81,40 @@ def test_oracle_reproduces_published_initial_spectrum(seed):
     assert 0.2 < np.median(snr_top) / np.median(snr_pub) < 5.0
 
 
+def test_dense_dtype_reading_cannot_be_told_from_the_published_record():
+    """flax 0.3.6 `nn.Dense` as called at net.py:53-61 may compute in its own dtype (float32) even under x64.  The oracle
+    restates both readings (`NetSpec.dense_dtype`).  Both reproduce the published step-0 record -- numerical rank 144, the count above
+    1e-11 lambda_max, the plateau of ~144 eigenvalues at 1e-12 .. 1e-14 lambda_max (the hidden-layer block: output kernels start at
+    1e-5), the round-off floor, the solver residual -- and they differ from EACH OTHER by 1e-7 in J, 1.5e-8 in S, 7e-8 in the eigenvalues
+    of the rank and 1.6e-8 |F| in the update as S sees it: seven orders below the Monte-Carlo bands the record can be compared within
+    (partitions, weights and samples of the published run are not reproducible).  fp32 noise enters S = <O~^T O~> through exactly
+    positive semi-definite sums, i.e. in SECOND order on its null space (~4e-13 here, the size of a host eigh's own round-off), so the
+    record's floor (22 values of 2e-15 .. 9e-13, two of -6e-15 / -4e-14) does not decide either.  The product computes the
+    conditioners in fp64 (the reading under which jax_enable_x64 means what main.py:2 says); a reference that did run them in fp32
+    is reproduced to 1.5e-8 in S -- inside BASELINE config 5's stated tolerance (S 1e-6, update 1e-5)."""
+    import dataclasses
+    ref = np.load(os.path.join(GOLD, "published_diffusion_d8_gauss.npz"))
+    out = {}
+    for dd in ("float64", "float32"):
+        spec, th, frozen = published_model(1)
+        spec = dataclasses.replace(spec, dense_dtype=dd)
+        g = torch.Generator().manual_seed(1)
+        z = O.latent_from_normals(spec, th, torch.randn(N, DIM, generator=g, dtype=torch.float64))
+        to = O.TDVPOracle(frozen=frozen)
+        u, aux = to.rhs(th, 0.0, O.VarStateOracle(spec, th), O.EvolutionEquationOracle(DIM, "diffusion"), z)
+        assert aux["J"].dtype == torch.float64 and aux["logp"].dtype == torch.float64         # the MLP's output is promoted where it meets x
+        check_against_published_step0(spectrum_with_A_columns(to.ev.numpy(), len(frozen)), float(to.solverResidual), float(to.tdvp_error), ref)
+        out[dd] = (to.S0.clone(), to.F0.clone(), to.ev.clone(), u.clone(), aux["J"].clone())
+    (S, F, ev, u, J), (S2, F2, ev2, u2, J2) = out["float64"], out["float32"]
+    dJ = float((J2 - J).abs().max() / J.abs().max())
+    assert 1e-9 < dJ < 1e-6                                                                   # the fp32 reading IS a different computation
+    assert float((S2 - S).abs().max() / S.abs().max()) < 1e-7 and float((F2 - F).abs().max() / F.abs().max()) < 1e-7
+    rank = ev > 1e-9 * ev[-1]
+    assert int(rank.sum()) == int((ev2 > 1e-9 * ev2[-1]).sum()) == 144                       # the same numerical rank, the published one
+    assert float(((ev2 - ev)[rank].abs() / ev[rank]).max()) < 1e-6
+    assert float(torch.linalg.norm(S @ (u2 - u)) / torch.linalg.norm(F)) < 1e-6
+
+
 def test_oracle_follows_published_first_steps():
     """22 Heun steps on the published schedule (dt = 1e-7 doubling to 1e-2, stepper.py:129-139): t = 0 .. 0.053.
 
