@@ -197,6 +197,71 @@ def _timed(fn, reps=2):
     return float(np.median(ts)), float(np.min(ts)), ts
 
 
+def cpu_baseline_full(theta_cpu, inds_up, inds_down, workload="C2", slab=4096):
+    """`--cpu-baseline full`: the reference algorithm as written (oracle), ONCE at the workload's real sample count -- no extrapolation.
+    The per-sample autodiff (vmap(grad) + the Hessian pass) runs in slabs of `slab` samples whose Jacobians are concatenated into the
+    N x P array the reference materialises (var_state.py:29-34; 2.2 GB at C2); everything behind it is tdvp.py:36-94 on the full
+    arrays: centred copies, F0, the two un-symmetrised Gram GEMMs (S0, SExp), host eigh, EO @ V, pseudo-inverse.  One timed pass
+    (~1 minute at C2 on 16 cores), so it is not part of the default run; the record goes to profiles/."""
+    from oracle import vmc_oracle as O
+    w = WORKLOADS[workload]
+    dim, hidden, n_full = w["dim"], w["hidden"], w["n_samp"]
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    torch.set_num_threads(cores)
+    try:
+        from threadpoolctl import threadpool_limits
+        blas_cap = threadpool_limits(limits=cores)
+    except ImportError:
+        blas_cap = None
+    spec = O.NetSpec(dim=dim, inds_up=inds_up, inds_down=inds_down, intmediate=hidden, offset=list(w["offset"]))
+    P = O.num_parameters(spec)
+    if P > 8000:
+        raise SystemExit("--cpu-baseline full: the host eigh of a 16 181 x 16 181 matrix does not fit a benchmark run (SURVEY 8d); use the default sample mode")
+    vo = O.VarStateOracle(spec, theta_cpu)
+    eo = O.EvolutionEquationOracle(dim, EQ)
+    eo.eqParams[EQ]["params"]["lam"] = w.get("lam", LAM)
+    g = torch.Generator().manual_seed(0)
+    parts = {}
+    t_all = time.perf_counter()
+    t0 = time.perf_counter()
+    Es, Js, Ls = [], [], []
+    for first in range(0, n_full, slab):
+        n = min(slab, n_full - first)
+        z = O.latent_from_normals(spec, theta_cpu, torch.randn(n, dim, generator=g, dtype=torch.float64))
+        x, _ = vo.flow_sample(z)
+        E, J, lp = eo(vo, x, 0.0)
+        Es.append(E), Js.append(J), Ls.append(lp)
+    Eloc, J, logp = torch.cat(Es, 1), torch.cat(Js, 1), torch.cat(Ls, 1)
+    del Es, Js, Ls
+    parts["sample + autodiff J + Hessian (slabs of %d)" % slab] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    to = O.TDVPOracle()
+    S, F, EOdata = to.get_tdvp_equation(Eloc, J, logp, n_full)          # tdvp.py:36-52
+    parts["means, centred copies, F0, S0 and SExp GEMMs"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ev, Vn = np.linalg.eigh(S.numpy())                                  # tdvp.py:61-64
+    parts["host eigh"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    to.ev, to.V = torch.from_numpy(ev), torch.from_numpy(Vn)
+    to.VtF = to.V.T @ F
+    EO = EOdata[0] @ to.V                                               # tdvp.py:68
+    rho = ((EO - EO.sum(0) / n_full) ** 2).sum(0) / n_full              # tdvp.py:70
+    parts["EO @ V and its variance"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rel = torch.abs(to.ev / to.ev[-1])
+    upd = to.V @ (torch.where(rel > 1e-14, 1.0 / to.ev, torch.zeros_like(to.ev)) / (1.0 + (1e-11 / rel) ** 6) * to.VtF)   # tdvp.py:82-91
+    resid = float(torch.linalg.norm(S @ upd - F) / torch.linalg.norm(F))
+    parts["pseudo-inverse, residual"] = time.perf_counter() - t0
+    total = time.perf_counter() - t_all
+    if blas_cap is not None:
+        blas_cap.restore_original_limits()
+    return {"value": 1.0 / total, "unit": "TDVP steps/s", "cores": cores, "kind": "port", "workload": workload,
+            "sample": f"reference algorithm as written on torch/numpy fp64 CPU, ONE full step at N={n_full}, P={P}: nothing extrapolated",
+            "seconds_per_step": total, "parts_seconds": parts, "solver_residual": resid, "rank_1e-9": int((rel > 1e-9).sum()),
+            "note": "an eager torch.func port of the reference's algorithm, not XLA-jitted JAX-CPU (jax is not installable here): "
+                    "a reported baseline, not a comparison with the reference's own runtime"}
+
+
 def cpu_baseline(theta_cpu, inds_up, inds_down, workload="C2"):
     """The reference algorithm as written (oracle), timed piecewise on bounded samples -- one warm-up and two timed repetitions
     per part -- and extrapolated to the full step: the autodiff part (vmap(grad) + the Hessian pass) is timed at
@@ -312,6 +377,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full"],
+                    help="sample (default): the CPU port timed piecewise on bounded samples and extrapolated (finishes in ~25 s); full: ONE step of the "
+                         "port at the workload's real sample count, autodiff in 4096-sample slabs (~1 min at C2; C2 / C4 only)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="BASELINE config (default C2, the headline)")
     ap.add_argument("--samples", type=int, default=0, help="samples per rank (default: the workload's)")
     ap.add_argument("--jacobian", default="f64", choices=["f64", "f32", "f32blocks", "i8sliced", "i8f32"],
@@ -521,7 +589,7 @@ def main():
             # numbers quoted beside the headline come from this run as well
             line["beside"] = beside_headline(device, args, kwargs, theta)
         if world == 1 and not args.no_cpu_baseline and args.samples == WORKLOADS[args.workload]["n_samp"]:
-            line["cpu_baseline"] = cpu_baseline(theta.cpu(), vs.net.inds_up, vs.net.inds_down, args.workload)
+            line["cpu_baseline"] = (cpu_baseline_full if args.cpu_baseline == "full" else cpu_baseline)(theta.cpu(), vs.net.inds_up, vs.net.inds_down, args.workload)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if world > 1:
