@@ -392,6 +392,9 @@ def main():
                          "it (tdvp.py:21-26: spectral pseudo-inverse, diagonalShift 0, svdTol 1e-11) with the rank-revealing decomposition; "
                          "eigh-dense: the same with rocSOLVER's syevd on the full matrix -- both reported BESIDE the headline")
     ap.add_argument("--no-beside", action="store_true", help="skip the opt-in experiments measured after the timed region (`beside` in the line)")
+    ap.add_argument("--overlap-allreduce", action="store_true",
+                    help="N > 1: TDVP(overlapAllreduce=True) -- the S-build by groups of tile rows, every finished group all-reduced on a side stream "
+                         "while the next is formed (off by default; for an A/B on a multi-GPU node: rank_stage_ms.allreduce is then the EXPOSED part)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched ranks (--gpus N > 1 without a launcher): seconds before they are stopped")
     args = ap.parse_args()
 
@@ -443,6 +446,7 @@ def main():
         tdvp.spectralEngine = "dense" if args.solver == "eigh-dense" else "auto"
         if args.solver == "eigh-matrixfree":
             tdvp.matrixFree = True                               # EXPERIMENT: the reference-default solve without an assembled S
+    tdvp.overlapAllreduce = bool(args.overlap_allreduce)
     P = vs.numParameters
     n_total = args.samples * world
     kwargs = dict(evolutionEq=eq, psi=vs, nSamplesTDVP=n_total, nSamplesObs=n_total, timings=None, observables=False)
@@ -579,6 +583,9 @@ def main():
             # replicated part once) against this step -- derived from the per-rank HIP-event brackets above, not a separate run
             sf, gr, ar, rep = (float(np.max([r[i] for r in per_rank])) for i in range(4))
             line["rccl"] = rccl
+            # the collective inside the timed steps: its bracket on the launch stream is what the step WAITS for -- the whole all-reduce
+            # when it follows the S-build, only its exposed tail when it is interleaved with it (--overlap-allreduce)
+            line["allreduce_in_step"] = dict(tdvp.allreduceInfo or {}, exposed_ms_max_rank=ar, alone_ms=rccl["allreduce_alone_ms"])
             line["one_gpu_same_samples"] = {"ms_per_step_from_stages": world * (sf + gr) + rep, "this_run_ms_per_step": elapsed / args.steps * 1e3,
                                             "speedup": (world * (sf + gr) + rep) / (elapsed / args.steps * 1e3),
                                             "allreduce_bracket_ms_max_rank": ar,

@@ -157,6 +157,12 @@ int64_t vmcpde_gram_workspace_bytes(int32_t P, int64_t n_samples);
  *   no longer exactly positive semi-definite: factor it only with a relative diagonal shift >= 1e-4. */
 int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t P, int64_t n_samples, const double* c, const double* w,
                 double* packed, void* workspace, int64_t workspace_bytes, void* stream);
+/* ABI 5: the same sums as vmcpde_gram(JT, ldj, 0, P, n, NULL, NULL, ...) for the tiles of tile rows [row_begin, row_end) only (rows of 128
+ * parameters; the packed buffer is tile-row major, so they are one contiguous piece of it): same sample splits, same per-unit arithmetic,
+ * so a partition of the tile rows reproduces vmcpde_gram's buffer bit for bit.  Lets a sharded step pass finished row groups to the
+ * all-reduce (mpi_wrapper.py:129-163) while the next group is being formed.  Same workspace as vmcpde_gram. */
+int vmcpde_gram_rows(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, int32_t row_begin, int32_t row_end, double* packed,
+                     void* workspace, int64_t workspace_bytes, void* stream);
 /* tdvp.py:45-46,50-51: S[i][j] = packed/Ntot - d_i d_j (full symmetric, both triangles written) with
  * d = rowsum/Ntot + c - c_gram = (global mean) - (the shift vmcpde_gram was given; c_gram NULL = 0, i.e. uncentred Gram),
  * A_shifted = S + diag(diagonal_shift * diag S) + floor_dev[0] * I (optional second copy for the in-place Cholesky, may be NULL;

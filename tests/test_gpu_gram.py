@@ -299,3 +299,35 @@ def test_gram_i8_four_digits_on_an_fp32_jacobian(P, N):
     assert np.array_equal(_unpack(_gram_i8(Ji, ldj, P, N, slices=4, bits=8, f32=1), P), _unpack(_gram(Ji, ldj, P, N, f32=1), P))
     with pytest.raises(nat.VmcpdeError, match="fp32 Jacobian"):
         _gram_i8(J32, ldj, P, N, slices=7, bits=7, f32=1)
+
+
+@pytest.mark.parametrize("P,N,groups", [(4215, 4096, [(0, 17), (17, 24), (24, 29), (29, 33)]), (300, 1000, [(0, 1), (1, 3)]), (129, 70, [(1, 2), (0, 1)]),
+                                        (16183, 512, [(0, 64), (64, 90), (90, 110), (110, 127)])])
+def test_gram_by_tile_rows_is_the_whole_gram_bit_for_bit(P, N, groups):
+    """vmcpde_gram_rows (ABI 5): the steady-state Gram for the tiles of a few tile rows -- one contiguous piece of the packed buffer.  A
+    partition of the tile rows, in any order, reproduces vmcpde_gram's buffer exactly (same sample splits, same per-unit arithmetic):
+    what lets a sharded step all-reduce finished row groups while the next is being formed (TDVP(overlapAllreduce=True))."""
+    from vmc_pde_amd import _native as nat
+    L = nat.lib()
+    g = torch.Generator(device="cuda").manual_seed(P)
+    ldj = (N + 15) // 16 * 16
+    Ppad = (P + 127) // 128 * 128
+    JT = torch.zeros((Ppad, ldj), dtype=torch.float64, device="cuda")
+    JT[:P, :N] = torch.randn((P, N), generator=g, dtype=torch.float64, device="cuda")
+    npk = L.vmcpde_gram_packed_doubles(P)
+    ws = torch.empty(max(L.vmcpde_gram_workspace_bytes(P, N) // 8, 1), dtype=torch.float64, device="cuda")
+    whole = torch.zeros(npk, dtype=torch.float64, device="cuda")
+    nat.call("vmcpde_gram", nat.ptr(JT), ldj, 0, P, N, None, None, nat.ptr(whole), nat.ptr(ws), ws.numel() * 8, nat.stream())
+    parts = torch.full((npk,), float("nan"), dtype=torch.float64, device="cuda")
+    tri = lambda r: r * (r + 1) // 2
+    for r0, r1 in groups:
+        before = parts.clone()
+        nat.call("vmcpde_gram_rows", nat.ptr(JT), ldj, P, N, r0, r1, nat.ptr(parts), nat.ptr(ws), ws.numel() * 8, nat.stream())
+        lo, hi = tri(r0) * 128 * 128, tri(r1) * 128 * 128
+        touched = ~((parts == before) | (torch.isnan(parts) & torch.isnan(before)))
+        assert not bool(touched[:lo].any()) and not bool(touched[hi:].any())          # a group writes its own piece only
+    assert torch.equal(parts, whole)
+    with pytest.raises(nat.VmcpdeError, match="tile rows"):
+        nat.call("vmcpde_gram_rows", nat.ptr(JT), ldj, P, N, 2, 2, nat.ptr(parts), nat.ptr(ws), ws.numel() * 8, nat.stream())
+    with pytest.raises(nat.VmcpdeError, match="tile rows"):
+        nat.call("vmcpde_gram_rows", nat.ptr(JT), ldj, P, N, 0, Ppad // 128 + 1, nat.ptr(parts), nat.ptr(ws), ws.numel() * 8, nat.stream())

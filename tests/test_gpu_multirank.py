@@ -18,6 +18,8 @@ N, DIM, DEPTH, HIDDEN = 6001, 2, 3, (5, 5)     # odd N: ranks get 3001 / 3000 sa
 # the two solvers, and both through the pivoted low-rank factor of S (forced: the default takes those routes from 1024 / 4096 parameters
 # on) -- the second call of the Cholesky variant runs its static plan
 SOLVERS = (("chol", dict(diagonalShift=1e-5, solver="cholesky")), ("eigh", dict(solver="eigh")),
+           # the same step with the collective interleaved with the S-build by groups of tile rows (P = 281: three tile rows, three groups)
+           ("chol-overlap", dict(diagonalShift=1e-5, solver="cholesky", overlapAllreduce=True)),
            ("chol-lowrank", dict(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine="lowrank")),
            ("eigh-lowrank", dict(solver="eigh", spectralEngine="lowrank")),
            # the matrix-free experiment: no S at all; moments, every 32-column panel and every S0 v are summed over the ranks
@@ -96,6 +98,12 @@ def test_two_ranks_match_single_rank():
                 assert float(torch.linalg.norm(S0 @ (r[0] - u0)) / torch.linalg.norm(F0)) < 1e-8
         # the replicated solve is bit-identical on both ranks (same all-reduced inputs, deterministic kernels)
         assert torch.equal(got[0][name][0], got[1][name][0]) and torch.equal(got[0][name][3], got[1][name][3])
+    # the overlapped collective moves the same bits as the single call: S, F and both updates, on one rank and on two
+    for a, b in zip(single["chol"][:6], single["chol-overlap"][:6]):
+        assert torch.equal(a, b)
+    for rank in (0, 1):
+        for a, b in zip(got[rank]["chol"][:6], got[rank]["chol-overlap"][:6]):
+            assert torch.equal(a, b)
 
 
 def test_abi_allreduce_on_a_single_rank_communicator():

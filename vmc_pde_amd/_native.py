@@ -69,6 +69,7 @@ _PROTOS = {
     "vmcpde_gram_packed_doubles": (_i64, [_i32]),
     "vmcpde_gram_workspace_bytes": (_i64, [_i32, _i64]),
     "vmcpde_gram": (_int, [_vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "vmcpde_gram_rows": (_int, [_vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
     "vmcpde_gram_i8_workspace_bytes": (_i64, [_i32, _i64, _i32, _i32]),
     "vmcpde_gram_i8": (_int, [_vp, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "vmcpde_gram_finalize": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f64, _f64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),

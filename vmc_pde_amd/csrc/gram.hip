@@ -110,9 +110,11 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const TIn* __restrict__ JT
 }
 
 // the steady-state variant (fp64, uncentred, unweighted): DMA-staged main loop
+// (ntiles: the tiles this launch deals out; ntiles_out: the tiles of the whole lower triangle = the slab pitch -- they differ only for
+// vmcpde_gram_rows, whose perm holds the global indices of the tiles of a few tile rows)
 __global__ __launch_bounds__(256, GRAM_BKD == 8 ? 3 : 2) void gram_dma_kernel(const double* __restrict__ JT, int64_t ldj, int64_t N, int ntiles, int nsplit,
                                                           int64_t chunk, int total_units, int units_per_xcd, int order,
-                                                          const int* __restrict__ perm, double* __restrict__ out) {
+                                                          const int* __restrict__ perm, double* __restrict__ out, int ntiles_out) {
   extern __shared__ double lds[];
   int split, tile;
   if (!gram_unit(ntiles, nsplit, total_units, units_per_xcd, order, perm, split, tile)) return;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256, GRAM_BKD == 8 ? 3 : 2) void gram_dma_kernel(co
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
   tile_mainloop_dma<GRAM_BKD>(acc, JT, ldj, ti * TILE, JT, ldj, tj * TILE, ti == tj, k0, k1, lds);
-  tile_store(acc, out + ((int64_t)split * ntiles + tile) * (TILE * TILE));
+  tile_store(acc, out + ((int64_t)split * ntiles_out + tile) * (TILE * TILE));
 }
 
 // BASELINE config 5, fast variant ("f32 blocks"): fp32 Jacobian, products summed in fp32 by v_mfma_f32_16x16x4_f32 over blocks of
@@ -152,12 +154,13 @@ __global__ __launch_bounds__(256, 2) void gram_f32_kernel(const double* __restri
 }
 
 // packed[tile][e] = sum_split slabs[split][tile][e]   (fixed order -> deterministic)
-__global__ void reduce_splits_kernel(const double* __restrict__ slabs, int nsplit, int64_t per_split, double* __restrict__ packed) {
+// (count doubles of every slab, slabs `pitch` doubles apart: the whole triangle, or the tiles of a few tile rows)
+__global__ void reduce_splits_kernel(const double* __restrict__ slabs, int nsplit, int64_t count, int64_t pitch, double* __restrict__ packed) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
-  if (i >= per_split) return;
+  if (i >= count) return;
   double2_t s = *reinterpret_cast<const double2_t*>(slabs + i);
   for (int k = 1; k < nsplit; ++k) {
-    const double2_t v = *reinterpret_cast<const double2_t*>(slabs + (int64_t)k * per_split + i);
+    const double2_t v = *reinterpret_cast<const double2_t*>(slabs + (int64_t)k * pitch + i);
     s.x += v.x;
     s.y += v.y;
   }
@@ -430,7 +433,7 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
       ctx->attr_gram_dma = true;
     }
     hipLaunchKernelGGL(gram_dma_kernel, dim3(grid), dim3(256), dma_lds, st, static_cast<const double*>(JT), ldj, n_samples, g.ntiles,
-                       g.nsplit, g.chunk, total, per_xcd, order, perm, out);
+                       g.nsplit, g.chunk, total, per_xcd, order, perm, out, g.ntiles);
   } else if (jt_f32) VMC_LAUNCH_GRAM_T(float);
   else VMC_LAUNCH_GRAM_T(double);
 #undef VMC_LAUNCH_GRAM_T
@@ -439,8 +442,62 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
   if (g.nsplit > 1) {
     const int64_t per_split = (int64_t)g.ntiles * TILE * TILE;
     const int64_t threads = per_split / 2;
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, out, g.nsplit, per_split,
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, out, g.nsplit, per_split, per_split,
                        packed);
+    VMC_CHECK_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+// The steady-state Gram (fp64, uncentred, unweighted) for the tiles of tile rows [row_begin, row_end) only -- the packed buffer is tile-row
+// major, so these are ONE contiguous piece of it, complete (split sums included) when this call's launches have drained.  Same sample
+// splits as vmcpde_gram on the whole triangle, same per-unit arithmetic: calling it for a partition of the tile rows gives the packed
+// buffer of one vmcpde_gram call bit for bit.  What it is for: a multi-GPU step can hand finished row groups to the all-reduce while
+// the next group is still being formed (mpi_wrapper.py:129-163 reduces after the whole sum).
+extern "C" int vmcpde_gram_rows(const double* JT, int64_t ldj, int32_t P, int64_t n_samples, int32_t row_begin, int32_t row_end, double* packed,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
+  VMC_REQUIRE(JT && packed, "vmcpde_gram_rows: null argument");
+  VMC_REQUIRE(P >= 1 && n_samples >= 1, "bad shape");
+  VMC_REQUIRE(ldj >= n_samples && (ldj % 2) == 0 && ldj < (1 << 22), "ldj must be even, >= n_samples and < 2^22");
+  VMC_REQUIRE((reinterpret_cast<uintptr_t>(JT) & 15) == 0, "JT must be 16-byte aligned");
+  const GramPlan g = make_plan(P, n_samples, SLOTS_DMA);             // the plan of the whole triangle: same splits, same chunks
+  VMC_REQUIRE(0 <= row_begin && row_begin < row_end && row_end <= g.nb, "tile rows [%d, %d) outside [0, %d)", row_begin, row_end, g.nb);
+  const int64_t need = (int64_t)g.nsplit * g.ntiles * TILE * TILE * (int64_t)sizeof(double);
+  double* out = packed;
+  if (g.nsplit > 1) {
+    VMC_REQUIRE(workspace && workspace_bytes >= need, "gram workspace too small: need %lld bytes", (long long)need);
+    out = static_cast<double*>(workspace);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int t0 = (int)tri_count(row_begin), t1 = (int)tri_count(row_end), nsub = t1 - t0;
+  DeviceCtx* ctx = device_ctx();
+  if (!ctx) return -2;
+  DeviceCtxLock lock;
+  // the group's tiles along a Morton curve (global tile indices), balanced over the XCDs like the whole triangle's (gram_order.hpp)
+  const int key = (g.nb << 20) | (row_begin << 10) | row_end;         // (plain sizes use keys below 2^20; nb <= 127, rows <= 127)
+  auto it = ctx->gram_perms.find(key);
+  if (it == ctx->gram_perms.end()) {
+    std::vector<int> host;
+    for (int t : morton_tile_order(g.nb))
+      if (t >= t0 && t < t1) host.push_back(t);
+    int* dev = nullptr;
+    VMC_CHECK_HIP(hipMalloc(&dev, host.size() * sizeof(int)));
+    VMC_CHECK_HIP(hipMemcpy(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice));
+    it = ctx->gram_perms.emplace(key, dev).first;
+  }
+  const int per_xcd = order2_slots_per_xcd(nsub, g.nsplit);
+  const size_t dma_lds = 4 * DmaGeom<GRAM_BKD>::DT * sizeof(double);
+  if (!ctx->attr_gram_dma && dma_lds > 64 * 1024) {
+    VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds));
+    ctx->attr_gram_dma = true;
+  }
+  hipLaunchKernelGGL(gram_dma_kernel, dim3(per_xcd * 8), dim3(256), dma_lds, st, JT, ldj, n_samples, nsub, g.nsplit, g.chunk, nsub * g.nsplit,
+                     per_xcd, 2, it->second, out, g.ntiles);
+  VMC_CHECK_HIP(hipGetLastError());
+  if (g.nsplit > 1) {
+    const int64_t count = (int64_t)nsub * TILE * TILE, pitch = (int64_t)g.ntiles * TILE * TILE, off = (int64_t)t0 * TILE * TILE;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((count / 2 + 255) / 256)), dim3(256), 0, st, out + off, g.nsplit, count, pitch,
+                       packed + off);
     VMC_CHECK_HIP(hipGetLastError());
   }
   return 0;

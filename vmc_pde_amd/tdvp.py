@@ -106,6 +106,11 @@ class TDVP(LowRankRoutes):
                                   # "auto": uncentred once the previous call showed max_p mean_p^2/var_p < 1e3, i.e. the
                                   #   cancellation costs < 3 of fp64's 16 digits; centred otherwise
     fuseMoments: bool = True      # uncentred path: sum O and sum O (E - cE) ride in the syrk as two appended Jacobian rows
+    overlapAllreduce: bool = False  # sharded samples, steady-state Gram: the S-build runs as groups of tile rows (vmcpde_gram_rows) and every
+                                  # finished group -- one contiguous piece of the packed buffer -- is all-reduced on a side stream while
+                                  # the next is being formed; finalize waits for the last.  Same bits as the single call.  Off by default:
+                                  # it trades ~3 partial rounds of the Gram's schedule for the hidden collective and has never met more
+                                  # than one GPU (VMCPDE_OVERLAP_ALLREDUCE=1 / VMCPDE_OVERLAP_GROUPS=G, default 4, for an A/B on a node)
     f32BlockGram: bool = False    # with an fp32 Jacobian: fp32 MFMA sums over blocks of <= 128 samples, fp64 across blocks (2x MFMA rate)
     frozenParameters: object = None   # flat parameter indices held fixed: their rows / columns of S and entries of F are zeroed, so
                                   # both solvers return a zero update for them (the pseudo-inverse drops the zero modes, tdvp.py:82;
@@ -140,6 +145,7 @@ class TDVP(LowRankRoutes):
         self.ev = self.V = self.VtF = None
         self._ratio_host = self._ratio_event = None
         self._ratio_prev = None
+        self.allreduceInfo = None
         self._uncentred_ok = False
         self._floor = None
 
@@ -193,6 +199,51 @@ class TDVP(LowRankRoutes):
                              f"(got {self.diagonalShift:g}); use the widening fp32 path (f32BlockGram=False) for smaller shifts")
         with self._Section(self, "gram"):             # bench.py: HIP events on the launch stream around the S-build
             self._gram_launch(b, JT, ldj, f32, P, n, c, w, out)
+
+    def _gram_and_allreduce(self, b, JT, ldj, Pg, n, c_gram):
+        """The S-build of this rank's shard into b["packed"] and the step's ONE collective over b["pack"] = [tiles | sum O | sum E~O |
+        Eloc sums | n] (mpi_wrapper.py:129-163) -- back to back, or (overlapAllreduce) interleaved by groups of tile rows."""
+        overlap = (self.overlapAllreduce or os.environ.get("VMCPDE_OVERLAP_ALLREDUCE", "0") == "1") and c_gram is None and \
+            JT.dtype == global_defs.tReal and not getattr(self, "int8Gram", False) and not self.f32BlockGram
+        nb = (Pg + nat.GRAM_TILE - 1) // nat.GRAM_TILE
+        ngroups = min(max(int(os.environ.get("VMCPDE_OVERLAP_GROUPS", "4")), 1), nb)
+        if not overlap or ngroups < 2:
+            self._gram(b, JT, ldj, Pg, n, c_gram, None, b["packed"])
+            with self._Section(self, "allreduce"):
+                mpi.allreduce_sum_(b["pack"])        # the one collective of the step (no-op on a single rank)
+            self.allreduceInfo = dict(overlapped=False)
+            return
+        need = nat.lib().vmcpde_gram_workspace_bytes(Pg, n)
+        if b["gram_ws"] is None or b["gram_ws"].numel() * 8 < need:
+            b["gram_ws"] = torch.empty(max(need // 8, 1), dtype=global_defs.tReal, device=JT.device)
+        # tile rows dealt into groups of about equal tile counts (row r holds r + 1 tiles); the last group also carries the buffer's tail
+        tri = lambda r: r * (r + 1) // 2
+        bounds, r = [0], 0
+        for g in range(1, ngroups):
+            while r < nb and tri(r) < g * tri(nb) / ngroups:
+                r += 1
+            bounds.append(min(max(r, bounds[-1] + 1), nb - (ngroups - g)))
+        bounds.append(nb)
+        main = torch.cuda.current_stream(JT.device)
+        if getattr(self, "_side_stream", None) is None or self._side_stream.device != JT.device:
+            self._side_stream = torch.cuda.Stream(device=JT.device)
+        side, T2 = self._side_stream, nat.GRAM_TILE * nat.GRAM_TILE
+        with self._Section(self, "gram"):
+            for g in range(ngroups):
+                r0, r1 = bounds[g], bounds[g + 1]
+                nat.call("vmcpde_gram_rows", nat.ptr(JT), ldj, Pg, n, r0, r1, nat.ptr(b["packed"]), nat.ptr(b["gram_ws"]), b["gram_ws"].numel() * 8,
+                         nat.stream())
+                ready = torch.cuda.Event()
+                ready.record(main)
+                side.wait_event(ready)
+                piece = b["pack"][tri(r0) * T2:(tri(r1) * T2 if g + 1 < ngroups else b["pack"].numel())]
+                with torch.cuda.stream(side):
+                    mpi.allreduce_sum_(piece)
+        with self._Section(self, "allreduce"):       # what is left of the collective when the last group's tiles are done: its exposed part
+            done = torch.cuda.Event()
+            done.record(side)
+            main.wait_event(done)
+        self.allreduceInfo = dict(overlapped=True, groups=ngroups, tile_rows=bounds)
 
     def _gram_launch(self, b, JT, ldj, f32, P, n, c, w, out):
         """The fp64-MFMA syrk (csrc/gram.hip) on the parameter-major Jacobian: packed lower-triangle tiles of sum_n w_n^2 (J_n - c)(J_n - c)^T."""
@@ -269,9 +320,7 @@ class TDVP(LowRankRoutes):
             if not bordered:
                 nat.call("vmcpde_row_moments", nat.ptr(JT), ldj, f32, P, n, nat.ptr(e), nat.ptr(c), nat.ptr(cE), nat.ptr(b["rowsum"]),
                          nat.ptr(b["rowdot"]), nat.stream())
-            self._gram(b, JT, ldj, P + 2 if bordered else P, n, c_gram, None, b["packed"])
-            with self._Section(self, "allreduce"):
-                mpi.allreduce_sum_(b["pack"])        # the one collective of the step (no-op on a single rank)
+            self._gram_and_allreduce(b, JT, ldj, P + 2 if bordered else P, n, c_gram)
             self._replicated = self._Section(self, "replicated")      # finalize + factorisation + substitution + diagnostics: closed in solve()
             self._replicated.__enter__()
             if use_chol and b["A"] is None:
