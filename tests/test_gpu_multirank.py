@@ -31,6 +31,7 @@ def _problem():
     sampler = V.Sampler(key=77, dim=DIM, name="Gauss", mcmc_info={"offset": np.ones(DIM), "bound": 0.25})
     vs = V.VarState(sampler, DIM, 5, DEPTH, network_args=dict(intmediate=HIDDEN, offset=np.ones(DIM), latentSpaceName="Gauss", dim=DIM))
     vs.set_parameters(vs.net.init(5, out_scale=0.05))
+    vs.theta_start = vs.get_parameters().clone()
     eq = V.EvolutionEquation(dim=DIM, name="advection_hamiltonian_wDiss")
     eq.eqParams[eq.name]["params"]["lam"] = 0.1
     return V, vs, eq
@@ -42,7 +43,8 @@ def _two_calls(V, vs, eq, solver_kw):
     else:
         cls = V.TDVP
     tdvp = cls(**solver_kw)
-    th0 = vs.get_parameters()
+    vs.sampler._calls = 0                     # every variant draws the same two batches (sample n of call k is a function of (key, k, n))
+    th0 = vs.theta_start.clone()              # ... at the same two states
     u0, _ = tdvp(th0, 0.0, vs, eq, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
     none = torch.zeros(1, 1, dtype=th0.dtype, device=th0.device)          # (the matrix-free variant has no S0)
     S0, F0 = (tdvp.S0.clone() if tdvp.S0 is not None else none), tdvp.F0.clone()

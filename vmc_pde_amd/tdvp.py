@@ -227,23 +227,41 @@ class TDVP(LowRankRoutes):
         main = torch.cuda.current_stream(JT.device)
         if getattr(self, "_side_stream", None) is None or self._side_stream.device != JT.device:
             self._side_stream = torch.cuda.Stream(device=JT.device)
+            self._group_streams = []
+        # group launches on streams of their own (VMCPDE_OVERLAP_STREAMS=0: all on the caller's stream, where every group's last, partly
+        # filled round of workgroups is a bubble): the next group's workgroups fill the CUs the previous one frees; the first
+        # groups get the higher priority so that they still finish first
+        concurrent = os.environ.get("VMCPDE_OVERLAP_STREAMS", "1") != "0"
+        while concurrent and len(self._group_streams) < ngroups:
+            self._group_streams.append(torch.cuda.Stream(device=JT.device, priority=-1 if len(self._group_streams) < ngroups - 1 else 0))
         side, T2 = self._side_stream, nat.GRAM_TILE * nat.GRAM_TILE
         with self._Section(self, "gram"):
+            start = torch.cuda.Event()
+            start.record(main)
+            readies = []
             for g in range(ngroups):
                 r0, r1 = bounds[g], bounds[g + 1]
-                nat.call("vmcpde_gram_rows", nat.ptr(JT), ldj, Pg, n, r0, r1, nat.ptr(b["packed"]), nat.ptr(b["gram_ws"]), b["gram_ws"].numel() * 8,
-                         nat.stream())
+                cs = self._group_streams[g] if concurrent else main
+                if concurrent:
+                    cs.wait_event(start)
+                with torch.cuda.stream(cs):
+                    nat.call("vmcpde_gram_rows", nat.ptr(JT), ldj, Pg, n, r0, r1, nat.ptr(b["packed"]), nat.ptr(b["gram_ws"]), b["gram_ws"].numel() * 8,
+                             nat.stream())
                 ready = torch.cuda.Event()
-                ready.record(main)
+                ready.record(cs)
+                readies.append(ready)
                 side.wait_event(ready)
                 piece = b["pack"][tri(r0) * T2:(tri(r1) * T2 if g + 1 < ngroups else b["pack"].numel())]
                 with torch.cuda.stream(side):
                     mpi.allreduce_sum_(piece)
+            if concurrent:
+                for ready in readies:
+                    main.wait_event(ready)
         with self._Section(self, "allreduce"):       # what is left of the collective when the last group's tiles are done: its exposed part
             done = torch.cuda.Event()
             done.record(side)
             main.wait_event(done)
-        self.allreduceInfo = dict(overlapped=True, groups=ngroups, tile_rows=bounds)
+        self.allreduceInfo = dict(overlapped=True, groups=ngroups, tile_rows=bounds, group_streams=concurrent)
 
     def _gram_launch(self, b, JT, ldj, f32, P, n, c, w, out):
         """The fp64-MFMA syrk (csrc/gram.hip) on the parameter-major Jacobian: packed lower-triangle tiles of sum_n w_n^2 (J_n - c)(J_n - c)^T."""
