@@ -339,6 +339,15 @@ int vmcpde_gram_columns(const double* JT, int64_t ldj, int32_t P, int64_t n_samp
  * diagonal gets v = e_k, tau = 2).  Two reflectors per launch while their columns fit the registers of a workgroup (P <= 16 384), one
  * otherwise.  scratch: [dev] 5 r + 5 doubles. */
 int vmcpde_householder_rows(double* LT, int64_t ldl, int32_t P, int32_t r, double* YT, double* tau, double* scratch, void* stream);
+/* ABI 5: the r x r core of that decomposition (tdvp.py:57-64 on range(L)) without a library eigensolver.  One-sided Jacobi on the columns
+ * of an r x r matrix C (r <= 1024): on return the columns are mutually orthogonal, C_out = U diag(sigma) with U the left singular vectors and
+ * sigma the singular values of the input -- for C = R1 (the triangular factor of L = Q1 R1) the eigenvectors and the square roots of the
+ * eigenvalues of R1 R1^T = Q1^T (L L^T) Q1, in no particular order.  CT: [dev] cols_pad x rows_pad doubles, row c = column c of C, zero
+ * padded (vmcpde_jacobi_shape gives the padded sizes: rows to a multiple of 64, columns to a multiple of the columns a workgroup sweeps).
+ * n_sweeps (<= 30) sweeps are launched; launches behind a sweep that rotated nothing return at once.  counters: [dev] n_sweeps + 1 int32,
+ * counters[s] = rotations of sweep s -- converged iff some counters[s] == 0 (the caller may read it later; nothing synchronises). */
+int vmcpde_jacobi_shape(int32_t r, int32_t* rows_pad, int32_t* cols_pad);
+int vmcpde_jacobi_columns(double* CT, int32_t r, int32_t n_sweeps, int32_t* counters, void* stream);
 
 #ifdef __cplusplus
 }

@@ -652,3 +652,75 @@ def test_lowrank_routes_on_small_models(hidden):
         assert float((tm.ev - ts.ev).abs().max()) < 1e-12 * float(ts.ev[-1])
         assert float(torch.linalg.norm(S @ (um - us))) < 1e-9 * nF
 
+
+
+@pytest.mark.parametrize("r,triangular", [(1, False), (5, True), (64, True), (65, False), (206, True), (256, True), (300, True), (600, False), (1000, True)])
+def test_jacobi_columns_against_numpy(r, triangular):
+    """vmcpde_jacobi_columns (csrc/jacobi.hip): one-sided Jacobi on the columns of an r x r matrix whose columns span seven decades (as the
+    triangular factor R1 of the pivoted factor does): on return the columns are orthogonal to sqrt(rows) eps, their norms are the singular
+    values (to the accuracy of each COLUMN's scale, not of the largest), and U diag(sigma^2) U^T is C C^T -- the r x r core of the
+    rank-revealing spectral solve (tdvp.py:57-64 on range(L)) without a library eigensolver."""
+    from vmc_pde_amd import _native as nat
+    import ctypes as C
+    rng = np.random.default_rng(r)
+    A = rng.standard_normal((r, r))
+    if triangular:
+        A = np.triu(A)
+    A = A * np.logspace(0, -7, r)[None, :]                        # graded columns
+    rows, cols = C.c_int32(), C.c_int32()
+    nat.call("vmcpde_jacobi_shape", r, C.byref(rows), C.byref(cols))
+    rows, cols = rows.value, cols.value
+    assert rows % 64 == 0 and rows >= r and cols >= r and rows - r < 64
+    CT = torch.zeros((cols, rows), dtype=torch.float64, device="cuda")
+    CT[:r, :r] = torch.from_numpy(A.T.copy())
+    counters = torch.full((32,), -1, dtype=torch.int32, device="cuda")
+    nat.call("vmcpde_jacobi_columns", nat.ptr(CT), r, 20, nat.ptr(counters), nat.stream())
+    cnt = counters.cpu().numpy()[:21]
+    assert (cnt >= 0).all() and (cnt == 0).any(), cnt                # converged: a sweep that rotated nothing
+    first_zero = int(np.argmax(cnt == 0))
+    assert (cnt[first_zero:] == 0).all() and first_zero <= 12, cnt  # ... and nothing ran behind it
+    B = CT.cpu().numpy()[:r, :r].T                                   # columns u_j sigma_j
+    assert not CT[r:].any() and not CT[:, r:].any()                  # the zero padding stays zero
+    sig = np.linalg.norm(B, axis=0)
+    order = np.argsort(sig)[::-1]
+    sv = np.linalg.svd(A, compute_uv=False)
+    assert np.abs(sig[order] - sv).max() < 1e-14 * sv[0]
+    big = sv > 1e-9 * sv[0]
+    assert np.abs(sig[order][big] / sv[big] - 1).max() < 1e-10       # relative accuracy well below the top of the spectrum
+    U = B / sig
+    G = U.T @ U
+    assert np.abs(G - np.eye(r)).max() < 4 * np.sqrt(rows) * 1.2e-16 + 1e-15
+    assert np.linalg.norm((U * sig ** 2) @ U.T - A @ A.T) < 1e-13 * sv[0] ** 2
+    with pytest.raises(nat.VmcpdeError, match="1024"):
+        nat.call("vmcpde_jacobi_columns", nat.ptr(CT), 1025, 4, nat.ptr(counters), nat.stream())
+
+
+def test_jacobi_core_matches_the_library_core_at_headline_size(headline_net):
+    """The same rank-revealing decomposition with the r x r core solved by the own Jacobi kernel (default) and by the library's syevd:
+    eigenvalues to 1e-13 lambda_max, orthonormal V, the same update as the matrix sees it, twice (the second call launches the sweep
+    count the first one needed)."""
+    import vmc_pde_amd as V
+    varstate, ep, th = headline_net
+    N = 8192
+    vs = varstate(N)
+    out = {}
+    for core in ("library", "jacobi"):
+        tp = V.TDVP(svdTol=1e-6, coreEigensolver=core)
+        for _ in range(2):
+            u, _ = tp(th.cuda(), 0.0, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+            tp.check()
+        assert tp.spectralInfo["engine"] == "lowrank" and tp.spectralInfo["core"] == ("jacobi" if core == "jacobi" else "syevd"), tp.spectralInfo
+        out[core] = (tp.S0.clone(), tp.F0.clone(), tp.ev.clone(), tp.V.clone(), u.clone(), float(tp.solverResidual), float(tp.tdvp_error), tp)
+    S, F, ev_l, V_l, u_l, res_l, err_l, _ = out["library"]
+    S2, F2, ev_j, V_j, u_j, res_j, err_j, tj = out["jacobi"]
+    assert torch.equal(S, S2) and torch.equal(F, F2)
+    P, lmax, nF = S.shape[0], float(ev_l[-1]), float(torch.linalg.norm(F))
+    assert float((ev_j - ev_l).abs().max()) < 1e-13 * lmax and bool((ev_j[1:] >= ev_j[:-1]).all())
+    eye = torch.eye(P, dtype=torch.float64, device="cuda")
+    assert float((V_j.T @ V_j - eye).abs().max()) < 1e-13
+    r_j, r_l = float(torch.linalg.norm(S @ V_j - V_j * ev_j)) / lmax, float(torch.linalg.norm(S @ V_l - V_l * ev_l)) / lmax
+    assert r_j < max(3 * r_l, 1e-13), (r_j, r_l)
+    assert float(torch.linalg.norm(S @ (u_j - u_l))) < 1e-10 * nF
+    assert abs(res_j - res_l) < 1e-10 and abs(err_j - err_l) < 1e-10
+    st = tj._jacobi
+    assert not st["off"] and 4 <= st["n_sweeps"] <= 12, st            # the plan follows what the first call needed

@@ -15,8 +15,8 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIBDIR = PKG / "_lib"
 LIB = LIBDIR / "libvmcpde.so"
-SOURCES = ["model.hip", "flow.hip", "sampler.hip", "gram.hip", "gram_i8.hip", "moments.hip", "solve.hip", "eig.hip", "comm.hip"]
-HEADERS = [CSRC / "common.hpp", CSRC / "mfma_tile.hpp", CSRC / "gram_order.hpp", CSRC / "flow_kernels.inc", PKG.parent / "include" / "vmcpde.h"]
+SOURCES = ["model.hip", "flow.hip", "sampler.hip", "gram.hip", "gram_i8.hip", "moments.hip", "solve.hip", "eig.hip", "jacobi.hip", "comm.hip"]
+HEADERS = [CSRC / "common.hpp", CSRC / "mfma_tile.hpp", CSRC / "gram_order.hpp", CSRC / "wave_ops.hpp", CSRC / "flow_kernels.inc", PKG.parent / "include" / "vmcpde.h"]
 ARCH = "gfx950"
 # per-file flags.  solve.hip: keep MFMA accumulators in VGPRs -- the diagonal-block sweep edits them with VALU instructions between
 # MFMAs, and with the default AGPR form every step pays 40 v_accvgpr moves (measured: the whole factorisation 0.1 ms slower)

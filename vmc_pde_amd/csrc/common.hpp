@@ -106,6 +106,7 @@ struct DeviceCtx {
   bool attr_gram_i8[4] = {false, false, false, false};   // (6 slices x 8 bits, 6 x 7, 7 x 7, 4 x 8) of the int8 experiment
   int flow_eval_lds_by[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // largest dynamic-LDS size flow_eval_kernel was raised to, by [block width variant][KD = 1, KD = 1 capped, 2, 4]
   int flow_sample_lds_by[2] = {0, 0};
+  int jacobi_lds[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // dynamic-LDS size jacobi_step_kernel<rows / 64> was raised to
   std::map<int, int*> gram_perms;               // [dev] Gram tile orders (position -> lower-triangle tile index) by number of row blocks: built once
                                                 // per matrix size and GPU and never freed, so alternating sizes / threads never re-synchronise
 };

@@ -302,15 +302,73 @@ class LowRankRoutes:
             self.spectralInfo["rejected"] = "trace_left above %g x svdTol x lambda_max" % LOWRANK_SVDTOL_FRACTION
             return None
         self._lowrank_last_rank = r
+        jacobi = self._core_uses_jacobi(r)
+        Lc = w["LT"][:r].clone() if jacobi else None               # (the Householder chain overwrites the factor)
         Y, Xn, Q1 = self._lowrank_range_basis(w, P, r, device)
         SQ = S @ Q1
-        T = _long_k_product(Q1.T.contiguous(), SQ.T.contiguous())
+        Q1t = Q1.T.contiguous()
+        T = _long_k_product(Q1t, SQ.T.contiguous())
         T = 0.5 * (T + T.T)
-        # (the r x r core on one host LAPACK thread takes 1.6 ms against 5.4 ms for syevd's launch chain at r = 238, but the host
-        # synchronisation it needs costs the calling loop more than that: 33.0 against 30.2 ms per TDVP call -- measured and dropped)
-        wv, W = torch.linalg.eigh(T)                               # r x r (rocSOLVER)
+        if jacobi:
+            wv, W = self._core_eigh_jacobi(w, T, _long_k_product(Lc[:, :P], Q1t), r, device)
+        else:
+            # (the r x r core on one host LAPACK thread takes 1.6 ms against 5.4 ms for syevd's launch chain at r = 238, but the host
+            # synchronisation it needs costs the calling loop more than that: 33.0 against 30.2 ms per TDVP call -- measured and dropped)
+            wv, W = torch.linalg.eigh(T)                           # r x r (rocSOLVER)
+        self.spectralInfo["core"] = "jacobi" if jacobi else "syevd"
         U = Q1 @ W
         return self._lowrank_assemble(Y, Xn, U, wv, r, P, device)
+
+    # ---- the r x r core: one-sided Jacobi on the triangular factor (csrc/jacobi.hip) ------------------------------------
+    def _core_uses_jacobi(self, r):
+        """coreEigensolver="jacobi" (default) for ranks the kernel takes (<= 1024), unless an earlier call's sweeps did not converge (read
+        one call later, like every other health record of the engine: nothing synchronises inside a call)."""
+        if getattr(self, "coreEigensolver", "jacobi") != "jacobi" or os.environ.get("VMCPDE_CORE_EIGH", "jacobi") != "jacobi" or r > 1024:
+            return False
+        st = getattr(self, "_jacobi", None)
+        if st is not None and st["event"] is not None and not st["off"]:
+            st["event"].synchronize()
+            n = st["launched"]
+            done = [s for s in range(n) if int(st["host"][s]) == 0]
+            if not done:
+                import warnings
+                warnings.warn(f"Jacobi core of the spectral solve: {n} sweeps did not converge (rotations per sweep {st['host'][:n].tolist()}); "
+                              f"using the library eigensolver from now on", RuntimeWarning)
+                st["off"] = True
+            else:
+                st["n_sweeps"] = min(max(done[0] + 2, 4), 20)      # what the last call needed (its confirming sweep included) and one to spare
+            st["event"] = None
+        return st is None or not st["off"]
+
+    def _core_eigh_jacobi(self, w, T, R1t, r, device):
+        """(wv ascending, W) with T W = W diag(wv) for T = Q1^T S Q1 = R1 R1^T + Q1^T R Q1.  R1t = (Q1^T L)^T, r x r: row k = column k of R1.
+        The columns of R1 are orthogonalised by Jacobi rotations (left singular vectors u_j, singular values sigma_j); the eigenvalues are
+        then taken as Rayleigh quotients u_j^T T u_j, which folds the remainder R of the factorisation in (|Q1^T R Q1| <= trace(R): the
+        size of a dense eigensolver's backward error) and costs two r x r products."""
+        st = getattr(self, "_jacobi", None)
+        if st is None:
+            st = self._jacobi = dict(n_sweeps=12, launched=0, off=False, event=None, host=torch.zeros(32, dtype=torch.int32).pin_memory())
+        rows, cols = nat.C.c_int32(), nat.C.c_int32()
+        nat.call("vmcpde_jacobi_shape", r, nat.C.byref(rows), nat.C.byref(cols))
+        rows, cols = rows.value, cols.value
+        if w.get("jc") is None or w["jc"].shape != (cols, rows):
+            w["jc"] = torch.zeros((cols, rows), dtype=global_defs.tReal, device=device)
+            w["jc_counters"] = torch.zeros(32, dtype=torch.int32, device=device)
+        CT = w["jc"]
+        CT.zero_()
+        CT[:r, :r] = R1t
+        n = st["n_sweeps"]
+        nat.call("vmcpde_jacobi_columns", nat.ptr(CT), r, n, nat.ptr(w["jc_counters"]), nat.stream())
+        st["host"].copy_(w["jc_counters"], non_blocking=True)
+        st["launched"] = n
+        st["event"] = torch.cuda.Event()
+        st["event"].record()
+        sig2 = (CT * CT).sum(1)
+        idx = torch.sort(sig2).indices[cols - r:]                  # (the zero padding sorts first)
+        W = (CT[idx, :r] / torch.sqrt(sig2[idx])[:, None]).T.contiguous()
+        wv = ((T @ W) * W).sum(0)
+        order = torch.argsort(wv)
+        return wv[order], W[:, order].contiguous()
 
     @staticmethod
     def _lowrank_assemble(Y, Xn, U, wv, r, P, device):
