@@ -321,9 +321,11 @@ class LowRankRoutes:
 
     # ---- the r x r core: one-sided Jacobi on the triangular factor (csrc/jacobi.hip) ------------------------------------
     def _core_uses_jacobi(self, r):
-        """coreEigensolver="jacobi" (default) for ranks the kernel takes (<= 1024), unless an earlier call's sweeps did not converge (read
-        one call later, like every other health record of the engine: nothing synchronises inside a call)."""
-        if getattr(self, "coreEigensolver", "jacobi") != "jacobi" or os.environ.get("VMCPDE_CORE_EIGH", "jacobi") != "jacobi" or r > 1024:
+        """coreEigensolver="jacobi" (or VMCPDE_CORE_EIGH=jacobi; the default is the library's syevd, which is faster) for ranks the kernel
+        takes well (<= 512), unless an earlier call's sweeps did not converge (read one call later, like every other health record of the
+        engine: nothing synchronises inside a call)."""
+        want = os.environ.get("VMCPDE_CORE_EIGH") or getattr(self, "coreEigensolver", "library")
+        if want != "jacobi" or r > 512:        # (beyond 512 rows a workgroup's LDS holds 8 columns a side: tens of sweeps)
             return False
         st = getattr(self, "_jacobi", None)
         if st is not None and st["event"] is not None and not st["off"]:
@@ -347,7 +349,7 @@ class LowRankRoutes:
         size of a dense eigensolver's backward error) and costs two r x r products."""
         st = getattr(self, "_jacobi", None)
         if st is None:
-            st = self._jacobi = dict(n_sweeps=12, launched=0, off=False, event=None, host=torch.zeros(32, dtype=torch.int32).pin_memory())
+            st = self._jacobi = dict(n_sweeps=20, launched=0, off=False, event=None, host=torch.zeros(32, dtype=torch.int32).pin_memory())
         rows, cols = nat.C.c_int32(), nat.C.c_int32()
         nat.call("vmcpde_jacobi_shape", r, nat.C.byref(rows), nat.C.byref(cols))
         rows, cols = rows.value, cols.value

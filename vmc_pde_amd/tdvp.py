@@ -84,10 +84,12 @@ class TDVP(LowRankRoutes):
                                   #   the backward error of a dense eigensolver, the ~P - r eigenvalues below 1e-16 of the largest
                                   #   reported as exact zeros.  "auto": lowrank from LOWRANK_MIN_P parameters on when diagonalShift
                                   #   leaves S rank deficient, dense whenever the rank exceeds the cap (then not retried for a while).
-    coreEigensolver: str = "jacobi"   # the r x r symmetric eigenproblem inside the rank-revealing spectral engine: "jacobi" -- one-sided Jacobi
-                                  #   on the triangular factor R1 of L = Q1 R1 (csrc/jacobi.hip: a few launches per sweep, ~7 sweeps),
-                                  #   "library" -- torch.linalg.eigh = rocSOLVER's syevd (a chain of some hundred launches: 4.35 of the
-                                  #   engine's 6.8 ms at the headline size).  VMCPDE_CORE_EIGH=library for an A/B.
+    coreEigensolver: str = "library"  # the r x r symmetric eigenproblem inside the rank-revealing spectral engine: "library" -- torch.linalg.eigh =
+                                  #   rocSOLVER's syevd (a chain of some hundred launches: 4.35 of the engine's 6.8 ms at the headline size);
+                                  #   "jacobi" -- the own kernel, blocked one-sided Jacobi on the triangular factor R1 of L = Q1 R1
+                                  #   (csrc/jacobi.hip).  Correct and tested, but SLOWER (11 ms at the headline size: every rotation moves two
+                                  #   whole columns through the LDS for three flops per element) -- kept as a measured
+                                  #   negative result; VMCPDE_CORE_EIGH=jacobi for an A/B.
     choleskyEngine: str = "auto"  # how solver="cholesky" solves (S + diagonalShift diag(S) + floor I) u = F.  "dense": the blocked factorisation of
                                   #   the full matrix (csrc/solve.hip: 2.0 ms at P = 4213, 36 ms at 16 181).  "lowrank": S = L L^T + R by the
                                   #   pivoted Cholesky of csrc/eig.hip (r = 190 columns of 4213), the diagonal part D through the Woodbury
