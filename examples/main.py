@@ -103,24 +103,21 @@ def main():
                                       nSamplesObs=nSamplesObs, normFunction=norm_fun, timings=timings, integrals=not args.no_integrals)
         vState.set_parameters(dp)
         infos["times"].append(t)
-        print(f"t = {t:.3f}, dt = {dt:e}")
-        print("\t Timings:")
-        timings.print_timings()
-        print(f"\t Total (in main.py): {time.perf_counter() - t1}")
-        print("\t Data:")
-        print(f"\t > Solver Residual = {float(tdvpEq.solverResidual)}")
-        print(f"\t > TDVP Error = {float(tdvpEq.tdvp_error)}")
-        print(f"\t > Entropy = {float(info['entropy'])}")
-        print(f"\t > dist params = {vState.params['params']['dist_params']}")
-        print(f"\t > Means = {info['x1']}")
-        for key in info.keys():
-            infos.setdefault(key, []).append(host(info[key]))
-        if tdvpEq.ev is not None:      # spectral quantities exist on the eigh path only (not with --diagonal-shift)
+        # the run record (the `infos` keys and shapes are what the reference's plot scripts read, main.py:163-190) ...
+        for key, value in info.items():
+            infos.setdefault(key, []).append(host(value))
+        if tdvpEq.ev is not None:      # spectral quantities exist on the eigh path only (not with --solver cholesky)
             infos["ev"].append(host(tdvpEq.ev))
             infos["snr"].append(host(tdvpEq.snr))
         infos["solver_res"].append(host(tdvpEq.solverResidual))
         infos["tdvp_error"].append(host(tdvpEq.tdvp_error))
         infos["dist_params"].append(host(vState.params['params']['dist_params'].clone()))
+        # ... and one status line per step
+        sections = {k: v[-1] for k, v in timings.timing_dict.items() if v}
+        route = (tdvpEq.choleskyInfo or tdvpEq.spectralInfo or {}).get("engine", "-")
+        print(f"step {len(infos['times']):4d}  t = {t:.6f}  dt = {dt:.3e}  residual {float(tdvpEq.solverResidual):.2e}  tdvp_error {float(tdvpEq.tdvp_error):.3e}  "
+              f"entropy {float(info['entropy']):.4f}  mean {np.round(host(info['x1']).numpy(), 3).tolist()}  solve: {route}  "
+              f"[{', '.join(f'{k} {1e3 * v:.1f} ms' for k, v in sections.items())}; step {1e3 * (time.perf_counter() - t1):.1f} ms]", flush=True)
         t = t + dt
         # checkpoint (parameters, clock, sampler stream position AND the run record) -- written next to the target and renamed,
         # so a kill in the middle of the write leaves the previous checkpoint intact

@@ -201,7 +201,7 @@ int vmcpde_tdvp_moments(const double* packed, int32_t P, int32_t bordered, doubl
  * an fp32 Jacobian (jt_f32 = 1: BASELINE config 5, every stored value is represented to 2^-31 of its row maximum), 10 digit pairs --, the n_slices (n_slices + 1) / 2 slice-pair products with
  * s + t < n_slices summed exactly in int32 and combined in fp64.  Exact on integer data; on real data the dropped terms are
  * ~1e-14 (row max / row rms)^2 of |S|_F for 6 slices; stats ([dev] 1 double, may be NULL) receives the largest row max / row rms
- * (within a factor two; at most sqrt(n)), which a caller can watch (TDVP falls back to the fp64 kernel above 64).  workspace: [dev] vmcpde_gram_i8_workspace_bytes (row exponents, the
+ * (within a factor two; at most sqrt(n)), which a caller can watch (vmc_pde_amd.experimental.TDVP falls back to the fp64 kernel above a limit computed from what regularises the solve, (0.1 reg / 1.5e-14)^(1/1.3) with reg = max(svdTol, diagonalShift): ~25 at svdTol = 1e-11, 5e4 at the bench's 1e-4; sharded samples decide on the largest figure of any rank).  workspace: [dev] vmcpde_gram_i8_workspace_bytes (row exponents, the
  * n_slices int8 planes = n_slices * P_pad * N bytes, split slabs). */
 int64_t vmcpde_gram_i8_workspace_bytes(int32_t P, int64_t n_samples, int32_t n_slices, int32_t digit_bits);
 int vmcpde_gram_i8(const void* JT, int64_t ldj, int32_t jt_f32, int32_t P, int64_t n_samples, int32_t n_slices, int32_t digit_bits, const double* c,
