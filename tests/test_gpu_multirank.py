@@ -23,7 +23,9 @@ SOLVERS = (("chol", dict(diagonalShift=1e-5, solver="cholesky")), ("eigh", dict(
            ("chol-lowrank", dict(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine="lowrank")),
            ("eigh-lowrank", dict(solver="eigh", spectralEngine="lowrank")),
            # the matrix-free experiment: no S at all; moments, every 32-column panel and every S0 v are summed over the ranks
-           ("chol-matrixfree", dict(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", matrixFree=True)))
+           ("chol-matrixfree", dict(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", matrixFree=True)),
+           # the int8 S-build experiment: its heavy-tail figure is all-reduced (max) so that every rank decides alike
+           ("chol-int8", dict(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", int8Gram=True)))
 
 
 def _problem():
@@ -38,7 +40,7 @@ def _problem():
 
 
 def _two_calls(V, vs, eq, solver_kw):
-    if solver_kw.get("matrixFree"):
+    if solver_kw.get("matrixFree") or solver_kw.get("int8Gram"):
         from vmc_pde_amd.experimental import TDVP as cls        # (the matrix-free experiment is a subclass of the product class)
     else:
         cls = V.TDVP
