@@ -213,7 +213,7 @@ class TDVP(LowRankRoutes):
             JT.dtype == global_defs.tReal and not getattr(self, "int8Gram", False) and not self.f32BlockGram
         nb = (Pg + nat.GRAM_TILE - 1) // nat.GRAM_TILE
         ngroups = min(max(int(os.environ.get("VMCPDE_OVERLAP_GROUPS", "4")), 1), nb)
-        if not overlap or ngroups < 2:
+        if not overlap or ngroups < 2 or nb < 2:
             self._gram(b, JT, ldj, Pg, n, c_gram, None, b["packed"])
             with self._Section(self, "allreduce"):
                 mpi.allreduce_sum_(b["pack"])        # the one collective of the step (no-op on a single rank)
@@ -222,11 +222,19 @@ class TDVP(LowRankRoutes):
         need = nat.lib().vmcpde_gram_workspace_bytes(Pg, n)
         if b["gram_ws"] is None or b["gram_ws"].numel() * 8 < need:
             b["gram_ws"] = torch.empty(max(need // 8, 1), dtype=global_defs.tReal, device=JT.device)
-        # tile rows dealt into groups of about equal tile counts (row r holds r + 1 tiles); the last group also carries the buffer's tail
+        # tile rows dealt into groups (row r holds r + 1 tiles): about equal tile counts, or -- VMCPDE_OVERLAP_FRACTIONS="0.5,0.8" -- cut at
+        # those cumulative shares of the tiles (a small LAST group leaves little of the collective exposed behind the S-build); the last
+        # group also carries the buffer's tail
         tri = lambda r: r * (r + 1) // 2
+        cuts = [float(v) for v in os.environ.get("VMCPDE_OVERLAP_FRACTIONS", "").split(",") if v.strip()]
+        if cuts:
+            ngroups = min(len(cuts) + 1, nb)
+            cuts = sorted(min(max(v, 0.0), 1.0) for v in cuts)[:ngroups - 1]
+        else:
+            cuts = [g / ngroups for g in range(1, ngroups)]
         bounds, r = [0], 0
         for g in range(1, ngroups):
-            while r < nb and tri(r) < g * tri(nb) / ngroups:
+            while r < nb and tri(r) < cuts[g - 1] * tri(nb):
                 r += 1
             bounds.append(min(max(r, bounds[-1] + 1), nb - (ngroups - g)))
         bounds.append(nb)
@@ -617,6 +625,7 @@ class TDVP(LowRankRoutes):
                 tmpEv, tmpV = np.linalg.eigh(S.detach().cpu().numpy())        # tdvp.py:61-64 (host LAPACK)
             self.ev = torch.from_numpy(tmpEv).to(F.device)
             self.V = torch.from_numpy(tmpV).to(F.device)
+            self.spectralInfo = dict(self.spectralInfo or {}, engine="host")       # (the reference's default: LAPACK on the host)
         self.VtF = torch.empty(P, dtype=global_defs.tReal, device=F.device)
         Vc = self.V.contiguous()
         self.V = Vc
