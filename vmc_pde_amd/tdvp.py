@@ -115,8 +115,9 @@ class TDVP(LowRankRoutes):
     overlapAllreduce: bool = False  # sharded samples, steady-state Gram: the S-build runs as groups of tile rows (vmcpde_gram_rows) and every
                                   # finished group -- one contiguous piece of the packed buffer -- is all-reduced on a side stream while
                                   # the next is being formed; finalize waits for the last.  Same bits as the single call.  Off by default:
-                                  # it trades ~3 partial rounds of the Gram's schedule for the hidden collective and has never met more
-                                  # than one GPU (VMCPDE_OVERLAP_ALLREDUCE=1 / VMCPDE_OVERLAP_GROUPS=G, default 4, for an A/B on a node)
+                                  # it trades a partly filled round of the Gram's schedule per group for the hidden collective and has never met more
+                                  # than one GPU (VMCPDE_OVERLAP_ALLREDUCE=1; VMCPDE_OVERLAP_FRACTIONS="0.8" -- the default: two groups cut at 80 % of the tiles --
+                                  # or VMCPDE_OVERLAP_GROUPS=G equal groups, for an A/B on a node)
     f32BlockGram: bool = False    # with an fp32 Jacobian: fp32 MFMA sums over blocks of <= 128 samples, fp64 across blocks (2x MFMA rate)
     frozenParameters: object = None   # flat parameter indices held fixed: their rows / columns of S and entries of F are zeroed, so
                                   # both solvers return a zero update for them (the pseudo-inverse drops the zero modes, tdvp.py:82;
@@ -212,7 +213,7 @@ class TDVP(LowRankRoutes):
         overlap = (self.overlapAllreduce or os.environ.get("VMCPDE_OVERLAP_ALLREDUCE", "0") == "1") and c_gram is None and \
             JT.dtype == global_defs.tReal and not getattr(self, "int8Gram", False) and not self.f32BlockGram
         nb = (Pg + nat.GRAM_TILE - 1) // nat.GRAM_TILE
-        ngroups = min(max(int(os.environ.get("VMCPDE_OVERLAP_GROUPS", "4")), 1), nb)
+        ngroups = min(max(int(os.environ.get("VMCPDE_OVERLAP_GROUPS", "2")), 1), nb)
         if not overlap or ngroups < 2 or nb < 2:
             self._gram(b, JT, ldj, Pg, n, c_gram, None, b["packed"])
             with self._Section(self, "allreduce"):
@@ -226,7 +227,10 @@ class TDVP(LowRankRoutes):
         # those cumulative shares of the tiles (a small LAST group leaves little of the collective exposed behind the S-build); the last
         # group also carries the buffer's tail
         tri = lambda r: r * (r + 1) // 2
-        cuts = [float(v) for v in os.environ.get("VMCPDE_OVERLAP_FRACTIONS", "").split(",") if v.strip()]
+        # (default: ONE cut at 0.8 -- measured on one GPU at the C4 shard, where nothing is hidden: the Gram 8.88 ms as one launch, 9.06
+        # with this cut, 9.24 with cuts at 0.5 / 0.8, 9.59 with four equal groups)
+        frac_env = os.environ.get("VMCPDE_OVERLAP_FRACTIONS", "" if "VMCPDE_OVERLAP_GROUPS" in os.environ else "0.8")
+        cuts = [float(v) for v in frac_env.split(",") if v.strip()]
         if cuts:
             ngroups = min(len(cuts) + 1, nb)
             cuts = sorted(min(max(v, 0.0), 1.0) for v in cuts)[:ngroups - 1]
