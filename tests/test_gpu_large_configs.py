@@ -81,6 +81,25 @@ def test_cholesky_side_stream_branch_on_small_matrices(P, monkeypatch):
     assert torch.equal(Ap2[:P, :P].tril(), Ap[:P, :P].tril())       # fused and forked launches do the same arithmetic
 
 
+@pytest.mark.parametrize("P,W,head", [(1000, 2, 4), (1000, 3, 5), (1500, 4, 6), (2049, 2, 1), (2049, 2, 40)])
+def test_cholesky_super_panels_over_the_head_of_the_matrix_only(P, W, head, monkeypatch):
+    # VMCPDE_CHOL_SUPER_HEAD: super-panels of W block columns over the first `head` block columns (the last one clipped at the head's
+    # end), single panels behind -- same factor as the one-level schedule
+    rng = np.random.default_rng(P + W + head)
+    Q, _ = np.linalg.qr(rng.standard_normal((P, P)))
+    Amat = (Q * np.logspace(0, -4, P)) @ Q.T
+    monkeypatch.setenv("VMCPDE_CHOL_SUPER", str(W))
+    monkeypatch.setenv("VMCPDE_CHOL_SUPER_HEAD", str(head))
+    Ap, Pp, ws, need, info = _factor(torch.as_tensor(Amat).to(DEV), P)
+    assert int(info.item()) == 0
+    Lref = np.linalg.cholesky(Amat)
+    assert np.abs(np.tril(Ap.cpu().numpy()[:P, :P]) - Lref).max() < 1e-10 * np.abs(Lref).max()
+    monkeypatch.setenv("VMCPDE_CHOL_SUPER", "1")
+    monkeypatch.delenv("VMCPDE_CHOL_SUPER_HEAD")
+    Ap1, *_ = _factor(torch.as_tensor(Amat).to(DEV), P)
+    assert float((Ap1[:P, :P].tril() - Ap[:P, :P].tril()).abs().max()) < 1e-12 * np.abs(Lref).max()
+
+
 @pytest.mark.parametrize("P,W", [(300, 2), (1000, 2), (1000, 3), (1000, 8), (1500, 4), (2049, 16)])
 def test_cholesky_super_panels_on_small_matrices(P, W, monkeypatch):
     # the two-level schedule large matrices use (super-panels of W block columns: K = 128 W trailing updates, chunked strips,

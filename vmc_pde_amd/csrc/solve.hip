@@ -1253,12 +1253,16 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
     static_assert(2 * TILE_DMA_LDS_BYTES <= ((size_t)NB * DP + 4 * SB * 17 + 2 * SB) * sizeof(double), "two tiles per workgroup of the update launch");
     int W = env_int("VMCPDE_CHOL_SUPER", 0);
     if (W <= 0) W = (nb >= SUPER_MIN_BLOCKS) ? SUPER_WIDTH : 1;
+    // VMCPDE_CHOL_SUPER_HEAD = h (> 0): super-panels only over the first h block columns -- where the trailing matrix is large and a
+    // K = 128 update is bound by re-reading and re-writing it --, single panels behind (A/B knob)
+    int head = env_int("VMCPDE_CHOL_SUPER_HEAD", 0);
+    if (head <= 0 || head > nb) head = nb;
     // Lookahead at super-panel level (two-level schedule only): the K = 128 W update that closes super-panel s is split.  Part (a), the
     // block columns of super-panel s + 1, stays on the caller's stream together with the next diagonal block; part (b), everything to
     // the right of s + 1, goes to a side stream whose queue is masked to 7 of every 8 CUs, so the latency chain of super-panel s + 1
     // (diagonal blocks, strips, its K = 128 tiles) always finds free CUs and runs UNDER (b) instead of behind it.  (b) of super-panel s
     // must be complete before the last panel of s + 1 touches the first block column of s + 2 (mode-1 strips) and before (b) of s + 1.
-    bool overlap = (W > 1) && env_int("VMCPDE_CHOL_OVERLAP", 0) != 0;
+    bool overlap = (W > 1) && head == nb && env_int("VMCPDE_CHOL_OVERLAP", 0) != 0;
     hipStream_t bulk = nullptr;
     if (overlap) {
       DeviceCtxLock lock;
@@ -1275,7 +1279,9 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
     for (int k = 0; k + 1 < nb; ++k) {
       const int k0 = k * NB;
       const int nrem = nb - (k + 1);                                  // block rows below the panel
-      const int s0 = (k / W) * W, s1 = (s0 + W < nb) ? (s0 + W) : nb; // the super-panel of k: block columns [s0, s1)
+      // the super-panel of k: block columns [s0, s1)
+      const int s0 = (k < head) ? (k / W) * W : k;
+      const int s1 = (k < head) ? ((s0 + W < head) ? (s0 + W) : head) : k + 1;
       const bool last_of_super = (k + 1 == s1);
       const int kc0 = last_of_super ? s0 * NB : k0;                   // operand columns of this panel's update
       const int nchunk = last_of_super ? (k + 1 - s0) : 1;
