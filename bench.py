@@ -368,7 +368,9 @@ def cpu_baseline(theta_cpu, inds_up, inds_down, workload="C2"):
             "fair_variant": {"value": 1.0 / fair, "unit": "TDVP steps/s",
                              "what": "same port without the reference's redundant work (one centred Gram GEMM, no SExp, no EO@V)"},
             "note": "an eager torch.func port of the reference's algorithm, not XLA-jitted JAX-CPU (jax is not installable here): "
-                    "a reported baseline, not a comparison with the reference's own runtime"}
+                    "a reported baseline, not a comparison with the reference's own runtime",
+            "checked_against": "--cpu-baseline full: ONE step of the same port at the real N = 65 536 took 47.97 s on 16 cores where this "
+                               "extrapolation said 46.9 s (profiles/r04_run1_bench_cpu_full.json)" if workload == "C2" else None}
 
 
 def main():
