@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """The reference driver loop (vmc_fluids/main.py:60-210, plumbing only: no plots) on vmc_pde_amd.
 
-    python examples/main.py [--mode mwe|diffusion|harmonicOsc|harmonicOsc_diff] [--t-end 0.05] [--samples 10000]
+    python examples/main.py [--mode mwe|diffusion|harmonicOsc|harmonicOsc_diff] [--t-end 0.05] [--samples 10000] [--gpus N]
+
+`--gpus N` (N > 1): one process per GPU (the reference: `mpirun -n N python main.py`, mpi_wrapper.py:9-11) -- this process starts the N ranks
+itself (vmc_pde_amd/launch.py) unless a launcher already did (torchrun: RANK / WORLD_SIZE in the environment); the samples are sharded, the
+packed (S, F) buffer is all-reduced once per right-hand side over RCCL, rank 0 prints and writes the records.
 
 Same objects, same call sequence, same printed diagnostics and `infos` keys as the reference; arrays are fp64 torch tensors
 on the GPU.  The `infos` record is written to <wdir>/infos.npz (`--infos infos.hdf5`: the reference's HDF5 file, where h5py exists), and -- what the reference lacks -- the parameters are
@@ -53,7 +57,23 @@ def main():
     ap.add_argument("--no-integrals", action="store_true",
                     help="skip the three small-ball integrals (tdvp.py:152-162; the reference evaluates them on every call and its "
                          "published records hold them, so they are on by default)")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node the Monte-Carlo samples are sharded over (backend nccl = RCCL; "
+                                                        "VMCPDE_DIST_BACKEND=gloo rehearses it with all ranks on one GPU)")
     args = ap.parse_args()
+    from vmc_pde_amd import launch
+    if args.gpus > 1 and not launch.under_launcher():     # be the launcher: N fresh rank processes; this one never touches the GPU
+        rc, _ = launch.run_ranks([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], args.gpus, relay=lambda line: print(line, end="", flush=True))
+        sys.exit(rc)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+        torch.cuda.set_device(dev)
+        backend = os.environ.get("VMCPDE_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    if rank != 0:                                           # one narrator: rank 0 prints and writes the records
+        import builtins
+        builtins.print = lambda *a, **k: None
     m = mode_dict[args.mode]
     dim, offset = m["dim"], m["offset"]
     initKey = 1
@@ -122,13 +142,19 @@ def main():
         # checkpoint (parameters, clock, sampler stream position AND the run record) -- written next to the target and renamed,
         # so a kill in the middle of the write leaves the previous checkpoint intact
         tdvpEq.check("before the checkpoint")      # a failed solve must not reach the checkpoint (the stepper checked already)
-        tmp = ckpt + ".tmp"
-        torch.save({"theta": vState.get_parameters().cpu(), "t": t, "dt": myStepper.dt, "sampler_calls": smp._calls, "infos": infos,
-                    "tdvp": tdvpEq.state_dict()}, tmp)
-        os.replace(tmp, ckpt)
-        if len(infos["times"]) % args.save_every == 0:
-            util.store_infos(wdir, infos, args.infos)
-    print("wrote", util.store_infos(wdir, infos, args.infos))                                                                              # main.py:209
+        state = tdvpEq.state_dict()                # (every rank: it waits for this rank's asynchronous records)
+        if rank == 0:
+            tmp = ckpt + ".tmp"
+            torch.save({"theta": vState.get_parameters().cpu(), "t": t, "dt": myStepper.dt, "sampler_calls": smp._calls, "infos": infos,
+                        "tdvp": state}, tmp)
+            os.replace(tmp, ckpt)
+            if len(infos["times"]) % args.save_every == 0:
+                util.store_infos(wdir, infos, args.infos)
+    if rank == 0:
+        print("wrote", util.store_infos(wdir, infos, args.infos))                                                                          # main.py:209
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -213,3 +213,36 @@ def test_bench_starts_its_own_ranks_and_proves_who_took_part():
     assert two["one_gpu_same_samples"]["ms_per_step_from_stages"] > 0
     # weak scaling: `value` counts 65 536-sample steps over all ranks
     assert abs(two["value"] - 2 / (two["ms_per_step"] * 1e-3) * 2048 / 65536) < 1e-9 * two["value"]
+
+
+def test_driver_loop_on_two_ranks_matches_one_rank(tmp_path):
+    """examples/main.py --gpus 2 (the reference: `mpirun -n 2 python main.py`): the driver starts its own two ranks, shards the samples, reduces
+    (S, F) once per right-hand side, rank 0 writes the records -- and the parameters after nine Heun steps are those of the one-rank run on the
+    same global batches.  Over gloo with both ranks on the one GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    out = {}
+    for n in (1, 2):
+        wdir = os.path.join(str(tmp_path), f"ranks{n}") + "/"
+        cmd = [sys.executable, os.path.join(root, "examples", "main.py"), "--mode", "mwe", "--samples", "2048", "--t-end", "3e-6", "--wdir", wdir,
+               "--gpus", str(n)]
+        res = subprocess.run(cmd, env=dict(env, VMCPDE_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        assert res.stdout.count("Number of Model parameters: 37") == 1          # one narrator
+        out[n] = (torch.load(os.path.join(wdir, "checkpoint.pt"), weights_only=False), np.load(os.path.join(wdir, "infos.npz")), res.stdout)
+    (c1, r1, _), (c2, r2, _) = out[1], out[2]
+    assert c1["t"] == c2["t"] and c1["sampler_calls"] == c2["sampler_calls"] and len(r1["times"]) == len(r2["times"]) >= 8
+    import vmc_pde_amd as V
+    th0 = None
+    d12 = float(torch.linalg.norm(c2["theta"] - c1["theta"]))
+    # the distance travelled: from the initial parameters (the same construction as the driver's) to the end of the one-rank run
+    smp = V.Sampler(dim=2, numChains=30, name="Gauss", mcmc_info={"offset": np.zeros(2), "bound": 0.25})
+    vs = V.VarState(smp, 2, 1, 4, network_args={"intmediate": (1,), "offset": np.zeros(2), "latentSpaceName": "Gauss", "dim": 2})
+    th0 = vs.get_parameters().cpu()
+    travelled = float(torch.linalg.norm(c1["theta"] - th0))
+    assert travelled > 0 and d12 < 1e-5 * travelled, (d12, travelled)
+    # the two-rank record is rank 0's shard (1024 of the 2048 samples): same law, different estimate -- and the spectrum is the global S's
+    assert np.allclose(r1["ev"][-1], r2["ev"][-1], rtol=1e-9, atol=1e-12 * r1["ev"][-1].max())
+    assert abs(r1["entropy"][-1] - r2["entropy"][-1]) < 0.2
