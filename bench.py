@@ -589,10 +589,18 @@ def main():
             # when it follows the S-build, only its exposed tail when it is interleaved with it (--overlap-allreduce)
             line["allreduce_in_step"] = dict(tdvp.allreduceInfo or {}, exposed_ms_max_rank=ar, alone_ms=rccl["allreduce_alone_ms"])
             line["one_gpu_same_samples"] = {"ms_per_step_from_stages": world * (sf + gr) + rep, "this_run_ms_per_step": elapsed / args.steps * 1e3,
-                                            "speedup": (world * (sf + gr) + rep) / (elapsed / args.steps * 1e3),
                                             "allreduce_bracket_ms_max_rank": ar,
                                             "note": "N x (sample+flow + gram) + replicated of the slowest rank's brackets; the measured N = 1 "
                                                     "line of the same workload is `python bench.py --workload " + args.workload + "`"}
+            # the committed N = 1 record of this workload (another box, another day): the figure a reader of this line divides by (the driver computes efficiencies itself from its own N = 1 run)
+            rec = os.path.join(ROOT, "profiles", "r04_run1_bench.json" if args.workload == "C2" else f"r04_run1_bench_{args.workload}.json")
+            if os.path.exists(rec) and args.jacobian == "f64" and args.solver == "cholesky":
+                try:
+                    one = json.loads(next(l for l in open(rec) if l.startswith("{")))
+                    if one["config"]["n_samp_per_gpu"] == args.samples:
+                        line["n1_record"] = {"file": os.path.relpath(rec, ROOT), "value": one["value"], "ms_per_step": one["ms_per_step"]}
+                except Exception:
+                    pass
         if world == 1 and not args.no_beside and args.solver == "cholesky" and args.jacobian == "f64":
             # AFTER the timed region and not part of `value`: the opt-in experiments on the same problem and the same box, so that the
             # numbers quoted beside the headline come from this run as well
