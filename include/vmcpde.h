@@ -270,7 +270,7 @@ int vmcpde_pinv_coeffs(const double* ev, const double* VtF, const double* snr, i
 /* ---- tdvp.py:57-64 (eigh of S), the dependent chains of the rank-revealing decomposition (csrc/eig.hip) --------------------------
  * The reference diagonalises the full P x P matrix.  S = <J^T J> of these models is numerically rank deficient (238 of 4213
  * eigenvalues above 1e-16 of the largest at the headline size), and a full decomposition [null-space basis | Ritz vectors] follows
- * from a pivoted Cholesky factor of S and a Householder QR of that factor in O(P r^2) (vmc_pde_amd/tdvp.py makes the GEMMs).
+ * from a pivoted Cholesky factor of S and a Householder QR of that factor in O(P r^2) (vmc_pde_amd/lowrank.py makes the GEMMs).
  *
  * vmcpde_pivoted_cholesky: steps [first_step, first_step + n_steps) of S = L L^T + R with diagonal pivoting (dpstrf's algorithm,
  * unblocked, no row interchanges: rows keep their place, L[piv[j]][k] = 0 for j < k).  S: [dev] symmetric, full storage, pitch lds
@@ -303,7 +303,7 @@ int vmcpde_pivoted_cholesky_blocked(const double* S, int64_t lds, int32_t P, dou
  * many candidates survive a block (~13 of 32 chosen by the diagonal alone, most of a hinted block) and with it the number of dependent
  * block steps.  The list is copied into the workspace (piv may be reused at once) and stays armed until replaced; piv == NULL disarms. */
 int vmcpde_lowrank_hint(const int32_t* piv, const int32_t* state, int32_t P, void* workspace, int64_t workspace_bytes, void* stream);
-/* ---- EXPERIMENT: the same factorisation without an assembled S (matrix-free TDVP step, vmc_pde_amd/tdvp.py `matrixFree`) -------
+/* ---- EXPERIMENT: the same factorisation without an assembled S (matrix-free TDVP step, vmc_pde_amd/experimental/matrix_free.py) -------
  * S = J^T J / N - m m^T enters the pivoted factorisation only through its diagonal and the 32 columns a block step pivots on, so the
  * Jacobian is read once per block step instead of N P^2 flop:
  *   vmcpde_lowrank_begin(diag)        start from the diagonal of S ([dev] P); same workspace / state as the blocked factorisation

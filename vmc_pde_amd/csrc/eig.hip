@@ -8,7 +8,7 @@
 //      r dependent steps, each one launch: column k = (S[:, p] - L[:, :k] L[p, :k]^T) / sqrt(d_p), d -= column^2, arg max of d.
 //   2. Householder QR of the P x r factor (r dependent steps, each one launch: one workgroup per trailing column) -- column-wise
 //      backward stable whatever the grading of L (its columns span 8 decades), and its compact WY form gives BOTH an orthonormal
-//      basis Q1 of range(L) and one of the complement, Q2, as plain GEMMs (host side: vmc_pde_amd/tdvp.py).
+//      basis Q1 of range(L) and one of the complement, Q2, as plain GEMMs (host side: vmc_pde_amd/lowrank.py).
 //   3. Rayleigh-Ritz on range(L): eigh of the r x r matrix Q1^T S Q1, Ritz vectors Q1 W; V = [Q2 | Q1 W] with eigenvalue 0 for Q2.
 //
 // This file holds 1 and 2 (the dependent chains); the GEMMs, the triangular solve and the r x r decomposition of 3 are library
