@@ -346,6 +346,16 @@ int vmcpde_householder_rows(double* LT, int64_t ldl, int32_t P, int32_t r, doubl
  * padded (vmcpde_jacobi_shape gives the padded sizes: rows to a multiple of 64, columns to a multiple of the columns a workgroup sweeps).
  * n_sweeps (<= 30) sweeps are launched; launches behind a sweep that rotated nothing return at once.  counters: [dev] n_sweeps + 1 int32,
  * counters[s] = rotations of sweep s -- converged iff some counters[s] == 0 (the caller may read it later; nothing synchronises). */
+/* ABI 5: the Woodbury application of the low-rank regularised solve, M^-1 v for M = D + L L^T (D > 0 diagonal, L = LT^T of rank r):
+ *   M^-1 v = y - D^-1 L G^-1 L^T y,  y = D^-1 v,  G = I + L^T D^-1 L  (r x r, factored by the caller: vmcpde_cholesky / vmcpde_chol_solve).
+ * project: y = v / D and t1 = L^T y, with v = F (u, Su NULL) or the residual F - Su - D.u of the full system (S0 + D) u = F at u
+ *          (Su = S0 u from vmcpde_gemv) -- the right-hand side of a refinement step;   y: [dev] P,  t1: [dev] r.
+ * combine: out = (u ? u : 0) + y - D^-1 L t2  with t2 = G^-1 t1;  out may alias u.  Replaces two library gemv and six elementwise
+ *          launches per application (tdvp.py:91 is one matrix-vector product; this is its counterpart on the factor). */
+int vmcpde_woodbury_project(const double* LT, int64_t ldl, int32_t P, int32_t r, const double* D, const double* F, const double* Su,
+                            const double* u, double* y, double* t1, void* stream);
+int vmcpde_woodbury_combine(const double* LT, int64_t ldl, int32_t P, int32_t r, const double* D, const double* y, const double* t2,
+                            const double* u, double* out, void* stream);
 int vmcpde_jacobi_shape(int32_t r, int32_t* rows_pad, int32_t* cols_pad);
 int vmcpde_jacobi_columns(double* CT, int32_t r, int32_t n_sweeps, int32_t* counters, void* stream);
 

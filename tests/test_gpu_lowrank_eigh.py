@@ -726,3 +726,43 @@ def test_jacobi_core_matches_the_library_core_at_headline_size(headline_net):
     assert abs(res_j - res_l) < 1e-10 and abs(err_j - err_l) < 1e-10
     st = tj._jacobi
     assert not st["off"] and 4 <= st["n_sweeps"] <= 14, st            # the plan follows what the first call needed
+
+
+@pytest.mark.parametrize("P,r,ldl", [(4213, 256, 4224), (300, 7, 320), (65, 64, 128), (16181, 384, 16192)])
+def test_woodbury_application_against_numpy(P, r, ldl):
+    """vmcpde_woodbury_project / _combine: M^-1 v for M = D + L L^T through G = I + L^T D^-1 L (factored and solved by the library's own small
+    Cholesky), for v = F and for v = the residual F - S u - D u of a refinement step -- against numpy's dense solve of M."""
+    from vmc_pde_amd import _native as nat
+    rng = np.random.default_rng(P + r)
+    L = rng.standard_normal((P, r)) * np.logspace(0, -3, r)[None, :]
+    L[:, r - 2:] = 0.0                                                 # (columns past the rank are zero in the static plan)
+    D = rng.uniform(1e-3, 1.0, P)
+    F, u0, Su = rng.standard_normal(P), rng.standard_normal(P), rng.standard_normal(P)
+    LT = torch.zeros((r, ldl), dtype=torch.float64, device="cuda")
+    LT[:, :P] = torch.from_numpy(L.T.copy())
+    Dd, Fd, ud, Sud = (torch.from_numpy(v).cuda() for v in (D, F, u0, Su))
+    rpad = (r + 127) // 128 * 128
+    G = torch.zeros((rpad, rpad), dtype=torch.float64, device="cuda")
+    G[:r, :r] = torch.from_numpy(np.eye(r) + L.T @ (L / D[:, None]))
+    G[r:, r:] = torch.eye(rpad - r, dtype=torch.float64, device="cuda")
+    need = nat.lib().vmcpde_chol_workspace_bytes(rpad)
+    gws = torch.empty(need // 8, dtype=torch.float64, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    nat.call("vmcpde_cholesky", nat.ptr(G), rpad, rpad, nat.ptr(info), nat.ptr(gws), need, nat.stream())
+    y = torch.empty(P, dtype=torch.float64, device="cuda")
+    t1 = torch.zeros(rpad, dtype=torch.float64, device="cuda")
+    t2 = torch.empty(rpad, dtype=torch.float64, device="cuda")
+    out = torch.empty(P, dtype=torch.float64, device="cuda")
+    M = np.diag(D) + L @ L.T
+    for u_in, v in ((None, F), (ud, F - Su - D * u0)):
+        nat.call("vmcpde_woodbury_project", nat.ptr(LT), ldl, P, r, nat.ptr(Dd), nat.ptr(Fd), nat.ptr(Sud) if u_in is not None else None, nat.ptr(u_in),
+                 nat.ptr(y), nat.ptr(t1), nat.stream())
+        assert np.allclose(y.cpu().numpy(), v / D, rtol=1e-14, atol=0) and np.allclose(t1[:r].cpu().numpy(), L.T @ (v / D), rtol=1e-11, atol=1e-12)
+        nat.call("vmcpde_chol_solve", nat.ptr(G), rpad, rpad, nat.ptr(t1), nat.ptr(t2), nat.ptr(gws), need, nat.stream())
+        target = out if u_in is None else ud.clone()
+        nat.call("vmcpde_woodbury_combine", nat.ptr(LT), ldl, P, r, nat.ptr(Dd), nat.ptr(y), nat.ptr(t2), nat.ptr(target) if u_in is not None else None,
+                 nat.ptr(target), nat.stream())                        # (in place over u for the refinement form)
+        ref = np.linalg.solve(M, v) + (u0 if u_in is not None else 0.0)
+        assert np.linalg.norm(target.cpu().numpy() - ref) < 1e-9 * np.linalg.norm(ref)
+    with pytest.raises(nat.VmcpdeError, match="come together"):
+        nat.call("vmcpde_woodbury_project", nat.ptr(LT), ldl, P, r, nat.ptr(Dd), nat.ptr(Fd), None, nat.ptr(ud), nat.ptr(y), nat.ptr(t1), nat.stream())

@@ -108,6 +108,8 @@ _PROTOS = {
     "vmcpde_gram_columns": (_int, [_vp, _i64, _i32, _i64, _vp, _vp, _f64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "vmcpde_row_moments_sq": (_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vmcpde_householder_rows": (_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "vmcpde_woodbury_project": (_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vmcpde_woodbury_combine": (_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vmcpde_jacobi_shape": (_int, [_i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "vmcpde_jacobi_columns": (_int, [_vp, _i32, _i32, _vp, _vp]),
 }

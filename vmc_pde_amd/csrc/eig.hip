@@ -1303,3 +1303,69 @@ extern "C" int vmcpde_jt_matvec(const double* JT, int64_t ldj, int32_t P, int64_
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+// ---- the Woodbury application of the low-rank regularised solve (tdvp.py:73-94 with the factor of csrc/eig.hip) ---------------------------
+// M = D + L L^T,  M^-1 v = y - D^-1 L G^-1 L^T y  with  y = D^-1 v  and  G = I + L^T D^-1 L (factored by the caller).
+namespace {
+
+// t1[k] = sum_p LT[k][p] y[p] with y = v / D and v = F (u == nullptr) or the residual F - Su - D u of the full system at u; workgroup 0
+// also writes y.  One workgroup per column of L (row of LT: contiguous).
+__global__ __launch_bounds__(256) void woodbury_project_kernel(const double* __restrict__ LT, int64_t ldl, int P, const double* __restrict__ D,
+                                                               const double* __restrict__ F, const double* __restrict__ Su,
+                                                               const double* __restrict__ u, double* __restrict__ y, double* __restrict__ t1) {
+  __shared__ double part[4];
+  const int k = (int)blockIdx.x, t = (int)threadIdx.x;
+  const double* __restrict__ row = LT + (int64_t)k * ldl;
+  double s = 0.0;
+  for (int p = t; p < P; p += 256) {
+    const double d = D[p];
+    const double v = u ? (F[p] - Su[p] - d * u[p]) : F[p];
+    const double yy = v / d;
+    if (k == 0) y[p] = yy;
+    s = fma(row[p], yy, s);
+  }
+  s = vmcpde::wave_sum(s);
+  if ((t & 63) == 0) part[t >> 6] = s;
+  __syncthreads();
+  if (t == 0) t1[k] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// out[p] = (u ? u[p] : 0) + y[p] - (sum_k LT[k][p] t2[k]) / D[p]: one thread per parameter, the r rows of LT read coalesced
+__global__ __launch_bounds__(64) void woodbury_combine_kernel(const double* __restrict__ LT, int64_t ldl, int P, int r, const double* __restrict__ D,
+                                                              const double* __restrict__ y, const double* __restrict__ t2,
+                                                              const double* __restrict__ u, double* __restrict__ out) {
+  const int p = (int)blockIdx.x * 64 + (int)threadIdx.x;
+  if (p >= P) return;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int k = 0;
+  for (; k + 4 <= r; k += 4) {
+    a0 = fma(LT[(int64_t)k * ldl + p], t2[k], a0);
+    a1 = fma(LT[(int64_t)(k + 1) * ldl + p], t2[k + 1], a1);
+    a2 = fma(LT[(int64_t)(k + 2) * ldl + p], t2[k + 2], a2);
+    a3 = fma(LT[(int64_t)(k + 3) * ldl + p], t2[k + 3], a3);
+  }
+  for (; k < r; ++k) a0 = fma(LT[(int64_t)k * ldl + p], t2[k], a0);
+  const double corr = ((a0 + a1) + (a2 + a3)) / D[p];
+  out[p] = (u ? u[p] : 0.0) + y[p] - corr;
+}
+
+}  // namespace
+
+extern "C" int vmcpde_woodbury_project(const double* LT, int64_t ldl, int32_t P, int32_t r, const double* D, const double* F, const double* Su,
+                                       const double* u, double* y, double* t1, void* stream) {
+  VMC_REQUIRE(LT && D && F && y && t1, "vmcpde_woodbury_project: null argument");
+  VMC_REQUIRE((u == nullptr) == (Su == nullptr), "vmcpde_woodbury_project: u and Su come together");
+  VMC_REQUIRE(P >= 1 && r >= 1 && ldl >= P, "vmcpde_woodbury_project: bad shape");
+  hipLaunchKernelGGL(woodbury_project_kernel, dim3((unsigned)r), dim3(256), 0, (hipStream_t)stream, LT, ldl, P, D, F, Su, u, y, t1);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vmcpde_woodbury_combine(const double* LT, int64_t ldl, int32_t P, int32_t r, const double* D, const double* y, const double* t2,
+                                       const double* u, double* out, void* stream) {
+  VMC_REQUIRE(LT && D && y && t2 && out, "vmcpde_woodbury_combine: null argument");
+  VMC_REQUIRE(P >= 1 && r >= 1 && ldl >= P, "vmcpde_woodbury_combine: bad shape");
+  hipLaunchKernelGGL(woodbury_combine_kernel, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, (hipStream_t)stream, LT, ldl, P, r, D, y, t2, u, out);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -247,7 +247,6 @@ class LowRankRoutes:
         if st["event"] is None:
             st["event"] = torch.cuda.Event()
         st["event"].record()
-        LTr = w["LT"][:rmax, :P]
         # G = I + L^T D^-1 L, contraction length P, result only rmax x rmax: as ONE library GEMM the 256 x 256 x 4213 shape runs on 8
         # workgroups (0.23 ms; the engine's own weighted syrk path 0.17 ms) -- as a batched GEMM over column chunks of 128 (the zero pad
         # of the rows of LT included) it fills the chip, and the chunk sums are added up
@@ -263,17 +262,25 @@ class LowRankRoutes:
         G.diagonal().add_(1.0)
         nat.call("vmcpde_cholesky", nat.ptr(G), rmax, rmax, nat.ptr(w["G_info"]), nat.ptr(gws), need, nat.stream())
 
-        def minv(v):
-            y = v / D
-            t1 = LTr @ y
-            nat.call("vmcpde_chol_solve", nat.ptr(G), rmax, rmax, nat.ptr(t1), nat.ptr(t2), nat.ptr(gws), need, nat.stream())
-            return torch.addcdiv(y, LTr.T @ t2, D, value=-1.0)
+        # u = M^-1 F, then u <- u + M^-1 (F - (S0 + D) u) against the TRUE matrix: per application two own launches around the r x r
+        # substitution (vmcpde_woodbury_project / _combine; the residual is formed inside the first)
+        if w.get("wb_y") is None or w["wb_y"].numel() != P or w["wb_t1"].numel() != rmax:
+            w["wb_y"] = torch.empty(P, dtype=global_defs.tReal, device=device)
+            w["wb_t1"] = torch.empty(rmax, dtype=global_defs.tReal, device=device)
+        yb, t1 = w["wb_y"], w["wb_t1"]
+        Dc, Fc = D.contiguous(), F.contiguous()
 
-        u = minv(F)
+        def apply(u_in):
+            nat.call("vmcpde_woodbury_project", nat.ptr(w["LT"]), ldl, P, rmax, nat.ptr(Dc), nat.ptr(Fc), nat.ptr(Su) if u_in is not None else None,
+                     nat.ptr(u_in), nat.ptr(yb), nat.ptr(t1), nat.stream())
+            nat.call("vmcpde_chol_solve", nat.ptr(G), rmax, rmax, nat.ptr(t1), nat.ptr(t2), nat.ptr(gws), need, nat.stream())
+            nat.call("vmcpde_woodbury_combine", nat.ptr(w["LT"]), ldl, P, rmax, nat.ptr(Dc), nat.ptr(yb), nat.ptr(t2), nat.ptr(u_in), nat.ptr(update),
+                     nat.stream())
+
+        apply(None)
         for _ in range(st["nref"]):
-            nat.call("vmcpde_gemv", nat.ptr(b["S"]), b["Ppad"], P, P, 0, nat.ptr(u), nat.ptr(Su), nat.stream())
-            u = u + minv(F - Su - D * u)
-        update.copy_(u)
+            nat.call("vmcpde_gemv", nat.ptr(b["S"]), b["Ppad"], P, P, 0, nat.ptr(update), nat.ptr(Su), nat.stream())
+            apply(update)
         b["info"].zero_()
         self.choleskyInfo = dict(engine="lowrank", mode="static", rmax=rmax, block_steps=st["nsteps"], refinements=st["nref"],
                                  planned_rank=st["rank"])
