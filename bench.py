@@ -404,8 +404,11 @@ def main():
     if args.gpus > 1 and not launch.under_launcher():
         # not under torch.distributed.run: be the launcher.  N fresh interpreters, one per GPU; this process makes no GPU call before or
         # after, relays rank 0's record and fails if any rank fails (mpi_wrapper.py:9-11: the reference gets its ranks from mpirun)
-        rc, out = launch.run_ranks([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], args.gpus, timeout=args.launch_timeout,
-                                   relay=lambda line: print(line, end="", flush=True))
+        try:
+            rc, out = launch.run_ranks([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], args.gpus, timeout=args.launch_timeout,
+                                       relay=lambda line: print(line, end="", flush=True))
+        except launch.LauncherSignalled as ex:              # (SIGTERM / SIGINT to the launcher: the ranks have been stopped)
+            sys.exit(128 + ex.signum)
         if rc == 0 and not any(l.lstrip().startswith("{") for l in out.splitlines()):
             print("bench: the ranks exited cleanly but rank 0 printed no record", file=sys.stderr)
             rc = 1
@@ -465,11 +468,21 @@ def main():
         tdvp(theta, 0.0, **kwargs)
     barrier()
     stage_events.clear()
+    # the host only enqueues (it runs ~a step ahead of the device); a generation-2 collection of the interpreter's garbage collector in
+    # the middle of the timed steps (tens of ms with torch's object graph) would starve the device of launches: collect now, keep the
+    # collector out of the timed region, restore it afterwards.  No work of the step is skipped.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         update, _ = tdvp(theta, 0.0, **kwargs)
+    t_enqueued = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    gc.unfreeze()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -484,6 +497,16 @@ def main():
     mine = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in stage_events.items()}
     gram_ms = mine.get("gram", float("nan"))
     order = ["sample+flow", "gram", "allreduce", "replicated"]
+    # every timed step on its own, first bracket's start to last bracket's end on the launch stream: `ms_per_step` is the mean the contract
+    # asks for; median and maximum next to it show whether one stalled step (a busy host, a neighbour on the node) is inside that mean
+    per_step = None
+    if all(len(stage_events.get(k, [])) == args.steps for k in ("sample+flow", "replicated")):
+        spans = np.asarray([stage_events["sample+flow"][i][0].elapsed_time(stage_events["replicated"][i][1]) for i in range(args.steps)])
+        per_step = {"median": float(np.median(spans)), "min": float(spans.min()), "max": float(spans.max()),
+                    "n_over_1p25_median": int((spans > 1.25 * np.median(spans)).sum()),
+                    "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
+                    "what": "HIP-event span of each timed step on the launch stream (start of sampling to end of the solve's diagnostics); "
+                            "host_enqueue = wall time the host needed to enqueue a step (it must stay below ms_per_step to keep the device fed)"}
     per_rank = [[mine.get(k, float("nan")) for k in order]]
     if world > 1:
         t_st = torch.tensor(per_rank[0], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
@@ -571,7 +594,7 @@ def main():
                          "algorithmic_flops_per_launch": flops * (i8_pairs or 1.0),
                          "fp64_equivalent_tflops": flops / (gram_ms * 1e-3) / 1e12, "measured_mfma_f64_peak": peak_meas,
                          "frac_of_measured_peak": achieved / peak_meas if (peak_meas > 0 and not i8_pairs) else None},
-            "stages_ms": stage_ms, "heun_step_ms": heun_ms,
+            "stages_ms": stage_ms, "step_span_ms": per_step, "heun_step_ms": heun_ms,
             # per-rank HIP-event averages over the timed steps (ms): the Amdahl terms of the multi-GPU step
             "rank_stage_ms": [dict(zip(order, r)) for r in per_rank],
             "allreduce_payload_bytes": payload_bytes,
@@ -588,9 +611,9 @@ def main():
             # the collective inside the timed steps: its bracket on the launch stream is what the step WAITS for -- the whole all-reduce
             # when it follows the S-build, only its exposed tail when it is interleaved with it (--overlap-allreduce)
             line["allreduce_in_step"] = dict(tdvp.allreduceInfo or {}, exposed_ms_max_rank=ar, alone_ms=rccl["allreduce_alone_ms"])
-            line["one_gpu_same_samples"] = {"ms_per_step_from_stages": world * (sf + gr) + rep, "this_run_ms_per_step": elapsed / args.steps * 1e3,
-                                            "allreduce_bracket_ms_max_rank": ar,
-                                            "note": "N x (sample+flow + gram) + replicated of the slowest rank's brackets; the measured N = 1 "
+            line["one_gpu_same_samples"] = {"kind": "modelled", "ms_per_step_from_stages": world * (sf + gr) + rep,
+                                            "this_run_ms_per_step": elapsed / args.steps * 1e3, "allreduce_bracket_ms_max_rank": ar,
+                                            "note": "MODELLED, not measured: N x (sample+flow + gram) + replicated of the slowest rank's brackets; the measured N = 1 "
                                                     "line of the same workload is `python bench.py --workload " + args.workload + "`"}
             # the committed N = 1 record of this workload (another box, another day): the figure a reader of this line divides by (the driver computes efficiencies itself from its own N = 1 run)
             rec = os.path.join(ROOT, "profiles", "r04_run1_bench.json" if args.workload == "C2" else f"r04_run1_bench_{args.workload}.json")

@@ -59,10 +59,17 @@ def main():
                          "published records hold them, so they are on by default)")
     ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node the Monte-Carlo samples are sharded over (backend nccl = RCCL; "
                                                         "VMCPDE_DIST_BACKEND=gloo rehearses it with all ranks on one GPU)")
+    ap.add_argument("--launch-timeout", type=float, default=None,
+                    help="--gpus N > 1 without a launcher: stop the ranks after this many seconds (default: no limit -- a run to --t-end may take "
+                         "hours; a rank that dies, or a signal to this process, stops the others either way)")
     args = ap.parse_args()
     from vmc_pde_amd import launch
     if args.gpus > 1 and not launch.under_launcher():     # be the launcher: N fresh rank processes; this one never touches the GPU
-        rc, _ = launch.run_ranks([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], args.gpus, relay=lambda line: print(line, end="", flush=True))
+        try:
+            rc, _ = launch.run_ranks([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], args.gpus, timeout=args.launch_timeout,
+                                     relay=lambda line: print(line, end="", flush=True))
+        except launch.LauncherSignalled as ex:              # (the ranks have been stopped)
+            rc = 128 + ex.signum
         sys.exit(rc)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if world > 1:

@@ -339,13 +339,6 @@ int vmcpde_gram_columns(const double* JT, int64_t ldj, int32_t P, int64_t n_samp
  * diagonal gets v = e_k, tau = 2).  Two reflectors per launch while their columns fit the registers of a workgroup (P <= 16 384), one
  * otherwise.  scratch: [dev] 5 r + 5 doubles. */
 int vmcpde_householder_rows(double* LT, int64_t ldl, int32_t P, int32_t r, double* YT, double* tau, double* scratch, void* stream);
-/* ABI 5: the r x r core of that decomposition (tdvp.py:57-64 on range(L)) without a library eigensolver.  One-sided Jacobi on the columns
- * of an r x r matrix C (r <= 1024): on return the columns are mutually orthogonal, C_out = U diag(sigma) with U the left singular vectors and
- * sigma the singular values of the input -- for C = R1 (the triangular factor of L = Q1 R1) the eigenvectors and the square roots of the
- * eigenvalues of R1 R1^T = Q1^T (L L^T) Q1, in no particular order.  CT: [dev] cols_pad x rows_pad doubles, row c = column c of C, zero
- * padded (vmcpde_jacobi_shape gives the padded sizes: rows to a multiple of 64, columns to a multiple of the columns a workgroup sweeps).
- * n_sweeps (<= 30) sweeps are launched; launches behind a sweep that rotated nothing return at once.  counters: [dev] n_sweeps + 1 int32,
- * counters[s] = rotations of sweep s -- converged iff some counters[s] == 0 (the caller may read it later; nothing synchronises). */
 /* ABI 5: the Woodbury application of the low-rank regularised solve, M^-1 v for M = D + L L^T (D > 0 diagonal, L = LT^T of rank r):
  *   M^-1 v = y - D^-1 L G^-1 L^T y,  y = D^-1 v,  G = I + L^T D^-1 L  (r x r, factored by the caller: vmcpde_cholesky / vmcpde_chol_solve).
  * project: y = v / D and t1 = L^T y, with v = F (u, Su NULL) or the residual F - Su - D.u of the full system (S0 + D) u = F at u
@@ -356,6 +349,13 @@ int vmcpde_woodbury_project(const double* LT, int64_t ldl, int32_t P, int32_t r,
                             const double* u, double* y, double* t1, void* stream);
 int vmcpde_woodbury_combine(const double* LT, int64_t ldl, int32_t P, int32_t r, const double* D, const double* y, const double* t2,
                             const double* u, double* out, void* stream);
+/* ABI 5: the r x r core of that decomposition (tdvp.py:57-64 on range(L)) without a library eigensolver.  One-sided Jacobi on the columns
+ * of an r x r matrix C (r <= 1024): on return the columns are mutually orthogonal, C_out = U diag(sigma) with U the left singular vectors and
+ * sigma the singular values of the input -- for C = R1 (the triangular factor of L = Q1 R1) the eigenvectors and the square roots of the
+ * eigenvalues of R1 R1^T = Q1^T (L L^T) Q1, in no particular order.  CT: [dev] cols_pad x rows_pad doubles, row c = column c of C, zero
+ * padded (vmcpde_jacobi_shape gives the padded sizes: rows to a multiple of 64, columns to a multiple of the columns a workgroup sweeps).
+ * n_sweeps (<= 30) sweeps are launched; launches behind a sweep that rotated nothing return at once.  counters: [dev] n_sweeps + 1 int32,
+ * counters[s] = rotations of sweep s -- converged iff some counters[s] == 0 (the caller may read it later; nothing synchronises). */
 int vmcpde_jacobi_shape(int32_t r, int32_t* rows_pad, int32_t* cols_pad);
 int vmcpde_jacobi_columns(double* CT, int32_t r, int32_t n_sweeps, int32_t* counters, void* stream);
 

@@ -149,7 +149,15 @@ def test_small_svdtol_sends_the_spectral_route_to_the_dense_decomposition():
     u_d, _ = t_dense(th.cuda(), 0.0, vs, ep, **kw)
     assert t_small.spectralInfo["engine"] == "dense" and t_small.spectralInfo.get("tried") == "lowrank", t_small.spectralInfo
     assert torch.equal(t_small.ev, t_dense.ev) and torch.equal(u_s, u_d)
-    assert t_small._lowrank_backoff > 0                                                  # not retried on every call
+    # a rejection by the svdTol gate cannot change from call to call: the attempt stays off (no factorisation wasted every 50 calls)
+    # until svdTol is raised past the value that was rejected
+    assert t_small._lowrank_gate_svdtol == 1e-14 and t_small._lowrank_backoff == 0
+    for _ in range(2):
+        t_small(th.cuda(), 0.0, vs, ep, **kw)
+        assert t_small.spectralInfo == {"engine": "dense"}, t_small.spectralInfo          # not even tried
+    t_small.svdTol = 1e-11
+    t_small(th.cuda(), 0.0, vs, ep, **kw)
+    assert t_small.spectralInfo["engine"] == "lowrank", t_small.spectralInfo
 
 
 def _headline_objects(N, key=7):

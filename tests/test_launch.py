@@ -95,3 +95,88 @@ def test_bench_becomes_the_launcher_without_touching_the_gpu(monkeypatch):
     with pytest.raises(SystemExit) as ex:
         bench.main()
     assert ex.value.code == 1
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    # (a zombie still answers kill 0: it is gone once its state says so)
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            return f.read().rsplit(")", 1)[1].split()[0] != "Z"
+    except FileNotFoundError:
+        return False
+
+
+LAUNCHER = ("import sys, time; sys.path.insert(0, {root!r}); from vmc_pde_amd import launch\n"
+            "code = 'import os, sys, time, subprocess; "
+            "h = subprocess.Popen([sys.executable, \"-c\", \"import time; time.sleep(120)\"]); "
+            "print(os.getpid(), h.pid, flush=True); time.sleep(120)'\n"
+            "try:\n"
+            "    rc, _ = launch.run_ranks([sys.executable, '-c', code], 2, relay=lambda l: print(l, end='', flush=True), base_env=None)\n"
+            "except launch.LauncherSignalled as ex:\n"
+            "    sys.exit(128 + ex.signum)\n"
+            "sys.exit(rc)\n")
+
+
+@pytest.mark.parametrize("sig", ["SIGTERM", "SIGINT", "SIGKILL"])
+def test_no_rank_survives_the_launcher(sig, tmp_path):
+    """a SIGTERM (`timeout -k` around the job, the driver's time limit), a Ctrl-C or a SIGKILL to the launching process must
+    not leave ranks behind holding their GPUs -- nor helper processes the ranks started (each rank is signalled as a process group)."""
+    import signal
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # ranks 0 and 1 both print "pid helper_pid"; rank 0's line is relayed on stdout, rank 1's goes to stderr
+    p = subprocess.Popen([sys.executable, "-c", LAUNCHER.format(root=root)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    line0 = p.stdout.readline().split()
+    line1 = p.stderr.readline().split()
+    pids = [int(x) for x in line0 + line1]
+    assert len(pids) == 4 and all(_alive(q) for q in pids)
+    t0 = time.monotonic()
+    p.send_signal(getattr(signal, sig))
+    rc = p.wait(30)
+    assert rc == (-9 if sig == "SIGKILL" else 128 + int(getattr(signal, sig)))
+    ranks = [pids[0], pids[2]]
+    t_end = time.monotonic() + 10
+    while time.monotonic() < t_end and any(_alive(q) for q in (ranks if sig == "SIGKILL" else pids)):
+        time.sleep(0.05)
+    assert not any(_alive(q) for q in ranks), "a rank outlived its launcher"
+    if sig != "SIGKILL":                               # (a killed launcher cannot reap the ranks' own children: the ranks die by PDEATHSIG)
+        assert not any(_alive(q) for q in pids), "a rank's helper process outlived the job"
+    else:
+        for q in pids:
+            try:
+                os.kill(q, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+    assert time.monotonic() - t0 < 25
+
+
+def test_a_relay_that_breaks_stops_the_job_instead_of_blocking_rank0():
+    """`bench.py --gpus 2 | head -1` -- the relay raises BrokenPipeError; rank 0 must not block on a full pipe (the pump keeps
+    draining) and the job ends with a non-zero code instead of hanging until the timeout."""
+    code = ("import os, sys, time\n"
+            "if os.environ['RANK'] == '0':\n"
+            "    for i in range(20000): print('x' * 100)\n"          # 2 MB: far more than a pipe buffer
+            "    sys.stdout.flush()\n"
+            "time.sleep(60)\n")
+    n = []
+
+    def relay(line):
+        n.append(1)
+        if len(n) > 3:
+            raise BrokenPipeError("stdout closed")
+
+    msgs = []
+    t0 = time.monotonic()
+    rc, out = launch.run_ranks([sys.executable, "-c", code], 2, relay=relay, log=msgs.append, stop_grace=2.0)
+    assert rc == 125 and time.monotonic() - t0 < 30
+    assert any("can no longer be relayed" in m for m in msgs)
+
+
+def test_the_whole_record_is_returned_even_when_it_is_long():
+    code = "import os\nif os.environ['RANK'] == '0':\n    for i in range(30000): print(i)\n"
+    rc, out = launch.run_ranks([sys.executable, "-c", code], 2, log=lambda m: None)
+    assert rc == 0 and out.splitlines()[-1] == "29999" and len(out.splitlines()) == 30000

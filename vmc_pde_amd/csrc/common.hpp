@@ -107,7 +107,8 @@ struct DeviceCtx {
   int flow_eval_lds_by[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // largest dynamic-LDS size flow_eval_kernel was raised to, by [block width variant][KD = 1, KD = 1 capped, 2, 4]
   int flow_sample_lds_by[2] = {0, 0};
   int jacobi_lds[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // dynamic-LDS size jacobi_step_kernel<rows / 64> was raised to
-  std::map<int, int*> gram_perms;               // [dev] Gram tile orders (position -> lower-triangle tile index) by number of row blocks: built once
+  std::map<int64_t, int*> gram_perms;           // [dev] Gram tile orders (position -> lower-triangle tile index): key = number of row blocks (whole triangle, built once)
+                                                //       or bit 62 | nb << 40 | row_begin << 20 | row_end (a group of tile rows, vmcpde_gram_rows; at most 64 kept)
                                                 // per matrix size and GPU and never freed, so alternating sizes / threads never re-synchronise
 };
 // returns nullptr (and sets the error string) if the current device cannot be queried

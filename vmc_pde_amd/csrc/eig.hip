@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(256) void woodbury_project_kernel(const double* __r
 // out[p] = (u ? u[p] : 0) + y[p] - (sum_k LT[k][p] t2[k]) / D[p]: one thread per parameter, the r rows of LT read coalesced
 __global__ __launch_bounds__(64) void woodbury_combine_kernel(const double* __restrict__ LT, int64_t ldl, int P, int r, const double* __restrict__ D,
                                                               const double* __restrict__ y, const double* __restrict__ t2,
-                                                              const double* __restrict__ u, double* __restrict__ out) {
+                                                              const double* u, double* out /* may alias u: no __restrict__ on the pair */) {
   const int p = (int)blockIdx.x * 64 + (int)threadIdx.x;
   if (p >= P) return;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;

@@ -474,9 +474,20 @@ extern "C" int vmcpde_gram_rows(const double* JT, int64_t ldj, int32_t P, int64_
   if (!ctx) return -2;
   DeviceCtxLock lock;
   // the group's tiles along a Morton curve (global tile indices), balanced over the XCDs like the whole triangle's (gram_order.hpp)
-  const int key = (g.nb << 20) | (row_begin << 10) | row_end;         // (plain sizes use keys below 2^20; nb <= 127, rows <= 127)
+  VMC_REQUIRE(g.nb < (1 << 20), "vmcpde_gram_rows: %d tile rows", g.nb);
+  const int64_t group_bit = (int64_t)1 << 62;                         // (whole-triangle orders use the plain row count as their key)
+  const int64_t key = group_bit | ((int64_t)g.nb << 40) | ((int64_t)row_begin << 20) | (int64_t)row_end;
   auto it = ctx->gram_perms.find(key);
   if (it == ctx->gram_perms.end()) {
+    // first use of this row group on this GPU: a blocking upload, once.  A caller that keeps changing its cuts must not grow the
+    // process for ever: beyond 64 cached groups all of them are dropped (hipFree waits for the kernels that may still read them)
+    int n_groups = 0;
+    for (auto& kv : ctx->gram_perms) n_groups += (kv.first & group_bit) != 0;
+    if (n_groups >= 64) {
+      for (auto jt = ctx->gram_perms.begin(); jt != ctx->gram_perms.end();) {
+        if (jt->first & group_bit) { (void)hipFree(jt->second); jt = ctx->gram_perms.erase(jt); } else ++jt;
+      }
+    }
     std::vector<int> host;
     for (int t : morton_tile_order(g.nb))
       if (t >= t0 && t < t1) host.push_back(t);

@@ -233,7 +233,6 @@ class LowRankRoutes:
             need = nat.lib().vmcpde_chol_workspace_bytes(rmax)
             w["G"] = torch.zeros((rmax, rmax), dtype=global_defs.tReal, device=device)
             w["G_ws"] = torch.empty(need // 8, dtype=global_defs.tReal, device=device)
-            w["G_info"] = torch.zeros(1, dtype=torch.int32, device=device)
             w["t2"] = torch.empty(rmax, dtype=global_defs.tReal, device=device)
             w["Su"] = torch.empty(P, dtype=global_defs.tReal, device=device)
         G, gws, t2, Su = w["G"], w["G_ws"], w["t2"], w["Su"]
@@ -260,7 +259,9 @@ class LowRankRoutes:
         B3 = Lfull.view(rmax, ldl // ck, ck).permute(1, 2, 0)
         torch.sum(torch.bmm(A3, B3), dim=0, out=G)
         G.diagonal().add_(1.0)
-        nat.call("vmcpde_cholesky", nat.ptr(G), rmax, rmax, nat.ptr(w["G_info"]), nat.ptr(gws), need, nat.stream())
+        # (its status word -- pinned pivots, i.e. a G that is not positive definite: a non-finite factor -- is the call's `info`, which
+        # vmcpde_tdvp_diagnostics hands to the residual guard like the dense factorisation's)
+        nat.call("vmcpde_cholesky", nat.ptr(G), rmax, rmax, nat.ptr(b["info"]), nat.ptr(gws), need, nat.stream())
 
         # u = M^-1 F, then u <- u + M^-1 (F - (S0 + D) u) against the TRUE matrix: per application two own launches around the r x r
         # substitution (vmcpde_woodbury_project / _combine; the residual is formed inside the first)
@@ -281,7 +282,6 @@ class LowRankRoutes:
         for _ in range(st["nref"]):
             nat.call("vmcpde_gemv", nat.ptr(b["S"]), b["Ppad"], P, P, 0, nat.ptr(update), nat.ptr(Su), nat.stream())
             apply(update)
-        b["info"].zero_()
         self.choleskyInfo = dict(engine="lowrank", mode="static", rmax=rmax, block_steps=st["nsteps"], refinements=st["nref"],
                                  planned_rank=st["rank"])
 

@@ -593,8 +593,10 @@ class TDVP(LowRankRoutes):
         if self.spectralEngine == "lowrank" and self.diagonalizeOnDevice is None:
             on_device = True
         self.spectralInfo = None
+        gated = self.spectralEngine == "auto" and getattr(self, "_lowrank_gate_svdtol", None) is not None and \
+            float(self.svdTol) <= self._lowrank_gate_svdtol      # (rejected by the svdTol gate before: only a LARGER svdTol can pass it)
         lowrank = on_device and self.spectralEngine != "dense" and not (self.diagonalShift > 1e-10) and self._lowrank_tol() is not None and \
-            (self.spectralEngine == "lowrank" or (P >= LOWRANK_MIN_P and self._lowrank_backoff == 0))
+            (self.spectralEngine == "lowrank" or (P >= LOWRANK_MIN_P and self._lowrank_backoff == 0 and not gated))
         if on_device and self.spectralEngine == "auto" and self._lowrank_backoff > 0:
             self._lowrank_backoff -= 1
         if lowrank:
@@ -610,7 +612,12 @@ class TDVP(LowRankRoutes):
                 self.ev, self.V = res
                 done = True
             elif self.spectralEngine == "auto":
-                self._lowrank_backoff = LOWRANK_RETRY_AFTER        # rank above the cap: dense for the next calls
+                if (self.spectralInfo or {}).get("rejected"):
+                    # the svdTol gate: a property of (svdTol, this model's spectrum), not of the call -- the wasted factorisation would recur
+                    # at every retry for a cause that cannot change, so the attempt stays off until svdTol does
+                    self._lowrank_gate_svdtol = float(self.svdTol)
+                else:
+                    self._lowrank_backoff = LOWRANK_RETRY_AFTER    # rank above the cap: dense for the next calls
         if on_device and not done:
             if self.spectralInfo is None or self.spectralInfo.get("engine") != "lowrank":
                 self.spectralInfo = dict(engine="dense")
