@@ -359,6 +359,19 @@ int vmcpde_woodbury_combine(const double* LT, int64_t ldl, int32_t P, int32_t r,
 int vmcpde_jacobi_shape(int32_t r, int32_t* rows_pad, int32_t* cols_pad);
 int vmcpde_jacobi_columns(double* CT, int32_t r, int32_t n_sweeps, int32_t* counters, void* stream);
 
+/* ABI 6: the same r x r core (tdvp.py:57-64 on range(L)) by the classical route, with the dependent part in own kernels.  A library syevd
+ * on the 206 x 206 core of the headline workload takes 4.3 ms, 2.9 ms of it the Householder tridiagonalisation -- a chain of ~10 launches
+ * per column.  vmcpde_sytrd_small: T = Q tridiag(D, E) Q^T for a symmetric n x n matrix (n <= vmcpde_sytrd_small_max_n() = 256; only the
+ * lower triangle of the row-major T is read, T is not modified) in ONE 512-thread workgroup that keeps the lower triangle in registers
+ * (LAPACK's dsytd2, lower: Q = H_0 ... H_{n-2}, H_k = I - tau_k v_k v_k^T).  D, E, tau: [dev] n (E[n-1] = tau[n-1] = 0); V: [dev] n x ldv,
+ * row k = v_k (zeros up to k, v_k[k+1] = 1).  Deterministic (no atomics, fixed summation orders): a pure function of the input bits.
+ * vmcpde_apply_reflectors: Zt[m][:] <- Q Zt[m][:] for the nvec rows of Zt -- the eigenvectors of tridiag(D, E), one per row (the
+ * column-major eigenvector matrix of a LAPACK-style tridiagonal solver such as rocSOLVER's stedc, which the host calls between the two),
+ * become those of T. */
+int32_t vmcpde_sytrd_small_max_n(void);
+int vmcpde_sytrd_small(const double* T, int64_t ldt, int32_t n, double* D, double* E, double* tau, double* V, int64_t ldv, void* stream);
+int vmcpde_apply_reflectors(const double* V, int64_t ldv, const double* tau, int32_t n, double* Zt, int64_t ldz, int32_t nvec, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

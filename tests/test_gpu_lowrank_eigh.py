@@ -706,26 +706,111 @@ def test_jacobi_core_matches_the_library_core_at_headline_size(headline_net):
     N = 8192
     vs = varstate(N)
     out = {}
-    for core in ("library", "jacobi"):
+    names = {"library": "syevd", "jacobi": "jacobi", "auto": "sytrd(own)+stedc+back-transform(own)"}
+    for core in ("library", "jacobi", "auto"):
         tp = V.TDVP(svdTol=1e-6, coreEigensolver=core)
         for _ in range(2):
             u, _ = tp(th.cuda(), 0.0, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
             tp.check()
-        assert tp.spectralInfo["engine"] == "lowrank" and tp.spectralInfo["core"] == ("jacobi" if core == "jacobi" else "syevd"), tp.spectralInfo
+        assert tp.spectralInfo["engine"] == "lowrank" and tp.spectralInfo["core"] == names[core], tp.spectralInfo
         out[core] = (tp.S0.clone(), tp.F0.clone(), tp.ev.clone(), tp.V.clone(), u.clone(), float(tp.solverResidual), float(tp.tdvp_error), tp)
     S, F, ev_l, V_l, u_l, res_l, err_l, _ = out["library"]
-    S2, F2, ev_j, V_j, u_j, res_j, err_j, tj = out["jacobi"]
-    assert torch.equal(S, S2) and torch.equal(F, F2)
     P, lmax, nF = S.shape[0], float(ev_l[-1]), float(torch.linalg.norm(F))
-    assert float((ev_j - ev_l).abs().max()) < 1e-13 * lmax and bool((ev_j[1:] >= ev_j[:-1]).all())
     eye = torch.eye(P, dtype=torch.float64, device="cuda")
-    assert float((V_j.T @ V_j - eye).abs().max()) < 1e-13
-    r_j, r_l = float(torch.linalg.norm(S @ V_j - V_j * ev_j)) / lmax, float(torch.linalg.norm(S @ V_l - V_l * ev_l)) / lmax
-    assert r_j < max(3 * r_l, 1e-13), (r_j, r_l)
-    assert float(torch.linalg.norm(S @ (u_j - u_l))) < 1e-10 * nF
-    assert abs(res_j - res_l) < 1e-10 and abs(err_j - err_l) < 1e-10
+    r_l = float(torch.linalg.norm(S @ V_l - V_l * ev_l)) / lmax
+    for core in ("jacobi", "auto"):       # "auto" = the default: own tridiagonalisation + library stedc + own back-transformation (r <= 256)
+        S2, F2, ev_j, V_j, u_j, res_j, err_j, tj = out[core]
+        assert torch.equal(S, S2) and torch.equal(F, F2)
+        assert float((ev_j - ev_l).abs().max()) < 1e-13 * lmax and bool((ev_j[1:] >= ev_j[:-1]).all()), core
+        assert float((V_j.T @ V_j - eye).abs().max()) < 1e-13, core
+        r_j = float(torch.linalg.norm(S @ V_j - V_j * ev_j)) / lmax
+        assert r_j < max(3 * r_l, 1e-13), (core, r_j, r_l)
+        assert float(torch.linalg.norm(S @ (u_j - u_l))) < 1e-10 * nF, core
+        assert abs(res_j - res_l) < 1e-10 and abs(err_j - err_l) < 1e-10, core
+    tt = out["auto"][-1]
+    assert tt._tridiag["off"] is False and int(tt._tridiag["host"][0]) == 0            # stedc's status word of the last call
+    tj = out["jacobi"][-1]
     st = tj._jacobi
     assert not st["off"] and 4 <= st["n_sweeps"] <= 14, st            # the plan follows what the first call needed
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 65, 128, 129, 206, 255, 256])
+def test_own_tridiagonalisation_and_back_transformation_against_numpy(n):
+    """vmcpde_sytrd_small / vmcpde_apply_reflectors (csrc/tridiag.hip): T = Q tridiag(d, e) Q^T of a symmetric matrix graded over seven
+    decades (like the core Q1^T S Q1 of the rank-revealing spectral solve) in one workgroup -- the reflectors give an orthogonal Q, Q^T T Q
+    is tridiagonal with exactly the returned (d, e), the eigenvalues of the tridiagonal matrix are those of T; and the back-transformation of
+    the tridiagonal matrix's eigenvectors (numpy's here) gives eigenvectors of T.  Bitwise reproducible (no atomics)."""
+    from vmc_pde_amd import _native as nat
+    rng = np.random.default_rng(n)
+    Q0, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = 2.0e4 * 10.0 ** (-np.arange(n) / max(n / 7.0, 1.0))
+    A = (Q0 * lam) @ Q0.T
+    A = 0.5 * (A + A.T)
+    ld = 264                                                          # a padded leading dimension (only the lower triangle is read)
+    T = torch.full((n, ld), float("nan"), dtype=torch.float64, device="cuda")
+    T[:, :n] = torch.from_numpy(np.tril(A) + np.triu(np.full((n, n), np.nan), 1))     # the strict upper triangle is never read
+    nmax = int(nat.lib().vmcpde_sytrd_small_max_n())
+    assert nmax == 256
+    outs = []
+    for _ in range(2):
+        D, E, tau = (torch.full((nmax,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(3))
+        Vr = torch.full((nmax, nmax), float("nan"), dtype=torch.float64, device="cuda")
+        nat.call("vmcpde_sytrd_small", nat.ptr(T), ld, n, nat.ptr(D), nat.ptr(E), nat.ptr(tau), nat.ptr(Vr), nmax, nat.stream())
+        outs.append((D.cpu().numpy()[:n], E.cpu().numpy()[:n], tau.cpu().numpy()[:n], Vr.cpu().numpy()[:n, :n]))
+    d, e, t, Vh = outs[0]
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)                                   # a pure function of the input bits
+    assert np.isfinite(d).all() and np.isfinite(e).all() and np.isfinite(t).all() and np.isfinite(Vh).all()
+    assert e[n - 1] == 0.0 and t[n - 1] == 0.0
+    Q = np.eye(n)
+    for k in range(n - 1):                                            # Q = H_0 H_1 ... H_{n-2}
+        v = Vh[k]
+        assert not v[:k + 1].any() and v[k + 1] == 1.0
+        Q = Q - t[k] * np.outer(Q @ v, v)
+    assert np.abs(Q.T @ Q - np.eye(n)).max() < 1e-13
+    Tt = np.diag(d) + np.diag(e[:n - 1], -1) + np.diag(e[:n - 1], 1)
+    scale = np.abs(A).max()
+    assert np.abs(Q.T @ A @ Q - Tt).max() < 2e-13 * scale
+    w_ref = np.linalg.eigvalsh(A)
+    assert np.abs(np.linalg.eigvalsh(Tt) - w_ref).max() < 1e-13 * w_ref[-1]
+    # back-transformation: rows of Zt = eigenvectors of the tridiagonal matrix
+    wt, Zt = np.linalg.eigh(Tt)
+    Zd = torch.from_numpy(np.ascontiguousarray(Zt.T)).cuda()
+    Vd = torch.from_numpy(np.ascontiguousarray(np.pad(Vh, ((0, nmax - n), (0, nmax - n))))).cuda()      # (kept alive until the kernel has run)
+    td = torch.from_numpy(np.pad(t, (0, nmax - n))).cuda()
+    nat.call("vmcpde_apply_reflectors", nat.ptr(Vd), nmax, nat.ptr(td), n, nat.ptr(Zd), n, n, nat.stream())
+    W = Zd.cpu().numpy().T                                            # columns = eigenvectors of A
+    assert np.abs(W - Q @ Zt).max() < 1e-13
+    assert np.linalg.norm(A @ W - W * wt) < 1e-12 * w_ref[-1] and np.abs(W.T @ W - np.eye(n)).max() < 1e-13
+    with pytest.raises(nat.VmcpdeError, match="256"):
+        nat.call("vmcpde_sytrd_small", nat.ptr(T), ld, 257, nat.ptr(D), nat.ptr(E), nat.ptr(tau), nat.ptr(Vr), nmax, nat.stream())
+
+
+@pytest.mark.parametrize("n", [3, 65, 206, 256])
+def test_tridiag_core_route_against_the_library_eigh(n):
+    """The whole core route of `coreEigensolver="auto"` on a graded matrix: own tridiagonalisation, rocSOLVER's stedc through ctypes
+    (vmc_pde_amd/rocsolver.py), own back-transformation -- against torch.linalg.eigh."""
+    import vmc_pde_amd as V
+    g = torch.Generator().manual_seed(n)
+    Q0, _ = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
+    lam = 2.0e4 * 10.0 ** (-torch.arange(n, dtype=torch.float64) / max(n / 7.0, 1.0))
+    A = ((Q0 * lam) @ Q0.T).cuda()
+    A = 0.5 * (A + A.T)
+    tp = V.TDVP()
+    assert tp._core_choice(n) == "tridiag"
+    w = {}
+    wv, W = tp._core_eigh_tridiag(w, A, n, A.device)
+    wv2, W2 = tp._core_eigh_tridiag(w, A, n, A.device)
+    assert torch.equal(wv, wv2) and torch.equal(W, W2)
+    ev, _ = torch.linalg.eigh(A)
+    lmax = float(ev[-1])
+    assert float((wv - ev).abs().max()) < 1e-13 * lmax and bool((wv[1:] >= wv[:-1]).all())
+    eye = torch.eye(n, dtype=torch.float64, device="cuda")
+    assert float((W.T @ W - eye).abs().max()) < 1e-13
+    assert float(torch.linalg.norm(A @ W - W * wv)) < 1e-12 * lmax
+    assert tp._core_choice(n) == "tridiag" and int(tp._tridiag["host"][0]) == 0      # (reads the status word of the call before)
+    assert tp._core_choice(257) == "library" and tp._core_choice(2) == "library"
+    assert V.TDVP(coreEigensolver="library")._core_choice(n) == "library"
 
 
 @pytest.mark.parametrize("P,r,ldl", [(4213, 256, 4224), (300, 7, 320), (65, 64, 128), (16181, 384, 16192)])

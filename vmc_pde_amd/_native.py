@@ -112,6 +112,9 @@ _PROTOS = {
     "vmcpde_woodbury_combine": (_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vmcpde_jacobi_shape": (_int, [_i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "vmcpde_jacobi_columns": (_int, [_vp, _i32, _i32, _vp, _vp]),
+    "vmcpde_sytrd_small_max_n": (_i32, []),
+    "vmcpde_sytrd_small": (_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "vmcpde_apply_reflectors": (_int, [_vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp]),
 }
 
 _lib = None

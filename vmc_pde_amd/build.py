@@ -15,7 +15,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIBDIR = PKG / "_lib"
 LIB = LIBDIR / "libvmcpde.so"
-SOURCES = ["model.hip", "flow.hip", "sampler.hip", "gram.hip", "gram_i8.hip", "moments.hip", "solve.hip", "eig.hip", "jacobi.hip", "comm.hip"]
+SOURCES = ["model.hip", "flow.hip", "sampler.hip", "gram.hip", "gram_i8.hip", "moments.hip", "solve.hip", "eig.hip", "jacobi.hip", "tridiag.hip", "comm.hip"]
 HEADERS = [CSRC / "common.hpp", CSRC / "mfma_tile.hpp", CSRC / "gram_order.hpp", CSRC / "wave_ops.hpp", CSRC / "flow_kernels.inc", PKG.parent / "include" / "vmcpde.h"]
 ARCH = "gfx950"
 # per-file flags.  solve.hip: keep MFMA accumulators in VGPRs -- the diagonal-block sweep edits them with VALU instructions between

@@ -309,7 +309,8 @@ class LowRankRoutes:
             self.spectralInfo["rejected"] = "trace_left above %g x svdTol x lambda_max" % LOWRANK_SVDTOL_FRACTION
             return None
         self._lowrank_last_rank = r
-        jacobi = self._core_uses_jacobi(r)
+        core = self._core_choice(r)
+        jacobi = core == "jacobi"
         Lc = w["LT"][:r].clone() if jacobi else None               # (the Householder chain overwrites the factor)
         Y, Xn, Q1 = self._lowrank_range_basis(w, P, r, device)
         SQ = S @ Q1
@@ -318,13 +319,66 @@ class LowRankRoutes:
         T = 0.5 * (T + T.T)
         if jacobi:
             wv, W = self._core_eigh_jacobi(w, T, _long_k_product(Lc[:, :P], Q1t), r, device)
+        elif core == "tridiag":
+            wv, W = self._core_eigh_tridiag(w, T, r, device)
         else:
             # (the r x r core on one host LAPACK thread takes 1.6 ms against 5.4 ms for syevd's launch chain at r = 238, but the host
             # synchronisation it needs costs the calling loop more than that: 33.0 against 30.2 ms per TDVP call -- measured and dropped)
             wv, W = torch.linalg.eigh(T)                           # r x r (rocSOLVER)
-        self.spectralInfo["core"] = "jacobi" if jacobi else "syevd"
+        self.spectralInfo["core"] = {"jacobi": "jacobi", "tridiag": "sytrd(own)+stedc+back-transform(own)"}.get(core, "syevd")
         U = Q1 @ W
         return self._lowrank_assemble(Y, Xn, U, wv, r, P, device)
+
+    # ---- the r x r core: which eigensolver ---------------------------------------------------------------------------------
+    def _core_choice(self, r):
+        """"tridiag" -- own Householder tridiagonalisation in one workgroup (csrc/tridiag.hip), rocSOLVER's stedc on the tridiagonal matrix,
+        own back-transformation: what coreEigensolver="auto" (the default) takes while r fits the kernel (<= 256) and an earlier call's stedc
+        has not reported a failure; "jacobi" -- the opt-in one-sided Jacobi kernel; "library" -- torch.linalg.eigh (rocSOLVER's syevd: 4.3 ms at
+        r = 206, 2.9 ms of it its tridiagonalisation's launch chain).  VMCPDE_CORE_EIGH overrides the constructor argument."""
+        want = os.environ.get("VMCPDE_CORE_EIGH") or getattr(self, "coreEigensolver", "auto")
+        if want == "jacobi":
+            return "jacobi" if self._core_uses_jacobi(r) else "library"
+        if want in ("auto", "tridiag"):
+            from . import rocsolver
+            st = getattr(self, "_tridiag", None)
+            if st is not None and st["event"] is not None:          # the previous call's stedc status, read one call later
+                st["event"].synchronize()
+                st["event"] = None
+                if int(st["host"][0]) != 0:
+                    import warnings
+                    warnings.warn(f"stedc reported {int(st['host'][0])} unconverged block(s) on the core of the spectral solve; using the library "
+                                  f"eigensolver from now on", RuntimeWarning)
+                    st["off"] = True
+            ok = 3 <= r <= int(nat.lib().vmcpde_sytrd_small_max_n()) and not (st is not None and st["off"]) and rocsolver.available()
+            return "tridiag" if ok else "library"
+        return "library"
+
+    def _core_eigh_tridiag(self, w, T, r, device):
+        """(wv ascending, W) with T W = W diag(wv): T = Q tridiag(d, e) Q^T by `vmcpde_sytrd_small` (one workgroup, the lower triangle in
+        registers), the tridiagonal eigenproblem by rocSOLVER's divide & conquer (a library call: vmc_pde_amd/rocsolver.py), W = Q Z by
+        `vmcpde_apply_reflectors`.  Nothing synchronises: stedc's status word is copied to the host and read by the next call."""
+        from . import rocsolver
+        st = getattr(self, "_tridiag", None)
+        if st is None:
+            st = self._tridiag = dict(off=False, event=None, host=torch.zeros(1, dtype=torch.int32).pin_memory())
+        nmax = int(nat.lib().vmcpde_sytrd_small_max_n())
+        td = w.get("td")
+        if td is None:
+            td = w["td"] = dict(D=torch.empty(nmax, dtype=global_defs.tReal, device=device), E=torch.empty(nmax, dtype=global_defs.tReal, device=device),
+                                tau=torch.empty(nmax, dtype=global_defs.tReal, device=device),
+                                V=torch.empty((nmax, nmax), dtype=global_defs.tReal, device=device),
+                                Z=torch.empty(nmax * nmax, dtype=global_defs.tReal, device=device),
+                                info=torch.zeros(1, dtype=torch.int32, device=device))
+        Tc = T if T.is_contiguous() else T.contiguous()
+        nat.call("vmcpde_sytrd_small", nat.ptr(Tc), Tc.stride(0), r, nat.ptr(td["D"]), nat.ptr(td["E"]), nat.ptr(td["tau"]), nat.ptr(td["V"]), nmax,
+                 nat.stream())
+        Z = td["Z"][:r * r].view(r, r)
+        rocsolver.stedc(td["D"][:r], td["E"][:r], Z, td["info"])
+        st["host"].copy_(td["info"], non_blocking=True)
+        st["event"] = torch.cuda.Event()
+        st["event"].record()
+        nat.call("vmcpde_apply_reflectors", nat.ptr(td["V"]), nmax, nat.ptr(td["tau"]), r, nat.ptr(Z), r, r, nat.stream())
+        return td["D"][:r].clone(), Z.t()
 
     # ---- the r x r core: one-sided Jacobi on the triangular factor (csrc/jacobi.hip) ------------------------------------
     def _core_uses_jacobi(self, r):

@@ -84,7 +84,11 @@ class TDVP(LowRankRoutes):
                                   #   the backward error of a dense eigensolver, the ~P - r eigenvalues below 1e-16 of the largest
                                   #   reported as exact zeros.  "auto": lowrank from LOWRANK_MIN_P parameters on when diagonalShift
                                   #   leaves S rank deficient, dense whenever the rank exceeds the cap (then not retried for a while).
-    coreEigensolver: str = "library"  # the r x r symmetric eigenproblem inside the rank-revealing spectral engine: "library" -- torch.linalg.eigh =
+    coreEigensolver: str = "auto" # the r x r symmetric eigenproblem inside the rank-revealing spectral engine.  "auto" (default) = "tridiag" while the
+                                  #   rank fits its kernel (r <= 256): own Householder tridiagonalisation in ONE workgroup with the lower
+                                  #   triangle in registers (csrc/tridiag.hip), rocSOLVER's divide & conquer on the tridiagonal matrix, own
+                                  #   back-transformation -- the library's syevd spends 2.9 of its 4.3 ms at r = 206 in the launch chain of its
+                                  #   tridiagonalisation; "library" -- torch.linalg.eigh =
                                   #   rocSOLVER's syevd (a chain of some hundred launches: 4.35 of the engine's 6.8 ms at the headline size);
                                   #   "jacobi" -- the own kernel, blocked one-sided Jacobi on the triangular factor R1 of L = Q1 R1
                                   #   (csrc/jacobi.hip).  Correct and tested, but SLOWER (11 ms at the headline size: every rotation moves two
