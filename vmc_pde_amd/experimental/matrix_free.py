@@ -251,7 +251,11 @@ class MatrixFreeMixin:
                     mpi.allreduce_sum_(Tm)
                 q = Q1.T @ mean
                 Tm = Tm / Ntot - torch.outer(q, q)
-                wv, W = torch.linalg.eigh(0.5 * (Tm + Tm.T))
+                Tm = 0.5 * (Tm + Tm.T)
+                if self._core_choice(r) == "tridiag":               # (the product's own core: csrc/tridiag.hip + stedc, lowrank.py)
+                    wv, W = self._core_eigh_tridiag(w, Tm, r, device)
+                else:
+                    wv, W = torch.linalg.eigh(Tm)
                 self.ev, self.V = self._lowrank_assemble(Y, Xn, Q1 @ W, wv, r, P, device)
                 self.spectralInfo = dict(engine="matrix-free", mode=mode, rank=r, block_steps=self._mf_plan["nsteps"], columns_ahead=ahead,
                                          own_passes_last_call=self._mf_plan.get("prev_passes"))
