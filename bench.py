@@ -464,17 +464,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        tdvp(theta, 0.0, **kwargs)
-    barrier()
-    stage_events.clear()
     # the host only enqueues (it runs ~a step ahead of the device); a generation-2 collection of the interpreter's garbage collector in
     # the middle of the timed steps (tens of ms with torch's object graph) would starve the device of launches: collect now, keep the
-    # collector out of the timed region, restore it afterwards.  No work of the step is skipped.
+    # collector out of the timed region, restore it afterwards.  No work of the step is skipped.  (Before the warm-up, not between warm-up
+    # and timed steps: the device must not idle there -- after 8 ms of idling the chip's power management makes the next S-build 1.8 ms
+    # slower, tools/diag/gram_between_phases_probe.py.)
     import gc
     gc.collect()
     gc.freeze()
     gc.disable()
+    for _ in range(args.warmup):
+        tdvp(theta, 0.0, **kwargs)
+    barrier()
+    stage_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         update, _ = tdvp(theta, 0.0, **kwargs)
@@ -502,7 +504,8 @@ def main():
     per_step = None
     if all(len(stage_events.get(k, [])) == args.steps for k in ("sample+flow", "replicated")):
         spans = np.asarray([stage_events["sample+flow"][i][0].elapsed_time(stage_events["replicated"][i][1]) for i in range(args.steps)])
-        per_step = {"median": float(np.median(spans)), "min": float(spans.min()), "max": float(spans.max()),
+        per_step = {"median": float(np.median(spans)), "min": float(spans.min()), "max": float(spans.max()), "slowest_step": int(spans.argmax()),
+                    "first": float(spans[0]),
                     "n_over_1p25_median": int((spans > 1.25 * np.median(spans)).sum()),
                     "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
                     "what": "HIP-event span of each timed step on the launch stream (start of sampling to end of the solve's diagnostics); "

@@ -734,6 +734,44 @@ def test_jacobi_core_matches_the_library_core_at_headline_size(headline_net):
     assert not st["off"] and 4 <= st["n_sweeps"] <= 14, st            # the plan follows what the first call needed
 
 
+@pytest.mark.parametrize("use_snr", [False, True])
+def test_rhovar_from_the_ritz_vectors_is_the_dense_formula(headline_net, monkeypatch, use_snr):
+    """tdvp.py:68-71 after the rank-revealing decomposition: only the r Ritz vectors can carry variance (v^T S v = 0 means every sample's
+    centred gradient is orthogonal to v), so rhoVar comes from one r x P x N product instead of the weighted Gram and a P^3 product -- the
+    same numbers as the dense formula on the Ritz modes, exact zeros where the dense formula leaves round-off; snr likewise; and the
+    SNR-regularised solve (useSNR) gives the same update with either."""
+    import vmc_pde_amd as V
+    varstate, ep, th = headline_net
+    N = 8192
+    vs = varstate(N)
+    kw = dict(nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+    tp = V.TDVP(svdTol=1e-6, useSNR=use_snr)
+    u_fast, _ = tp(th.cuda(), 0.0, vs, ep, **kw)
+    assert tp.spectralInfo["engine"] == "lowrank" and tp._ritz is not None
+    rho_fast, snr_fast = tp.rhoVar.clone(), tp.snr.clone()
+    monkeypatch.setenv("VMCPDE_RHOVAR_LOWRANK", "0")
+    tp._rhoVar = tp._snr = None
+    rho_dense = tp.rhoVar.clone()
+    td = V.TDVP(svdTol=1e-6, useSNR=use_snr)
+    u_dense, _ = td(th.cuda(), 0.0, vs, ep, **kw)
+    snr_dense = td.snr.clone()
+    assert torch.equal(td.ev, tp.ev)
+    P, r = tp.S0.shape[0], tp.spectralInfo["rank"]
+    ritz = tp.ev != 0
+    assert int(ritz.sum()) in (r, r - 1, r - 2)                       # (a Ritz value may be an exact 0 only by accident)
+    top = float(rho_dense.abs().max())
+    assert float((rho_fast - rho_dense)[ritz].abs().max()) < 1e-10 * top
+    assert not rho_fast[~ritz].any() and float(rho_dense[~ritz].abs().max()) < 1e-10 * top        # round-off against exact zeros
+    assert not snr_fast[~ritz].any() and bool(torch.isfinite(snr_fast).all())
+    live = ritz & (rho_dense > 1e-7 * top)
+    assert int(live.sum()) >= 30
+    assert float(((snr_fast - snr_dense)[live] / snr_dense[live]).abs().max()) < 1e-5
+    nF = float(torch.linalg.norm(tp.F0))
+    assert float(torch.linalg.norm(tp.S0 @ (u_fast - u_dense))) < 1e-9 * nF         # (identical when useSNR is off: rhoVar is not in the solve)
+    if not use_snr:
+        assert torch.equal(u_fast, u_dense)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 65, 128, 129, 206, 255, 256])
 def test_own_tridiagonalisation_and_back_transformation_against_numpy(n):
     """vmcpde_sytrd_small / vmcpde_apply_reflectors (csrc/tridiag.hip): T = Q tridiag(d, e) Q^T of a symmetric matrix graded over seven

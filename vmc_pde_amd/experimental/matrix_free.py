@@ -257,6 +257,7 @@ class MatrixFreeMixin:
                 else:
                     wv, W = torch.linalg.eigh(Tm)
                 self.ev, self.V = self._lowrank_assemble(Y, Xn, Q1 @ W, wv, r, P, device)
+                self._ritz = None
                 self.spectralInfo = dict(engine="matrix-free", mode=mode, rank=r, block_steps=self._mf_plan["nsteps"], columns_ahead=ahead,
                                          own_passes_last_call=self._mf_plan.get("prev_passes"))
                 Fc = F.contiguous()

@@ -327,7 +327,11 @@ class LowRankRoutes:
             wv, W = torch.linalg.eigh(T)                           # r x r (rocSOLVER)
         self.spectralInfo["core"] = {"jacobi": "jacobi", "tridiag": "sytrd(own)+stedc+back-transform(own)"}.get(core, "syevd")
         U = Q1 @ W
-        return self._lowrank_assemble(Y, Xn, U, wv, r, P, device)
+        ev, V = self._lowrank_assemble(Y, Xn, U, wv, r, P, device)
+        # what rhoVar / snr need (tdvp.py:68-71): only the r Ritz vectors carry variance -- a vector with v^T S v = 0 is orthogonal to
+        # every sample's centred gradient -- so the N x P x P work of the reference shrinks to one r x P x N product (TDVP.rhoVar)
+        self._ritz = dict(U=U, wv=wv, r=r, P=P)
+        return ev, V
 
     # ---- the r x r core: which eigensolver ---------------------------------------------------------------------------------
     def _core_choice(self, r):

@@ -517,9 +517,38 @@ class TDVP(LowRankRoutes):
         if self._rhoVar is None:
             if self.V is None:
                 raise RuntimeError("rhoVar/snr need the eigenbasis: use solver='eigh'")
-            G = self._weighted_gram(self._lazy["e"] - self._lazy["Emean"])
-            self._rhoVar = ((G @ self.V) * self.V).sum(0) - self.VtF ** 2
+            rz = getattr(self, "_ritz", None)
+            if rz is not None and self._lazy["JT"].dtype == global_defs.tReal and os.environ.get("VMCPDE_RHOVAR_LOWRANK", "1") != "0":
+                self._rhoVar = self._rhoVar_from_ritz(rz)
+            else:
+                G = self._weighted_gram(self._lazy["e"] - self._lazy["Emean"])
+                self._rhoVar = ((G @ self.V) * self.V).sum(0) - self.VtF ** 2
         return self._rhoVar
+
+    def _rhoVar_from_ritz(self, rz):
+        """tdvp.py:68-70 after the rank-revealing decomposition: (V^T G V)_kk = (1/N) sum_n E~_n^2 (O~_n . v_k)^2, and a vector with
+        v^T S0 v = (1/N) sum_n (O~_n . v)^2 = 0 is orthogonal to EVERY sample's centred gradient -- so the P - r eigenvectors the engine
+        reports with eigenvalue exactly 0 have rhoVar = 0 (and VtF = 0), and only the r Ritz vectors U = Q1 W need the samples:
+        Z = U^T (J - m 1^T), one r x P x N product over the retained Jacobian (114 GFLOP at the headline size instead of the 1.1 TFLOP
+        weighted Gram and the P^3 product behind it: 2.5 ms instead of 20 ms for the `snr` the reference's driver logs after every step,
+        main.py:187).  Modes the engine reports as null carry rhoVar = 0, snr = 0."""
+        z = self._lazy
+        if z["owner"] is not None and z["owner"].workspace_generation(z["n"]) != z["gen"]:
+            raise RuntimeError("SExp / rhoVar / snr are computed lazily from the Jacobian of the last TDVP call, but the VarState "
+                               "has evaluated another batch of the same size since (its workspace was overwritten): read these "
+                               "attributes before calling psi(...), psi.hessian or psi.evaluate again")
+        P, n, r = z["P"], z["n"], rz["r"]
+        U, wv = rz["U"], rz["wv"]
+        Jv = z["JT"][:P, :n]                                          # P x n view of the parameter-major Jacobian (row pitch ldj)
+        Z = U.T @ Jv                                                  # r x n
+        Z -= (U.T @ z["mean"])[:, None]
+        Z *= (z["e"] - z["Emean"])[None, :]
+        second = (Z * Z).sum(1)                                       # sum_n E~_n^2 (O~_n . u_k)^2 over this rank's samples
+        mpi.allreduce_sum_(second)
+        pos = torch.arange(r, device=U.device) + (P - r) * (wv >= 0)   # the Ritz columns of V: negatives first, the positives behind the zeros
+        out = torch.zeros(P, dtype=global_defs.tReal, device=U.device)
+        out[pos] = second / z["Ntot"] - self.VtF[pos] ** 2
+        return out
 
     @property
     def snr(self):
@@ -527,7 +556,10 @@ class TDVP(LowRankRoutes):
         if self._snr is None:
             if self.V is None:
                 raise RuntimeError("rhoVar/snr need the eigenbasis: use solver='eigh'")
-            self._snr = torch.sqrt(torch.abs(self._lazy["Ntot"] * (self.VtF * self.VtF) / self.rhoVar))
+            rho = self.rhoVar
+            snr = torch.sqrt(torch.abs(self._lazy["Ntot"] * (self.VtF * self.VtF) / rho))
+            # (modes the rank-revealing engine reports as null have rhoVar = 0 exactly: no sample's gradient reaches them -- snr 0, not 0 / 0)
+            self._snr = torch.where(rho == 0, torch.zeros_like(snr), snr) if getattr(self, "_ritz", None) is not None else snr
         return self._snr
 
     def _solver(self):
@@ -597,6 +629,7 @@ class TDVP(LowRankRoutes):
         if self.spectralEngine == "lowrank" and self.diagonalizeOnDevice is None:
             on_device = True
         self.spectralInfo = None
+        self._ritz = None                # (set by the rank-revealing engine: what rhoVar / snr need of it)
         gated = self.spectralEngine == "auto" and getattr(self, "_lowrank_gate_svdtol", None) is not None and \
             float(self.svdTol) <= self._lowrank_gate_svdtol      # (rejected by the svdTol gate before: only a LARGER svdTol can pass it)
         lowrank = on_device and self.spectralEngine != "dense" and not (self.diagonalShift > 1e-10) and self._lowrank_tol() is not None and \
