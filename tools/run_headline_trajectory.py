@@ -33,6 +33,9 @@ while t < T_END:
     vs.set_parameters(dp)
     t += dt
     n += 1
+    if os.environ.get("READ_SNR", "0") == "1" and tdvp.ev is not None:      # as the reference's driver does after every step (main.py:186-187)
+        ev_host, snr_host = tdvp.ev.cpu(), tdvp.snr.cpu()
+        assert bool(torch.isfinite(snr_host).all())
     if tdvp.choleskyInfo is not None:
         key = f"{tdvp.choleskyInfo.get('engine')}/{tdvp.choleskyInfo.get('mode', '-')}"
         modes[key] = modes.get(key, 0) + 1
