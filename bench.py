@@ -619,7 +619,7 @@ def main():
                                             "note": "MODELLED, not measured: N x (sample+flow + gram) + replicated of the slowest rank's brackets; the measured N = 1 "
                                                     "line of the same workload is `python bench.py --workload " + args.workload + "`"}
             # the committed N = 1 record of this workload (another box, another day): the figure a reader of this line divides by (the driver computes efficiencies itself from its own N = 1 run)
-            rec = os.path.join(ROOT, "profiles", "r04_run1_bench.json" if args.workload == "C2" else f"r04_run1_bench_{args.workload}.json")
+            rec = os.path.join(ROOT, "profiles", "r05_run1_bench.json" if args.workload == "C2" else f"r05_run1_bench_{args.workload}.json")
             if os.path.exists(rec) and args.jacobian == "f64" and args.solver == "cholesky":
                 try:
                     one = json.loads(next(l for l in open(rec) if l.startswith("{")))
