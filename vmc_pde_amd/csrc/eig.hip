@@ -866,6 +866,7 @@ __global__ __launch_bounds__(HQ_THREADS) void hqr_step_kernel(double* __restrict
 // rows k ..) go to rblk and are copied into LT by a final launch -- those columns must stay untouched while other workgroups of this
 // launch read them.  A thread holds elements i = k + 1 + t + 1024 e, e < MAXE (4, 8 or 16 by the number of rows): P <= 16 384.
 constexpr int HQ_MAXE_LIMIT = 16;
+constexpr int HQB_THREADS = 512;                       // workgroup of the batched form (hqr_batched_kernel)
 constexpr int HQ_RB = 4;                                 // doubles of rblk per column
 template <int NR, int MAXE>
 __global__ __launch_bounds__(HQ_THREADS) void hqr_multi_kernel(double* __restrict__ LT, int64_t ldl, int P, int k, double* __restrict__ YT,
@@ -1009,6 +1010,234 @@ __global__ __launch_bounds__(HQ_THREADS) void hqr_multi_kernel(double* __restric
   }
 }
 
+// The same NR steps per launch with the dot products BATCHED (round 5).  hqr_multi_kernel applies the earlier reflectors of the block to a
+// column one after the other -- a dependent block sum each, NR (NR - 1) / 2 + 2 NR - 1 of them per launch (13 for NR = 4), which is why four
+// steps per launch were no faster than two.  But H_{j-1} ... H_0 y = y - sum_a w_a v_a with  w_0 = tau_0 g_0,  w_b = tau_b (g_b - sum_{a<b} w_a c_ab),
+// g_a = v_a . y and c_ab = v_a . v_b: all g_a of a column against the ORIGINAL y, and the c_ab of the newest reflector, are ONE block sum of
+// several values; then the column's norm below its diagonal is a second one (recomputed, not downdated: the columns are graded).  2 NR
+// block-sum phases per launch instead of 13: four steps per launch now pay (52 instead of 103 dependent launches for 206 columns).
+template <int WAVES>
+__device__ __forceinline__ double block_sum_w(double v, double* red) {
+  v = wave_sum(v);
+  const int t = threadIdx.x;
+  __syncthreads();                                   // (red may still be read from the previous call)
+  if ((t & 63) == 0) red[t >> 6] = v;
+  __syncthreads();
+  double total = 0.0;
+#pragma unroll
+  for (int q = 0; q < WAVES; ++q) total += red[q];
+  return total;
+}
+
+template <int K, int WAVES>
+__device__ __forceinline__ void block_sum_n(double (&v)[K], double* red /* [K][WAVES] */) {
+#pragma unroll
+  for (int q = 0; q < K; ++q) v[q] = wave_sum(v[q]);
+  const int t = threadIdx.x;
+  __syncthreads();                                   // (red may still be read from the previous call)
+  if ((t & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) red[q * WAVES + (t >> 6)] = v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    double total = 0.0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) total += red[q * WAVES + w];
+    v[q] = total;
+  }
+}
+
+template <int NR, int MAXE, int THREADS>
+__global__ __launch_bounds__(THREADS) void hqr_batched_kernel(double* __restrict__ LT, int64_t ldl, int P, int k, double* __restrict__ YT,
+                                                                 double* __restrict__ tau, double* __restrict__ norm2, double* __restrict__ rblk) {
+  constexpr int WAVES = THREADS / 64;
+  __shared__ double red[2 * NR * WAVES];
+  __shared__ double s_diag;
+  const int t = threadIdx.x, m = blockIdx.x;
+  const int i0 = k + 1 + t;
+  const int ne = (P - k - 1 + THREADS - 1) / THREADS;        // (<= MAXE, checked by the host)
+  double v[NR][MAXE];             // v[j]: column k + j below row k (first as loaded, then with the earlier reflectors applied, then scaled to v_{k+j})
+  double tk[NR];
+  double cab[NR][NR];             // cab[a][b] = v_a . v_b for a < b (wave-uniform)
+  // ---- reflector k from column k
+  {
+    const double* __restrict__ x = LT + (int64_t)k * ldl;
+    double s2;
+    if (k == 0) {
+      s2 = 0.0;
+      for (int i = 1 + t; i < P; i += THREADS) s2 = fma(x[i], x[i], s2);
+      s2 = block_sum_w<WAVES>(s2, red);
+    } else {
+      s2 = norm2[k];
+    }
+    const double alpha = x[k];
+    const double nrm2 = fma(alpha, alpha, s2);
+    double scale = 0.0;
+    tk[0] = 2.0;
+    if (nrm2 > 0.0) {
+      const double beta = -copysign(sqrt(nrm2), alpha);
+      tk[0] = (beta - alpha) / beta;
+      scale = 1.0 / (alpha - beta);
+    }
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int i = i0 + e * THREADS;
+      v[0][e] = (e < ne && i < P) ? x[i] * scale : 0.0;
+    }
+  }
+  // ---- columns k + 1 .. k + NR - 1 with the earlier reflectors applied (batched), and their reflectors
+#pragma unroll
+  for (int j = 1; j < NR; ++j) {
+    const double* __restrict__ y = LT + (int64_t)(k + j) * ldl;
+    double ytop = y[k];
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int i = i0 + e * THREADS;
+      v[j][e] = (e < ne && i < P) ? y[i] : 0.0;
+    }
+    // one phase: g_a = v_a . y (a < j; v_0 has a one in row k, the later reflectors a zero) and c_{a,j-1} = v_a . v_{j-1} (a < j - 1)
+    double vals[2 * NR];
+#pragma unroll
+    for (int q = 0; q < 2 * NR; ++q) vals[q] = 0.0;
+#pragma unroll
+    for (int a = 0; a < j; ++a) {
+      double dot = (a == 0 && t == 0) ? ytop : 0.0;
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) dot = fma(v[a][e], v[j][e], dot);
+      vals[a] = dot;
+    }
+#pragma unroll
+    for (int a = 0; a + 1 < j; ++a) {
+      double dot = 0.0;
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) dot = fma(v[a][e], v[j - 1][e], dot);
+      vals[NR + a] = dot;
+    }
+    block_sum_n<2 * NR, WAVES>(vals, red);
+#pragma unroll
+    for (int a = 0; a + 1 < j; ++a) cab[a][j - 1] = vals[NR + a];
+    double w[NR];
+#pragma unroll
+    for (int b = 0; b < j; ++b) {
+      double g = vals[b];
+#pragma unroll
+      for (int a = 0; a < b; ++a) g = fma(-w[a], cab[a][b], g);
+      w[b] = tk[b] * g;
+    }
+    ytop -= w[0];
+#pragma unroll
+    for (int a = 0; a < j; ++a)
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) v[j][e] = fma(-w[a], v[a][e], v[j][e]);
+    // what is above the diagonal of column k + j now is final: R[k + a][k + j], a < j (row k: ytop; row k + a: thread a - 1, e = 0)
+    if (m == 0) {
+      if (t == 0) rblk[(int64_t)(k + j) * HQ_RB + 0] = ytop;
+#pragma unroll
+      for (int a = 1; a < j; ++a)
+        if (t == a - 1) rblk[(int64_t)(k + j) * HQ_RB + a] = v[j][0];
+    }
+    // reflector k + j: diagonal entry = element i = k + j (thread j - 1, e = 0), norm of what lies below it
+    double s2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int i = i0 + e * THREADS;
+      if (i > k + j) s2 = fma(v[j][e], v[j][e], s2);
+    }
+    __syncthreads();                                                // (s_diag may still be read from the previous column)
+    if (t == j - 1) s_diag = v[j][0];
+    s2 = block_sum_w<WAVES>(s2, red);                                        // (its barriers publish s_diag)
+    const double alpha = s_diag;
+    const double nrm2 = fma(alpha, alpha, s2);
+    double scale = 0.0;
+    tk[j] = 2.0;
+    if (nrm2 > 0.0) {
+      const double beta = -copysign(sqrt(nrm2), alpha);
+      tk[j] = (beta - alpha) / beta;
+      scale = 1.0 / (alpha - beta);
+    }
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int i = i0 + e * THREADS;
+      v[j][e] = (i < k + j) ? 0.0 : ((i == k + j) ? 1.0 : v[j][e] * scale);      // (zero beyond P: loaded as zero)
+    }
+  }
+  if (m == 0) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      double* __restrict__ yo = YT + (int64_t)(k + j) * ldl;
+      for (int i = t; i <= k; i += THREADS) yo[i] = (j == 0 && i == k) ? 1.0 : 0.0;
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) {
+        const int i = i0 + e * THREADS;
+        if (e < ne && i < (int)ldl) yo[i] = (i < P) ? v[j][e] : 0.0;
+      }
+      for (int i = i0 + ne * THREADS; i < (int)ldl; i += THREADS) yo[i] = 0.0;       // (pad columns past the last full stride)
+      if (t == 0) tau[k + j] = tk[j];
+    }
+    return;
+  }
+  // ---- the workgroup's own column c = k + NR - 1 + m: H_k .. H_{k+NR-1}, batched
+  double* __restrict__ z = LT + (int64_t)(k + NR - 1 + m) * ldl;
+  double cr[MAXE];
+  double ztop = z[k];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    const int i = i0 + e * THREADS;
+    cr[e] = (e < ne && i < P) ? z[i] : 0.0;
+  }
+  {
+    double vals[2 * NR];
+#pragma unroll
+    for (int q = 0; q < 2 * NR; ++q) vals[q] = 0.0;
+#pragma unroll
+    for (int a = 0; a < NR; ++a) {
+      double dot = (a == 0 && t == 0) ? ztop : 0.0;
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) dot = fma(v[a][e], cr[e], dot);
+      vals[a] = dot;
+    }
+#pragma unroll
+    for (int a = 0; a + 1 < NR; ++a) {
+      double dot = 0.0;
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) dot = fma(v[a][e], v[NR - 1][e], dot);
+      vals[NR + a] = dot;
+    }
+    block_sum_n<2 * NR, WAVES>(vals, red);
+#pragma unroll
+    for (int a = 0; a + 1 < NR; ++a) cab[a][NR - 1] = vals[NR + a];
+    double w[NR];
+#pragma unroll
+    for (int b = 0; b < NR; ++b) {
+      double g = vals[b];
+#pragma unroll
+      for (int a = 0; a < b; ++a) g = fma(-w[a], cab[a][b], g);
+      w[b] = tk[b] * g;
+    }
+    ztop -= w[0];
+#pragma unroll
+    for (int a = 0; a < NR; ++a)
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) cr[e] = fma(-w[a], v[a][e], cr[e]);
+  }
+  if (t == 0) z[k] = ztop;
+  double next = 0.0;                                                // (m == 1) sum of squares of column k + NR below ITS diagonal
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    const int i = i0 + e * THREADS;
+    if (e < ne && i < P) {
+      z[i] = cr[e];
+      if (i > k + NR) next = fma(cr[e], cr[e], next);
+    }
+  }
+  if (m == 1) {
+    next = block_sum_w<WAVES>(next, red);
+    if (t == 0) norm2[k + NR] = next;
+  }
+}
+
 // the entries of R above the diagonal inside the blocks of NR columns starting at k_begin, k_begin + NR, ... (nblocks of them)
 __global__ void hqr_commit_kernel(double* __restrict__ LT, int64_t ldl, int k_begin, int nr, int nblocks, const double* __restrict__ rblk) {
   const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -1085,32 +1314,68 @@ extern "C" int vmcpde_householder_rows(double* LT, int64_t ldl, int32_t P, int32
   hipStream_t st = (hipStream_t)stream;
   double* norm2 = scratch;
   double* rblk = scratch + r + 1;
-  // several steps per launch while a workgroup's registers hold the columns: two up to 16 384 rows.  (Four -- VMCPDE_HQR_BLOCK=4, up
-  // to 8192 rows -- measured no better than two: 1.05 against 1.01 ms for 203 columns at P = 4213, 1.49 ms with one; the thirteen block
+  // several steps per launch while a workgroup's registers hold the columns: two up to 16 384 rows, four up to 8192.  (Round 3, sequential
+  // dot products: four measured no better than two -- 1.05 against 1.01 ms for 203 columns at P = 4213, 1.49 ms with one; the thirteen block
   // sums of a launch of four, two barriers of sixteen waves each, cost what the two saved launch boundaries do.)
-  const int cap = env_int("VMCPDE_HQR_BLOCK", 2);
+  // Round 5: with the dot products of a launch batched (hqr_batched_kernel: 2 NR block-sum phases instead of 13 at NR = 4) four steps per
+  // launch do pay; VMCPDE_HQR_BATCHED=0 restores the sequential form, VMCPDE_HQR_BLOCK caps the steps per launch (default 4 batched, 2 not).
+  // (beyond 12 slices of 512 rows a lane -- P > 6145 -- the 1024-thread sequential pair kernel is faster: 1.33 against 1.51 ms at P = 8000)
+  const bool batched = env_int("VMCPDE_HQR_BATCHED", 1) != 0 && P <= 12 * HQB_THREADS + 1;
+  const int cap = env_int("VMCPDE_HQR_BLOCK", batched ? 4 : 2);
   const dim3 block(HQ_THREADS);
   int k = 0;
-  if (P <= 8 * HQ_THREADS && cap >= 4) {
-    const int k_begin = k;
-    int nblocks = 0;
-    for (; k + 3 < r; k += 4, ++nblocks) {
-      const dim3 grid(r - k - 3);
-      if (P <= 4 * HQ_THREADS) hipLaunchKernelGGL((hqr_multi_kernel<4, 4>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
-      else hipLaunchKernelGGL((hqr_multi_kernel<4, 8>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
+  if (batched) {
+    // 512-thread workgroups (eight waves: cheaper block sums; 256 registers a lane hold four reflectors' and the own column's slices)
+    const dim3 bblock(HQB_THREADS);
+    const int need = (P - 1 + HQB_THREADS - 1) / HQB_THREADS;       // slices of 512 rows a thread holds of a column
+#define VMC_HQRB(NRV)                                                                                                                        \
+  do {                                                                                                                                       \
+    if (need <= 4) hipLaunchKernelGGL((hqr_batched_kernel<NRV, 4, HQB_THREADS>), grid, bblock, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);   \
+    else if (need <= 8) hipLaunchKernelGGL((hqr_batched_kernel<NRV, 8, HQB_THREADS>), grid, bblock, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk); \
+    else if (need <= 10) hipLaunchKernelGGL((hqr_batched_kernel<NRV, 10, HQB_THREADS>), grid, bblock, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk); \
+    else hipLaunchKernelGGL((hqr_batched_kernel<NRV, 12, HQB_THREADS>), grid, bblock, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);           \
+  } while (0)
+    if (cap >= 4) {
+      const int k_begin = k;
+      int nblocks = 0;
+      for (; k + 3 < r; k += 4, ++nblocks) {
+        const dim3 grid(r - k - 3);
+        VMC_HQRB(4);
+      }
+      if (nblocks) hipLaunchKernelGGL(hqr_commit_kernel, dim3((nblocks * 4 * HQ_RB + 255) / 256), dim3(256), 0, st, LT, ldl, k_begin, 4, nblocks, rblk);
     }
-    if (nblocks) hipLaunchKernelGGL(hqr_commit_kernel, dim3((nblocks * 4 * HQ_RB + 255) / 256), dim3(256), 0, st, LT, ldl, k_begin, 4, nblocks, rblk);
-  }
-  if (P <= HQ_MAXE_LIMIT * HQ_THREADS && cap >= 2) {
-    const int k_begin = k;
-    int nblocks = 0;
-    for (; k + 1 < r; k += 2, ++nblocks) {
-      const dim3 grid(r - k - 1);
-      if (P <= 4 * HQ_THREADS) hipLaunchKernelGGL((hqr_multi_kernel<2, 4>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
-      else if (P <= 8 * HQ_THREADS) hipLaunchKernelGGL((hqr_multi_kernel<2, 8>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
-      else hipLaunchKernelGGL((hqr_multi_kernel<2, 16>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
+    if (cap >= 2) {
+      const int k_begin = k;
+      int nblocks = 0;
+      for (; k + 1 < r; k += 2, ++nblocks) {
+        const dim3 grid(r - k - 1);
+        VMC_HQRB(2);
+      }
+      if (nblocks) hipLaunchKernelGGL(hqr_commit_kernel, dim3((nblocks * 2 * HQ_RB + 255) / 256), dim3(256), 0, st, LT, ldl, k_begin, 2, nblocks, rblk);
     }
-    if (nblocks) hipLaunchKernelGGL(hqr_commit_kernel, dim3((nblocks * 2 * HQ_RB + 255) / 256), dim3(256), 0, st, LT, ldl, k_begin, 2, nblocks, rblk);
+#undef VMC_HQRB
+  } else {
+    if (P <= 8 * HQ_THREADS && cap >= 4) {
+      const int k_begin = k;
+      int nblocks = 0;
+      for (; k + 3 < r; k += 4, ++nblocks) {
+        const dim3 grid(r - k - 3);
+        if (P <= 4 * HQ_THREADS) hipLaunchKernelGGL((hqr_multi_kernel<4, 4>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
+        else hipLaunchKernelGGL((hqr_multi_kernel<4, 8>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
+      }
+      if (nblocks) hipLaunchKernelGGL(hqr_commit_kernel, dim3((nblocks * 4 * HQ_RB + 255) / 256), dim3(256), 0, st, LT, ldl, k_begin, 4, nblocks, rblk);
+    }
+    if (P <= HQ_MAXE_LIMIT * HQ_THREADS && cap >= 2) {
+      const int k_begin = k;
+      int nblocks = 0;
+      for (; k + 1 < r; k += 2, ++nblocks) {
+        const dim3 grid(r - k - 1);
+        if (P <= 4 * HQ_THREADS) hipLaunchKernelGGL((hqr_multi_kernel<2, 4>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
+        else if (P <= 8 * HQ_THREADS) hipLaunchKernelGGL((hqr_multi_kernel<2, 8>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
+        else hipLaunchKernelGGL((hqr_multi_kernel<2, 16>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
+      }
+      if (nblocks) hipLaunchKernelGGL(hqr_commit_kernel, dim3((nblocks * 2 * HQ_RB + 255) / 256), dim3(256), 0, st, LT, ldl, k_begin, 2, nblocks, rblk);
+    }
   }
   for (; k < r; ++k) hipLaunchKernelGGL(hqr_step_kernel, dim3(r - k), block, 0, st, LT, ldl, P, k, YT, tau, norm2);
   VMC_CHECK_HIP(hipGetLastError());
