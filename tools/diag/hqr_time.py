@@ -10,7 +10,7 @@ for P, r in ((4213, 206), (2000, 131), (8000, 206), (16181, 262)):
     L0 = torch.zeros((r, ldl), dtype=torch.float64, device="cuda")
     L0[:, :P] = torch.randn((r, P), generator=g, dtype=torch.float64, device="cuda") * torch.logspace(0, -7, r, dtype=torch.float64, device="cuda")[:, None]
     outs = {}
-    for name, env in (("sequential pairs", {"VMCPDE_HQR_BATCHED": "0"}), ("batched pairs", {"VMCPDE_HQR_BLOCK": "2"}), ("batched fours", {})):
+    for name, env in (("sequential pairs", {"VMCPDE_HQR_BATCHED": "0"}), ("batched pairs", {"VMCPDE_HQR_BLOCK": "2"}), ("fours (batched up to P = 6145)", {})):
         for k in ("VMCPDE_HQR_BATCHED", "VMCPDE_HQR_BLOCK"):
             os.environ.pop(k, None)
         os.environ.update(env)

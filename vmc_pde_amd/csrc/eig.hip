@@ -1049,7 +1049,7 @@ __device__ __forceinline__ void block_sum_n(double (&v)[K], double* red /* [K][W
   }
 }
 
-template <int NR, int MAXE, int THREADS>
+template <int NR, int MAXE, int THREADS, int RB = HQ_RB>
 __global__ __launch_bounds__(THREADS) void hqr_batched_kernel(double* __restrict__ LT, int64_t ldl, int P, int k, double* __restrict__ YT,
                                                                  double* __restrict__ tau, double* __restrict__ norm2, double* __restrict__ rblk) {
   constexpr int WAVES = THREADS / 64;
@@ -1133,10 +1133,10 @@ __global__ __launch_bounds__(THREADS) void hqr_batched_kernel(double* __restrict
       for (int e = 0; e < MAXE; ++e) v[j][e] = fma(-w[a], v[a][e], v[j][e]);
     // what is above the diagonal of column k + j now is final: R[k + a][k + j], a < j (row k: ytop; row k + a: thread a - 1, e = 0)
     if (m == 0) {
-      if (t == 0) rblk[(int64_t)(k + j) * HQ_RB + 0] = ytop;
+      if (t == 0) rblk[(int64_t)(k + j) * RB + 0] = ytop;
 #pragma unroll
       for (int a = 1; a < j; ++a)
-        if (t == a - 1) rblk[(int64_t)(k + j) * HQ_RB + a] = v[j][0];
+        if (t == a - 1) rblk[(int64_t)(k + j) * RB + a] = v[j][0];
     }
     // reflector k + j: diagonal entry = element i = k + j (thread j - 1, e = 0), norm of what lies below it
     double s2 = 0.0;
@@ -1239,14 +1239,14 @@ __global__ __launch_bounds__(THREADS) void hqr_batched_kernel(double* __restrict
 }
 
 // the entries of R above the diagonal inside the blocks of NR columns starting at k_begin, k_begin + NR, ... (nblocks of them)
-__global__ void hqr_commit_kernel(double* __restrict__ LT, int64_t ldl, int k_begin, int nr, int nblocks, const double* __restrict__ rblk) {
+__global__ void hqr_commit_kernel(double* __restrict__ LT, int64_t ldl, int k_begin, int nr, int nblocks, const double* __restrict__ rblk, int rb) {
   const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  const int per = nr * HQ_RB;
+  const int per = nr * rb;
   if (q >= nblocks * per) return;
-  const int blk = q / per, j = (q - blk * per) / HQ_RB, a = q % HQ_RB;
+  const int blk = q / per, j = (q - blk * per) / rb, a = q % rb;
   if (j == 0 || a >= j) return;
   const int k = k_begin + blk * nr;
-  LT[(int64_t)(k + j) * ldl + (k + a)] = rblk[(int64_t)(k + j) * HQ_RB + a];
+  LT[(int64_t)(k + j) * ldl + (k + a)] = rblk[(int64_t)(k + j) * rb + a];
 }
 
 int64_t pivchol_ws_doubles(int P) {
@@ -1318,10 +1318,11 @@ extern "C" int vmcpde_householder_rows(double* LT, int64_t ldl, int32_t P, int32
   // dot products: four measured no better than two -- 1.05 against 1.01 ms for 203 columns at P = 4213, 1.49 ms with one; the thirteen block
   // sums of a launch of four, two barriers of sixteen waves each, cost what the two saved launch boundaries do.)
   // Round 5: with the dot products of a launch batched (hqr_batched_kernel: 2 NR block-sum phases instead of 13 at NR = 4) four steps per
-  // launch do pay; VMCPDE_HQR_BATCHED=0 restores the sequential form, VMCPDE_HQR_BLOCK caps the steps per launch (default 4 batched, 2 not).
+  // launch do pay; VMCPDE_HQR_BATCHED=0 restores the sequential form, VMCPDE_HQR_BLOCK caps the steps per launch (default 4).
   // (beyond 12 slices of 512 rows a lane -- P > 6145 -- the 1024-thread sequential pair kernel is faster: 1.33 against 1.51 ms at P = 8000)
   const bool batched = env_int("VMCPDE_HQR_BATCHED", 1) != 0 && P <= 12 * HQB_THREADS + 1;
-  const int cap = env_int("VMCPDE_HQR_BLOCK", batched ? 4 : 2);
+  // (six per launch, tried: 120 + 20 doubles of slices a lane and the phase values no longer fit 256 registers -- 118 spilled, 1.70 ms)
+  const int cap = env_int("VMCPDE_HQR_BLOCK", 4);      // (sequential form: fours pay from ~6000 rows on -- 1.25 against 1.36 ms at P = 8000 -- and cost 4 % below)
   const dim3 block(HQ_THREADS);
   int k = 0;
   if (batched) {
@@ -1342,7 +1343,7 @@ extern "C" int vmcpde_householder_rows(double* LT, int64_t ldl, int32_t P, int32
         const dim3 grid(r - k - 3);
         VMC_HQRB(4);
       }
-      if (nblocks) hipLaunchKernelGGL(hqr_commit_kernel, dim3((nblocks * 4 * HQ_RB + 255) / 256), dim3(256), 0, st, LT, ldl, k_begin, 4, nblocks, rblk);
+      if (nblocks) hipLaunchKernelGGL(hqr_commit_kernel, dim3((nblocks * 4 * HQ_RB + 255) / 256), dim3(256), 0, st, LT, ldl, k_begin, 4, nblocks, rblk, HQ_RB);
     }
     if (cap >= 2) {
       const int k_begin = k;
@@ -1351,7 +1352,7 @@ extern "C" int vmcpde_householder_rows(double* LT, int64_t ldl, int32_t P, int32
         const dim3 grid(r - k - 1);
         VMC_HQRB(2);
       }
-      if (nblocks) hipLaunchKernelGGL(hqr_commit_kernel, dim3((nblocks * 2 * HQ_RB + 255) / 256), dim3(256), 0, st, LT, ldl, k_begin, 2, nblocks, rblk);
+      if (nblocks) hipLaunchKernelGGL(hqr_commit_kernel, dim3((nblocks * 2 * HQ_RB + 255) / 256), dim3(256), 0, st, LT, ldl, k_begin, 2, nblocks, rblk, HQ_RB);
     }
 #undef VMC_HQRB
   } else {
@@ -1363,7 +1364,7 @@ extern "C" int vmcpde_householder_rows(double* LT, int64_t ldl, int32_t P, int32
         if (P <= 4 * HQ_THREADS) hipLaunchKernelGGL((hqr_multi_kernel<4, 4>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
         else hipLaunchKernelGGL((hqr_multi_kernel<4, 8>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
       }
-      if (nblocks) hipLaunchKernelGGL(hqr_commit_kernel, dim3((nblocks * 4 * HQ_RB + 255) / 256), dim3(256), 0, st, LT, ldl, k_begin, 4, nblocks, rblk);
+      if (nblocks) hipLaunchKernelGGL(hqr_commit_kernel, dim3((nblocks * 4 * HQ_RB + 255) / 256), dim3(256), 0, st, LT, ldl, k_begin, 4, nblocks, rblk, HQ_RB);
     }
     if (P <= HQ_MAXE_LIMIT * HQ_THREADS && cap >= 2) {
       const int k_begin = k;
@@ -1374,7 +1375,7 @@ extern "C" int vmcpde_householder_rows(double* LT, int64_t ldl, int32_t P, int32
         else if (P <= 8 * HQ_THREADS) hipLaunchKernelGGL((hqr_multi_kernel<2, 8>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
         else hipLaunchKernelGGL((hqr_multi_kernel<2, 16>), grid, block, 0, st, LT, ldl, P, k, YT, tau, norm2, rblk);
       }
-      if (nblocks) hipLaunchKernelGGL(hqr_commit_kernel, dim3((nblocks * 2 * HQ_RB + 255) / 256), dim3(256), 0, st, LT, ldl, k_begin, 2, nblocks, rblk);
+      if (nblocks) hipLaunchKernelGGL(hqr_commit_kernel, dim3((nblocks * 2 * HQ_RB + 255) / 256), dim3(256), 0, st, LT, ldl, k_begin, 2, nblocks, rblk, HQ_RB);
     }
   }
   for (; k < r; ++k) hipLaunchKernelGGL(hqr_step_kernel, dim3(r - k), block, 0, st, LT, ldl, P, k, YT, tau, norm2);
