@@ -64,11 +64,11 @@ DTYPE_LABEL = {"f64": "f64", "i8f32": "f32 Jacobian storage, four 8-bit int8 dig
                "i8sliced": "f64 Jacobian, error-free int8 slicing (six balanced 8-bit digits), int32 sums, f64 combine (experiment)",
                "f32": "f64 accumulate, f32 Jacobian storage (BASELINE config 5)",
                "f32blocks": "f32 Jacobian, f32 MFMA sums over 128-sample blocks, f64 across blocks (BASELINE config 5, fast variant)"}
-OPERAND_LABEL = {"f64": "uncentred+DMA", "i8f32": "uncentred, 4 int8 digit planes + DMA", "i8sliced": "uncentred, int8 digit planes + DMA", "f32": "uncentred, fp32 widened in staging", "f32blocks": "uncentred+DMA, fp32 MFMA blocks"}
+OPERAND_LABEL = {"f64": "uncentred+DMA", "i8f32": "uncentred, 4 int8 digit planes + DMA", "i8sliced": "uncentred, int8 digit planes + DMA", "f32": "uncentred+DMA over fp32 sample pairs, widened at the fragment read", "f32blocks": "uncentred+DMA, fp32 MFMA blocks"}
 KERNEL_LABEL = {"f64": "gram_dma_kernel (fp64 MFMA syrk, + split-K reduce)",
                 "i8f32": "row_expo + slice + gram_i8_kernel<4,8,8> (v_mfma_i32_32x32x32_i8, 10 digit pairs) + split reduce + diagonal fix",
                 "i8sliced": "row_expo + slice + gram_i8_kernel<6,8,8> (v_mfma_i32_32x32x32_i8, 21 digit pairs) + split reduce + diagonal fix",
-                "f32": "gram_kernel<false,false,float> (fp32 operands widened, fp64 MFMA syrk, + split-K reduce)",
+                "f32": "gram_w32_kernel (fp32 operands DMA-staged as sample pairs, widened at the fragment read, fp64 MFMA syrk, + split-K reduce)",
                 "f32blocks": "gram_f32_kernel (fp32 MFMA block sums, fp64 across blocks, + split-K reduce)"}
 OUT_SCALE = 0.1                 # output kernels U(-0.1, 0.1) (the reference's 1e-5 makes J nearly degenerate)
 

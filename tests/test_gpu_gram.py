@@ -70,9 +70,12 @@ def test_gram_parity_with_centring(P, N):
 
 
 @pytest.mark.parametrize("P,N", [(129, 17), (411, 1000), (640, 4099)])
-def test_gram_fp32_operand_equals_fp64_path_on_fp32_values(P, N):
+def test_gram_fp32_operand_equals_fp64_path_on_fp32_values(P, N, monkeypatch):
     # config 5: the fp32 buffer is widened while staging, so on fp32-representable data all three variants
-    # (plain, centred, weighted) must be bit-identical to the fp64-operand kernel; row moments likewise
+    # (plain, centred, weighted) must be bit-identical to the fp64-operand kernel; row moments likewise.  (The register-staged loop:
+    # it orders its sums like the fp64 kernel.  The DMA-staged loop over sample pairs that the plain variant takes since round 5 is
+    # test_gram_fp32_dma_variant's.)
+    monkeypatch.setenv("VMCPDE_GRAM_F32_DMA", "0")
     J, _, ldj = _jt(P, N, seed=P * 3 + N, mean=2.0)
     J32 = J.astype(np.float32)
     Ppad = _pad(P, 128)
@@ -93,6 +96,35 @@ def test_gram_fp32_operand_equals_fp64_path_on_fp32_values(P, N):
         nat.call("vmcpde_row_moments", nat.ptr(buf), ldj, f32, P, N, nat.ptr(e), nat.ptr(c), nat.ptr(cE), nat.ptr(rs), nat.ptr(rd), nat.stream())
         outs.append((rs.clone(), rd.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("P,N", [(129, 17), (256, 64), (411, 1000), (640, 4099), (1000, 16385), (4213, 2048)])
+def test_gram_fp32_dma_variant(P, N, monkeypatch):
+    """jt_f32 = 1, uncentred and unweighted (BASELINE config 5 in the steady state): the DMA-staged loop over sample pairs, both floats of a
+    slot widened at the fragment read and fed to fp64 MFMAs.  (a) On small integers every product and partial sum is exact in fp64, so the
+    result must equal the integer Gram bit for bit -- any slip in the pair packing, the swizzled image, the fp64 C/D map or the ragged tail
+    shows up; (b) on real data it is the Gram of the stored fp32 values with another ORDER of the fp64 sums: equal to the register-staged
+    loop (= the fp64 kernel on the same values) to a few ulp of the entry's own scale, symmetric, deterministic."""
+    rng = np.random.default_rng(P + 7 * N)
+    Ppad, ldj = _pad(P, 128), _pad(N, 16)
+    Ji = rng.integers(-7, 8, size=(N, P)).astype(np.float32)
+    JT32 = torch.zeros((Ppad, ldj), dtype=torch.float32, device=DEV)
+    JT32[:P, :N] = torch.as_tensor(Ji.T)
+    S = _unpack(_gram(JT32, ldj, P, N, f32=1), P)
+    assert np.array_equal(S, Ji.astype(np.float64).T @ Ji.astype(np.float64))
+    Jr = (rng.standard_normal((N, P)) * rng.uniform(1e-3, 1e3, size=P)).astype(np.float32) + 0.3
+    JT32[:P, :N] = torch.as_tensor(Jr.T)
+    a = _gram(JT32, ldj, P, N, f32=1)
+    assert torch.equal(a, _gram(JT32, ldj, P, N, f32=1))                                # deterministic
+    monkeypatch.setenv("VMCPDE_GRAM_F32_DMA", "0")
+    b = _gram(JT32, ldj, P, N, f32=1)
+    assert not torch.equal(a, b)                                                         # (it really is another loop)
+    S1, S0 = _unpack(a, P), _unpack(b, P)
+    assert np.array_equal(S1, S1.T)
+    # entry (p, q) is a sum of N products of size ~ |J_p| |J_q| / N each: two differently ordered fp64 sums of it differ by a few
+    # sqrt(N) ulp of sqrt(S_pp S_qq) (measured 5.4e-15 at N = 4099)
+    scale = np.sqrt(np.outer(np.diag(S0), np.diag(S0)))
+    assert (np.abs(S1 - S0) / scale).max() < 4e-16 * np.sqrt(N) + 2e-15
 
 
 @pytest.mark.parametrize("P,N", [(129, 17), (256, 64), (411, 1000), (640, 4099), (1000, 16384)])

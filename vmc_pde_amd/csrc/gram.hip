@@ -149,8 +149,30 @@ __global__ __launch_bounds__(256, 2) void gram_f32_kernel(const double* __restri
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  tile_mainloop_dma<16, true>(acc, JT2, ldj2, ti * TILE, JT2, ldj2, tj * TILE, ti == tj, k0, k1, lds);
+  tile_mainloop_dma<16, 1>(acc, JT2, ldj2, ti * TILE, JT2, ldj2, tj * TILE, ti == tj, k0, k1, lds);
   tile_store_f32map(acc, out + ((int64_t)split * ntiles + tile) * (TILE * TILE));
+}
+
+// BASELINE config 5 proper on the DMA-staged loop (round 5): fp32 Jacobian storage, every product and sum in fp64.  The fp32 buffer is
+// viewed as sample pairs like gram_f32_kernel's, both floats of a slot are widened at the fragment read and feed two fp64 MFMAs.  The exact
+// Gram of the stored (rounded) Jacobian like the register-staged gram_kernel<.., float>, with another order of the fp64 sums.
+__global__ __launch_bounds__(256, 2) void gram_w32_kernel(const double* __restrict__ JT2, int64_t ldj2, int64_t N2, int ntiles, int nsplit,
+                                                          int64_t chunk2, int total_units, int units_per_xcd, int order,
+                                                          const int* __restrict__ perm, double* __restrict__ out) {
+  extern __shared__ double lds[];
+  int split, tile;
+  if (!gram_unit(ntiles, nsplit, total_units, units_per_xcd, order, perm, split, tile)) return;
+  int ti, tj;
+  tri_decode(tile, ti, tj);
+  const int64_t k0 = (int64_t)split * chunk2;
+  const int64_t k1 = (k0 + chunk2 < N2) ? (k0 + chunk2) : N2;
+  double4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  tile_mainloop_dma<16, 2>(acc, JT2, ldj2, ti * TILE, JT2, ldj2, tj * TILE, ti == tj, k0, k1, lds);
+  tile_store(acc, out + ((int64_t)split * ntiles + tile) * (TILE * TILE));
 }
 
 // packed[tile][e] = sum_split slabs[split][tile][e]   (fixed order -> deterministic)
@@ -375,8 +397,11 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
   const bool dma = !jt_f32 && !c && !w;       // the steady-state variant
   const bool f32blocks = jt_f32 == 2 && !c && !w;   // fp32 MFMA block sums (centred / weighted requests fall back to widening)
   VMC_REQUIRE(!f32blocks || (ldj % 4) == 0, "jt_f32 = 2 needs ldj to be a multiple of 4 (16-byte rows)");
+  // fp32 storage, fp64 products and sums, uncentred and unweighted: the DMA-staged loop over sample pairs (VMCPDE_GRAM_F32_DMA=0: the
+  // register-staged loop, which orders its sums like the fp64 kernel and is bit-identical to it on fp32-valued data)
+  const bool w32 = jt_f32 == 1 && !c && !w && (ldj % 4) == 0 && (reinterpret_cast<uintptr_t>(JT) & 15) == 0 && env_int("VMCPDE_GRAM_F32_DMA", 1) != 0;
   // in pairs of samples for the fp32-block variant (an odd N relies on the zero padding of the rows)
-  GramPlan g = f32blocks ? make_plan(P, (n_samples + 1) / 2, SLOTS_STAGED) : make_plan(P, n_samples, dma ? SLOTS_DMA : SLOTS_STAGED);
+  GramPlan g = (f32blocks || w32) ? make_plan(P, (n_samples + 1) / 2, SLOTS_STAGED) : make_plan(P, n_samples, dma ? SLOTS_DMA : SLOTS_STAGED);
   const int64_t need = (int64_t)g.nsplit * g.ntiles * TILE * TILE * (int64_t)sizeof(double);
   double* out = packed;
   if (g.nsplit > 1) {
@@ -425,6 +450,13 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
       ctx->attr_gram_f32 = true;
     }
     hipLaunchKernelGGL(gram_f32_kernel, dim3(grid), dim3(256), TILE_DMA_LDS_BYTES, st, static_cast<const double*>(JT), ldj / 2,
+                       (n_samples + 1) / 2, g.ntiles, g.nsplit, g.chunk, total, per_xcd, order, perm, out);
+  } else if (w32) {
+    if (!ctx->attr_gram_w32) {
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_w32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_DMA_LDS_BYTES));
+      ctx->attr_gram_w32 = true;
+    }
+    hipLaunchKernelGGL(gram_w32_kernel, dim3(grid), dim3(256), TILE_DMA_LDS_BYTES, st, static_cast<const double*>(JT), ldj / 2,
                        (n_samples + 1) / 2, g.ntiles, g.nsplit, g.chunk, total, per_xcd, order, perm, out);
   } else if (dma) {
     const size_t dma_lds = 4 * DmaGeom<GRAM_BKD>::DT * sizeof(double) + lds_pad;

@@ -354,6 +354,36 @@ __device__ __forceinline__ void mma_kstep_swz_f32(float4_t (&acc)[4][4], const d
   }
 }
 
+// The same fragments WIDENED: both floats of a slot become doubles and feed two fp64 MFMAs into the fp64 accumulators (fp64 C/D map) --
+// BASELINE config 5 proper (fp32 Jacobian storage, fp64 products and sums) on the DMA-staged loop: half the staged bytes, half the
+// fragment reads per MFMA, and the conversions (one per operand value, 0.5 per MFMA) on the VALU instead of the register-staged loop's
+// conversion while committing to LDS.
+template <int BKD>
+__device__ __forceinline__ void mma_kstep_swz_w32(double4_t (&acc)[4][4], const double* __restrict__ lds, int offAs, int offBs, int wr, int wc,
+                                                  const int (&koff)[BKD / 4]) {
+  const int lr = threadIdx.x & 15;
+  const double* __restrict__ ap = lds + offAs + (64 * wr + lr) * BKD;
+  const double* __restrict__ bp = lds + offBs + (64 * wc + lr) * BKD;
+#pragma unroll
+  for (int k4 = 0; k4 < BKD / 4; ++k4) {
+    float2_t a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float2_t*>(ap + 16 * i * BKD + koff[k4]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const float2_t*>(bp + 16 * j * BKD + koff[k4]);
+    double ax[4], ay[4], bx[4], by[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ax[i] = (double)a[i].x; ay[i] = (double)a[i].y; bx[i] = (double)b[i].x; by[i] = (double)b[i].y; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[i], bx[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay[i], by[j], acc[i][j], 0, 0, 0);
+      }
+  }
+}
+
 // fp64 running sums += fp32 block sums; the fp64 registers simply shadow the fp32 C/D map (row = 4*(lane/16) + reg)
 __device__ __forceinline__ void flush_f32_blocks(double4_t (&acc)[4][4], float4_t (&acc32)[4][4]) {
 #pragma unroll
@@ -387,7 +417,8 @@ __device__ __forceinline__ void mma_kstep_sym(double4_t (&acc)[4][4], const doub
 // zero); products are summed in fp32 by the matrix pipe over blocks of F32_BLOCK_STEPS K steps (<= 128 samples) and the block
 // sums are accumulated in fp64 -- acc then follows the fp32 C/D register map (tile_store_f32map).
 constexpr int F32_BLOCK_STEPS = 4;
-template <int BKD, bool F32 = false>
+// MODE 0: fp64 operands.  MODE 1 (F32 blocks) and MODE 2 (fp32 operands widened to fp64 MFMAs, fp64 C/D map): sample pairs as above.
+template <int BKD, int MODE = 0>
 __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const double* __restrict__ A, int64_t lda, int rowA0,
                                                   const double* __restrict__ B, int64_t ldb, int rowB0, bool alias, int64_t k0,
                                                   int64_t k1, double* __restrict__ lds, int tid = -1) {
@@ -415,6 +446,7 @@ __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const 
 #pragma unroll
     for (int k4 = 0; k4 < BKD / 4; ++k4) koff[k4] = (((2 * k4 + (lk >> 1)) ^ f) << 1) + (lk & 1);
   }
+  constexpr bool F32 = MODE == 1;
   float4_t acc32[F32 ? 4 : 1][F32 ? 4 : 1];
   if constexpr (F32) {
 #pragma unroll
@@ -455,6 +487,8 @@ __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const 
         mma_kstep_swz_f32<BKD>(acc32, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff);
         if ((s & (F32_BLOCK_STEPS - 1)) == F32_BLOCK_STEPS - 1) flush_f32_blocks(acc, acc32);
       }
+    } else if constexpr (MODE == 2) {
+      if (active) mma_kstep_swz_w32<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff);
     } else {
       mma_kstep_sym<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff, alias);
     }
@@ -494,6 +528,8 @@ __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const 
     __syncthreads();
     if constexpr (F32) {
       if (active) mma_kstep_swz_f32<BKD>(acc32, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff);
+    } else if constexpr (MODE == 2) {
+      if (active) mma_kstep_swz_w32<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff);
     } else {
       mma_kstep_sym<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff, alias);
     }
