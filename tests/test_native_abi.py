@@ -49,3 +49,14 @@ def test_product_never_imports_the_oracle():
     root = pathlib.Path(__file__).resolve().parents[1] / "vmc_pde_amd"
     for f in root.rglob("*.py"):
         assert "oracle" not in f.read_text(), f
+
+
+def test_rocsolver_binding_resolves_without_a_gpu():
+    """vmc_pde_amd/rocsolver.py binds ONE library routine -- rocSOLVER's tridiagonal divide & conquer, which runs between the library's own
+    tridiagonalisation and back-transformation kernels (csrc/tridiag.hip) -- from the libraries the running torch ships: the symbol must
+    resolve here (no compute call without a GPU); if it ever does not, `available()` says so and the spectral core falls back to syevd."""
+    from vmc_pde_amd import rocsolver
+    assert rocsolver.available() in (True, False)
+    if rocsolver.available():
+        blas, solver = rocsolver._load()
+        assert hasattr(solver, "rocsolver_dstedc") and hasattr(blas, "rocblas_create_handle") and hasattr(blas, "rocblas_set_stream")
