@@ -273,3 +273,43 @@ def test_gram_operator_protocol_routes_the_norm_function():
         e = Engine(S)
         assert float(expr(GramOperator(e))) == 0.0 and "dense" in e.used and "form" not in e.used
     assert GramOperator(Engine(S)).shape == S.shape
+
+
+def test_rhovar_from_ritz_vectors_positions_and_values_on_cpu():
+    """TDVP._rhoVar_from_ritz (tdvp.py:68-70 after the rank-revealing decomposition) as host logic, on CPU tensors: the r Ritz modes sit in
+    V as [negative Ritz values | P - r null vectors | non-negative Ritz values]; rhoVar of a Ritz mode is the dense formula's, of a null mode
+    exactly zero -- also when some Ritz values are (round-off) negative, which the GPU tests rarely produce."""
+    import vmc_pde_amd as V
+    from vmc_pde_amd import global_defs
+    rng = np.random.default_rng(5)
+    P, n, r = 23, 400, 7
+    B = rng.standard_normal((P, r))
+    J = (B @ rng.standard_normal((r, n))).T                      # n x P, rank r (after centring: rank <= r)
+    e = rng.standard_normal(n)
+    m = J.mean(0)
+    O = J - m
+    S = O.T @ O / n
+    w_all, V_all = np.linalg.eigh(S)
+    ritz = np.argsort(w_all)[P - r:]                              # the r modes that carry the spectrum
+    U = V_all[:, ritz]
+    wv = w_all[ritz].copy()
+    wv[0], wv[1] = -1e-17, -3e-18                                 # two round-off negatives: they sort in FRONT of the null block
+    order = np.argsort(wv)
+    U, wv = U[:, order], wv[order]
+    null = V_all[:, np.argsort(w_all)[:P - r]]
+    Vfull = np.concatenate([U[:, :2], null, U[:, 2:]], axis=1)   # what _lowrank_assemble builds for nneg = 2
+    Et = e - e.mean()
+    F = (Et[:, None] * O).mean(0)
+    VtF = Vfull.T @ F
+    G = (O * (Et ** 2)[:, None]).T @ O / n
+    rho_dense = np.einsum("pk,pq,qk->k", Vfull, G, Vfull) - VtF ** 2
+    tp = V.TDVP()
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=global_defs.tReal)
+    tp._lazy = dict(JT=T(J.T), P=P, n=n, mean=T(m), e=T(e), Emean=T(np.array(e.mean())), Ntot=float(n), owner=None, gen=None)
+    tp.VtF = T(VtF)
+    rho = tp._rhoVar_from_ritz(dict(U=T(U), wv=T(wv), r=r, P=P)).numpy()
+    pos = np.r_[0, 1, np.arange(P - r + 2, P)]
+    top = np.abs(rho_dense).max()
+    assert np.abs(rho[pos] - rho_dense[pos]).max() < 1e-12 * top
+    nullpos = np.setdiff1d(np.arange(P), pos)
+    assert not rho[nullpos].any() and np.abs(rho_dense[nullpos]).max() < 1e-12 * top
