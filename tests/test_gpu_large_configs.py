@@ -300,24 +300,24 @@ def test_spectral_solve_on_device_by_default_at_config4_width():
     assert float(torch.linalg.norm(to.S0 @ (ups[None] - ups[False]).cpu()) / nF) < 1e-9
 
 
-def _full_size_call(dim, hidden, N, eq, lam):
+def _full_size_call(dim, hidden, N, eq, lam, jacobian_dtype=None, tdvp_kwargs=None, calls=2):
     import vmc_pde_amd as V
     ups = [[int(v) for v in np.random.default_rng(b).permutation(dim)[: dim // 2]] for b in range(4)]
     dns = [[i for i in range(dim) if i not in u] for u in ups]
     off = np.zeros(dim)
     sampler = V.Sampler(key=1, dim=dim, name="Gauss", mcmc_info={"offset": off, "bound": 0.25})
     vs = V.VarState(sampler, dim, 1, 4, network_args=dict(intmediate=hidden, offset=off, latentSpaceName="Gauss", dim=dim),
-                    inds_up=ups, inds_down=dns)
+                    inds_up=ups, inds_down=dns, **({} if jacobian_dtype is None else {"jacobian_dtype": jacobian_dtype}))
     th = vs.net.init(1, out_scale=0.1)
     vs.set_parameters(th)
     ep = V.EvolutionEquation(dim=dim, name=eq)
     ep.eqParams[eq]["params"]["lam"] = lam
-    tp = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky")
+    tp = V.TDVP(**(dict(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky") if tdvp_kwargs is None else tdvp_kwargs))
     out = []
-    for _ in range(2):          # second call: lagged centring + uncentred DMA Gram + fused moments (the steady state)
+    for _ in range(calls):      # second call: lagged centring + uncentred DMA Gram + fused moments (the steady state)
         upd, _ = tp(th, 0.0, vs, ep, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
         torch.cuda.synchronize()
-        out.append((upd.clone(), float(tp.solverResidual), int(tp.cholInfo.item()), float(tp.tdvp_error)))
+        out.append((upd.clone(), float(tp.solverResidual), int(tp.cholInfo.item()) if tp.cholInfo is not None else 0, float(tp.tdvp_error)))
     return vs, tp, out
 
 
@@ -350,6 +350,67 @@ def test_full_size_config4_shard_tdvp_call():
     for upd, resid, info, err in out:
         assert torch.isfinite(upd).all() and info == 0 and resid < 1e-8 and 0.0 <= err < 1.0
     assert tp._uncentred_ok
+
+
+def test_full_size_config5_call_on_the_dma_staged_fp32_gram():
+    """BASELINE config 5 at full size (C2 with an fp32 Jacobian, fp64 products and sums): the steady-state call takes the DMA-staged Gram over
+    sample pairs (csrc/gram.hip::gram_w32_kernel); S0 v = J^T (J v) / N - m (m . v) on the stored fp32 Jacobian (widened), the same step
+    with the register-staged loop (VMCPDE_GRAM_F32_DMA=0) gives the same S to a few sqrt(N) ulp and the same update to 1e-9 |F| as the
+    matrix sees it, and the step is reproducible bit for bit."""
+    import os
+    runs = {}
+    for mode in ("1", "0", "1"):
+        os.environ["VMCPDE_GRAM_F32_DMA"] = mode
+        try:
+            vs, tp, out = _full_size_call(2, (21, 21), 65536, "advection_hamiltonian_wDiss", 0.1, jacobian_dtype=torch.float32)
+        finally:
+            os.environ.pop("VMCPDE_GRAM_F32_DMA", None)
+        assert vs.numParameters == 4213 and tp._uncentred_ok
+        for upd, resid, info, err in out:
+            assert torch.isfinite(upd).all() and info == 0 and resid < 1e-8 and 0.0 <= err < 1.0
+        runs.setdefault(mode, []).append((out[-1][0], tp.S0.clone(), tp.F0.clone()))
+        if mode == "1" and len(runs["1"]) == 1:
+            z = tp._lazy
+            P, n = z["P"], z["n"]
+            assert z["JT"].dtype == torch.float32
+            g = torch.Generator(device=DEV).manual_seed(3)
+            v = torch.randn(P, generator=g, dtype=torch.float64, device=DEV)
+            J = z["JT"][:P, :n].double()
+            ref = J @ (J.T @ v) / n - z["mean"] * (z["mean"] @ v)
+            assert float(torch.linalg.norm(tp.S0 @ v - ref) / torch.linalg.norm(ref)) < 1e-10
+        del vs, tp
+    (u1, S1, F1), (u1b, S1b, F1b) = runs["1"]
+    u0, S0, F0 = runs["0"][0]
+    assert torch.equal(u1, u1b) and torch.equal(S1, S1b)                              # reproducible
+    assert torch.equal(F1, F0) and not torch.equal(S1, S0)                           # (the same moments pass; another Gram loop)
+    d = torch.sqrt(torch.diagonal(S0).clamp_min(0))
+    scale = torch.outer(d, d).clamp_min(1e-300)
+    assert float(((S1 - S0).abs() / scale).max()) < 4e-16 * 256 + 1e-13             # (a few sqrt(65 536) ulp of sqrt(S_pp S_qq); centring cancels a little)
+    nF = float(torch.linalg.norm(F0))
+    assert float(torch.linalg.norm(S0 @ (u1 - u0))) < 1e-9 * nF
+
+
+def test_full_size_reference_default_call_is_reproducible_and_consistent():
+    """`TDVP()` exactly as the reference constructs it at the headline size (P = 4213, 65 536 samples): the rank-revealing engine with the own
+    tridiagonalisation + stedc + back-transformation core and the batched Householder chain.  Two independent runs give the same (ev, update)
+    bit for bit (no atomics anywhere: every rank of a sharded run must form the same update); S V = V diag(ev) on the Ritz modes; snr from
+    the Ritz vectors is finite, zero exactly on the null modes."""
+    runs = []
+    for _ in range(2):
+        vs, tp, out = _full_size_call(2, (21, 21), 65536, "advection_hamiltonian_wDiss", 0.1, tdvp_kwargs={})
+        assert tp.spectralInfo["engine"] == "lowrank" and tp.spectralInfo["core"].startswith("sytrd(own)"), tp.spectralInfo
+        snr = tp.snr
+        runs.append((out[-1][0], tp.ev.clone(), snr.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    ev, V = tp.ev, tp.V
+    ritz = ev != 0
+    lmax = float(ev[-1])
+    r = int(ritz.sum())
+    assert 100 < r <= 256 and bool((ev[1:] >= ev[:-1]).all())
+    Vr = V[:, ritz]
+    assert float(torch.linalg.norm(tp.S0 @ Vr - Vr * ev[ritz])) < 1e-11 * lmax * np.sqrt(r)
+    assert float((Vr.T @ Vr - torch.eye(r, dtype=torch.float64, device=DEV)).abs().max()) < 1e-13
+    assert bool(torch.isfinite(snr).all()) and not snr[~ritz].any() and int((snr[ritz] > 0).sum()) >= r - 2
 
 
 def test_full_size_step_is_bitwise_reproducible():
