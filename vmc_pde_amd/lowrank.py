@@ -327,11 +327,18 @@ class LowRankRoutes:
             wv, W = torch.linalg.eigh(T)                           # r x r (rocSOLVER)
         self.spectralInfo["core"] = {"jacobi": "jacobi", "tridiag": "sytrd(own)+stedc+back-transform(own)"}.get(core, "syevd")
         U = Q1 @ W
-        ev, V = self._lowrank_assemble(Y, Xn, U, wv, r, P, device)
-        # what rhoVar / snr need (tdvp.py:68-71): only the r Ritz vectors carry variance -- a vector with v^T S v = 0 is orthogonal to
-        # every sample's centred gradient -- so the N x P x P work of the reference shrinks to one r x P x N product (TDVP.rhoVar)
-        self._ritz = dict(U=U, wv=wv, r=r, P=P)
-        return ev, V
+        # Ascending order: the (few, round-off) negative Ritz values, the P - r zeros of the complement, the positive Ritz values -- as
+        # device-side positions, so that nothing here waits for the host.  Everything a call needs of the eigenbasis lives in the r Ritz
+        # vectors: V^T F vanishes on the complement (F is a combination of centred gradients, every one of them orthogonal to a vector with
+        # v^T S v = 0), the pseudo-inverse gives those modes the coefficient 0 (tdvp.py:82), and rhoVar / snr vanish there (TDVP.rhoVar).
+        # The P x (P - r) complement block of V (one more P x P x r product, 0.25 ms at the headline size) is therefore formed only when
+        # somebody reads `tdvp.V` -- the reference's driver never does (main.py:157-209 stores ev and snr).
+        pos = torch.arange(r, device=device) + (P - r) * (wv >= 0)
+        ev = torch.zeros(P, dtype=global_defs.tReal, device=device)
+        ev[pos] = wv
+        self._ritz = dict(U=U, wv=wv, r=r, P=P, pos=pos)
+        self._V_lazy = lambda: self._lowrank_assemble(Y, Xn, U, wv, r, P, device)[1]
+        return ev, None
 
     # ---- the r x r core: which eigensolver ---------------------------------------------------------------------------------
     def _core_choice(self, r):

@@ -153,6 +153,7 @@ class TDVP(LowRankRoutes):
         self._lazy = None
         self._SExp = self._rhoVar = self._snr = self._S = None
         self.S0 = None
+        self._V = self._V_lazy = None
         self.ev = self.V = self.VtF = None
         self._ratio_host = self._ratio_event = None
         self._ratio_prev = None
@@ -450,6 +451,20 @@ class TDVP(LowRankRoutes):
         return out[:P, :P]
 
     @property
+    def V(self):
+        """tdvp.py:59-64: the eigenvectors of S (columns, ascending eigenvalues).  After the rank-revealing decomposition the P - r columns
+        of the null space are formed on first access (lowrank.py: a call itself only needs the r Ritz vectors)."""
+        if self._V is None and self._V_lazy is not None:
+            with torch.cuda.device(self._ritz["U"].device):
+                self._V = self._V_lazy()
+            self._V_lazy = None
+        return self._V
+
+    @V.setter
+    def V(self, value):
+        self._V, self._V_lazy = value, None
+
+    @property
     def S(self):
         """tdvp.py:48-51: S0, or S0 + diagonalShift*diag(S0)."""
         if self._S is None:
@@ -515,7 +530,7 @@ class TDVP(LowRankRoutes):
     def rhoVar(self):
         """tdvp.py:68-70: Var_n[(E~ O~ V)_nk] = diag(V^T G V) - VtF^2 with G = <E~^2 O~ O~^T> (no N x P GEMM)."""
         if self._rhoVar is None:
-            if self.V is None:
+            if self.ev is None:
                 raise RuntimeError("rhoVar/snr need the eigenbasis: use solver='eigh'")
             rz = getattr(self, "_ritz", None)
             if rz is not None and self._lazy["JT"].dtype == global_defs.tReal and os.environ.get("VMCPDE_RHOVAR_LOWRANK", "1") != "0":
@@ -539,13 +554,15 @@ class TDVP(LowRankRoutes):
                                "attributes before calling psi(...), psi.hessian or psi.evaluate again")
         P, n, r = z["P"], z["n"], rz["r"]
         U, wv = rz["U"], rz["wv"]
+        pos = rz.get("pos")
         Jv = z["JT"][:P, :n]                                          # P x n view of the parameter-major Jacobian (row pitch ldj)
         Z = U.T @ Jv                                                  # r x n
         Z -= (U.T @ z["mean"])[:, None]
         Z *= (z["e"] - z["Emean"])[None, :]
         second = (Z * Z).sum(1)                                       # sum_n E~_n^2 (O~_n . u_k)^2 over this rank's samples
         mpi.allreduce_sum_(second)
-        pos = torch.arange(r, device=U.device) + (P - r) * (wv >= 0)   # the Ritz columns of V: negatives first, the positives behind the zeros
+        if pos is None:
+            pos = torch.arange(r, device=U.device) + (P - r) * (wv >= 0)   # the Ritz columns of V: negatives first, the positives behind the zeros
         out = torch.zeros(P, dtype=global_defs.tReal, device=U.device)
         out[pos] = second / z["Ntot"] - self.VtF[pos] ** 2
         return out
@@ -554,7 +571,7 @@ class TDVP(LowRankRoutes):
     def snr(self):
         """tdvp.py:71."""
         if self._snr is None:
-            if self.V is None:
+            if self.ev is None:
                 raise RuntimeError("rhoVar/snr need the eigenbasis: use solver='eigh'")
             rho = self.rhoVar
             snr = torch.sqrt(torch.abs(self._lazy["Ntot"] * (self.VtF * self.VtF) / rho))
@@ -630,6 +647,7 @@ class TDVP(LowRankRoutes):
             on_device = True
         self.spectralInfo = None
         self._ritz = None                # (set by the rank-revealing engine: what rhoVar / snr need of it)
+        self._V = self._V_lazy = None
         gated = self.spectralEngine == "auto" and getattr(self, "_lowrank_gate_svdtol", None) is not None and \
             float(self.svdTol) <= self._lowrank_gate_svdtol      # (rejected by the svdTol gate before: only a LARGER svdTol can pass it)
         lowrank = on_device and self.spectralEngine != "dense" and not (self.diagonalShift > 1e-10) and self._lowrank_tol() is not None and \
@@ -646,7 +664,9 @@ class TDVP(LowRankRoutes):
                     res = None
                     self.spectralInfo = dict(self.spectralInfo or {}, engine="lowrank", converged=False, error=str(exc)[:80])
             if res is not None:
+                lazy = self._V_lazy                       # (set by the engine; the setter of V clears it)
                 self.ev, self.V = res
+                self._V_lazy = lazy
                 done = True
             elif self.spectralEngine == "auto":
                 if (self.spectralInfo or {}).get("rejected"):
@@ -674,6 +694,15 @@ class TDVP(LowRankRoutes):
             self.ev = torch.from_numpy(tmpEv).to(F.device)
             self.V = torch.from_numpy(tmpV).to(F.device)
             self.spectralInfo = dict(self.spectralInfo or {}, engine="host")       # (the reference's default: LAPACK on the host)
+        if self._V is None and self._V_lazy is not None:
+            # the rank-revealing engine: V^T F from the r Ritz vectors, exact zeros on the null modes (lowrank.py)
+            rz = self._ritz
+            self.VtF = torch.zeros(P, dtype=global_defs.tReal, device=F.device)
+            vr = torch.empty(rz["r"], dtype=global_defs.tReal, device=F.device)
+            with torch.cuda.device(F.device):
+                nat.call("vmcpde_gemv", nat.ptr(rz["U"]), rz["U"].stride(0), P, rz["r"], 1, nat.ptr(F.contiguous()), nat.ptr(vr), nat.stream())   # tdvp.py:66
+            self.VtF[rz["pos"]] = vr
+            return
         self.VtF = torch.empty(P, dtype=global_defs.tReal, device=F.device)
         Vc = self.V.contiguous()
         self.V = Vc
@@ -729,7 +758,12 @@ class TDVP(LowRankRoutes):
                 snr = self.snr.contiguous() if self.useSNR else None                                   # tdvp.py:87-89
                 nat.call("vmcpde_pinv_coeffs", nat.ptr(self.ev), nat.ptr(self.VtF), nat.ptr(snr), P, float(self.svdTol),
                          float(self.snrTol), nat.ptr(coef), nat.stream())                              # tdvp.py:82-85
-                nat.call("vmcpde_gemv", nat.ptr(self.V), P, P, P, 0, nat.ptr(coef), nat.ptr(update), nat.stream())   # tdvp.py:91
+                if self._V is None and self._V_lazy is not None:       # (null modes carry the coefficient 0: only the Ritz vectors count)
+                    rz = self._ritz
+                    cr = coef[rz["pos"]].contiguous()
+                    nat.call("vmcpde_gemv", nat.ptr(rz["U"]), rz["U"].stride(0), P, rz["r"], 0, nat.ptr(cr), nat.ptr(update), nat.stream())   # tdvp.py:91
+                else:
+                    nat.call("vmcpde_gemv", nat.ptr(self.V), P, P, P, 0, nat.ptr(coef), nat.ptr(update), nat.stream())   # tdvp.py:91
             # residual and TDVP error (tdvp.py:93-94) from one S0 u: the shifted S adds (diagonalShift diag(S0) + floor) u
             S0u = torch.empty(P, dtype=global_defs.tReal, device=device)
             out = torch.empty(4, dtype=global_defs.tReal, device=device)
