@@ -22,6 +22,8 @@ SOLVERS = (("chol", dict(diagonalShift=1e-5, solver="cholesky")), ("eigh", dict(
            ("chol-overlap", dict(diagonalShift=1e-5, solver="cholesky", overlapAllreduce=True)),
            ("chol-lowrank", dict(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine="lowrank")),
            ("eigh-lowrank", dict(solver="eigh", spectralEngine="lowrank")),
+           # ... with the SNR-regularised pseudo-inverse: rhoVar comes from the r Ritz vectors, its sample sums all-reduced inside the solve
+           ("eigh-lowrank-snr", dict(solver="eigh", spectralEngine="lowrank", useSNR=True)),
            # the matrix-free experiment: no S at all; moments, every 32-column panel and every S0 v are summed over the ranks
            ("chol-matrixfree", dict(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", matrixFree=True)),
            # the int8 S-build experiment: its heavy-tail figure is all-reduced (max) so that every rank decides alike
