@@ -256,6 +256,7 @@ def cpu_baseline_full(theta_cpu, inds_up, inds_down, workload="C2", slab=4096):
     if blas_cap is not None:
         blas_cap.restore_original_limits()
     return {"value": 1.0 / total, "unit": "TDVP steps/s", "cores": cores, "kind": "port", "workload": workload,
+            "host_cpu_count": os.cpu_count() or 1, "affinity_count": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
             "sample": f"reference algorithm as written on torch/numpy fp64 CPU, ONE full step at N={n_full}, P={P}: nothing extrapolated",
             "seconds_per_step": total, "parts_seconds": parts, "solver_residual": resid, "rank_1e-9": int((rel > 1e-9).sum()),
             "note": "an eager torch.func port of the reference's algorithm, not XLA-jitted JAX-CPU (jax is not installable here): "
@@ -272,15 +273,12 @@ def cpu_baseline(theta_cpu, inds_up, inds_down, workload="C2"):
     from oracle import vmc_oracle as O
     w = WORKLOADS[workload]
     dim, hidden, n_full = w["dim"], w["hidden"], w["n_samp"]
-    # threads actually used: the cores this process may run on, capped at the GPU box's 16-core share per GPU
-    # (an OpenMP pool as wide as the host's 256 hardware threads makes the oracle's many small ops far slower)
-    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
-    torch.set_num_threads(cores)
-    try:                                           # numpy's OpenBLAS pool is separate from torch's: same thread cap
-        from threadpoolctl import threadpool_limits
-        blas_cap = threadpool_limits(limits=cores)
-    except ImportError:
-        blas_cap = None
+    # threads actually used ("all host cores, count printed"): the host's count and this process's affinity are recorded, and the
+    # pool width is the FASTEST of a sweep over 8 / 16 / 32 / 64 threads (those the affinity allows) on the largest autodiff point -- the
+    # dominant part of the step.  An OpenMP pool as wide as the host's 256 hardware threads makes the oracle's many small ops slower,
+    # not faster; the sweep in the record shows where that sets in on this host.
+    host_cpus = os.cpu_count() or 1
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cpus
     spec = O.NetSpec(dim=dim, inds_up=inds_up, inds_down=inds_down, intmediate=hidden, offset=list(w["offset"]))
     P = O.num_parameters(spec)
     vo = O.VarStateOracle(spec, theta_cpu)
@@ -290,6 +288,26 @@ def cpu_baseline(theta_cpu, inds_up, inds_down, workload="C2"):
     big = P > 8000
     n_gemm = 2048 if big else 4096
     ad_counts = (512, 1024, 2048) if big else (1024, 2048, 4096)
+    candidates = sorted({t for t in (8, 16, 32, 64) if t <= affinity} | ({affinity} if affinity < 8 else set()))
+    sweep = {}
+    if len(candidates) > 1:
+        zs = O.latent_from_normals(spec, theta_cpu, torch.randn(ad_counts[-1], dim, generator=g, dtype=torch.float64))
+
+        def autodiff_sweep():
+            x, _ = vo.flow_sample(zs)
+            return eo(vo, x, 0.0)
+        for t in candidates:
+            torch.set_num_threads(t)
+            sweep[t] = _timed(autodiff_sweep, 1)[0]
+        cores = min(sweep, key=sweep.get)
+    else:
+        cores = candidates[0]
+    torch.set_num_threads(cores)
+    try:                                           # numpy's OpenBLAS pool is separate from torch's: same thread cap
+        from threadpoolctl import threadpool_limits
+        blas_cap = threadpool_limits(limits=cores)
+    except ImportError:
+        blas_cap = None
 
     # (1) sampling + Eloc + Jacobian: vmap(grad) + the jacrev(jacfwd) Hessian pass (var_state.py:31-32, evolutionEq.py:107-119)
     ad = {}
@@ -352,6 +370,9 @@ def cpu_baseline(theta_cpu, inds_up, inds_down, workload="C2"):
     eigh_note = (f"eigh at the full P={P}" if not big else
                  f"eigh NOT RUN at P={P}: timed at P/4={p_eigh} ({t_eigh_meas[0]:.1f}s) and scaled by (P/{p_eigh})^3 = {eigh_scale:.0f}")
     return {"value": 1.0 / total, "unit": "TDVP steps/s", "cores": cores, "kind": "port", "workload": workload,
+            "host_cpu_count": host_cpus, "affinity_count": affinity,
+            "thread_sweep": {"part": f"autodiff J + Hessian at N={ad_counts[-1]} (1 warm-up + 1 timed call per setting)",
+                             "seconds_by_threads": {str(t): v for t, v in sweep.items()}, "picked": cores},
             "sample": (f"reference algorithm as written on torch/numpy fp64 CPU, each part 1 warm-up + {reps} timed repetition(s) (median): "
                        f"autodiff J + Hessian at N={list(ad_counts)} -> fitted line {icpt:.2f}s + {slope * 1e3:.3f}ms/sample -> {t_ad_full:.1f}s at "
                        f"N={n_full} (scaling the largest point alone would give {t_ad_naive:.1f}s), S0 and SExp Gram GEMMs + EO@V at N={n_gemm} "
@@ -369,7 +390,7 @@ def cpu_baseline(theta_cpu, inds_up, inds_down, workload="C2"):
                              "what": "same port without the reference's redundant work (one centred Gram GEMM, no SExp, no EO@V)"},
             "note": "an eager torch.func port of the reference's algorithm, not XLA-jitted JAX-CPU (jax is not installable here): "
                     "a reported baseline, not a comparison with the reference's own runtime",
-            "checked_against": "--cpu-baseline full: ONE step of the same port at the real N = 65 536 took 47.97 s on 16 cores where this "
+            "checked_against": "--cpu-baseline full: ONE step of the same port at the real N = 65 536 took 47.97 s on 16 threads where this "
                                "extrapolation said 46.9 s (profiles/r04_run1_bench_cpu_full.json)" if workload == "C2" else None}
 
 

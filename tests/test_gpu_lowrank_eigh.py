@@ -838,7 +838,9 @@ def test_tridiag_core_route_against_the_library_eigh(n):
     assert tp._core_choice(n) == "tridiag"
     w = {}
     wv, W = tp._core_eigh_tridiag(w, A, n, A.device)
+    W = W.clone()                                    # (W is a view of the reused workspace: keep the first call's values, not an alias)
     wv2, W2 = tp._core_eigh_tridiag(w, A, n, A.device)
+    assert W.data_ptr() != W2.data_ptr()
     assert torch.equal(wv, wv2) and torch.equal(W, W2)
     ev, _ = torch.linalg.eigh(A)
     lmax = float(ev[-1])
@@ -849,6 +851,40 @@ def test_tridiag_core_route_against_the_library_eigh(n):
     assert tp._core_choice(n) == "tridiag" and int(tp._tridiag["host"][0]) == 0      # (reads the status word of the call before)
     assert tp._core_choice(257) == "library" and tp._core_choice(2) == "library"
     assert V.TDVP(coreEigensolver="library")._core_choice(n) == "library"
+
+
+def test_a_failed_stedc_rejects_the_step_it_belongs_to(monkeypatch):
+    """The status word of the core's tridiagonal eigensolver is part of the step's health record: a non-zero word makes `check()` raise for THAT
+    step (as torch.linalg.eigh raises on a non-zero info) and sends later calls to the library core -- it is not merely a warning one call later."""
+    import vmc_pde_amd as V
+    from vmc_pde_amd import rocsolver
+    from helpers import make_spec, random_theta, make_varstate, FixedSampler
+    if not rocsolver.available():
+        pytest.skip("rocSOLVER's stedc is not resolvable")
+    dim, N = 2, 4096
+    spec = make_spec(dim, 4, (3, 3), offset=[0.5, -0.5])           # (P = 181: any rank fits the own core)
+    th = random_theta(spec, 3)
+    z = torch.randn(N, dim, generator=torch.Generator().manual_seed(1), dtype=torch.float64).cuda()
+    vs = make_varstate(spec, th, sampler=FixedSampler(z))
+    eq = V.EvolutionEquation(dim=dim, name="advection_hamiltonian_wDiss")
+    tp = V.TDVP(solver="eigh", spectralEngine="lowrank", svdTol=1e-6)
+    upd, _ = tp(th.cuda(), 0.0, vs, eq, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+    tp.check()                                                         # a healthy call passes, on the own core
+    assert tp.spectralInfo["core"].startswith("sytrd(own)")
+    real = rocsolver.stedc
+
+    def failing(D, E, Z, info):
+        real(D, E, Z, info)
+        info.fill_(3)
+    monkeypatch.setattr(rocsolver, "stedc", failing)
+    upd, _ = tp(th.cuda(), 0.0, vs, eq, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+    with pytest.raises(FloatingPointError, match="stedc"):
+        tp.check()
+    monkeypatch.setattr(rocsolver, "stedc", real)
+    upd2, _ = tp(th.cuda(), 0.0, vs, eq, nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+    tp.check()
+    assert tp.spectralInfo["core"] == "syevd"                          # the core stays on the library solver afterwards
+    assert float((upd2 - upd).abs().max()) < 1e-8 * float(upd.abs().max())
 
 
 @pytest.mark.parametrize("P,r,ldl", [(4213, 256, 4224), (300, 7, 320), (65, 64, 128), (16181, 384, 16192)])

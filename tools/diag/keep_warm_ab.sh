@@ -2,6 +2,10 @@
 # Round 5 prototype A/B: a flag-stopped compute-only kernel (tools/microbench/keep_warm.hip) on a side stream beside the solve's dependent
 # chains, so that the chip's power state does not ramp down before the next S-build (tools/diag/gram_between_phases_probe.py: 8 ms of idling
 # cost the next Gram 1.8 ms).  VMCPDE_KW = mode(0 bf16 MFMA, 1 fp32 VALU),burst,sleep16,workgroups,threads
+#
+# NOT REPRODUCIBLE FROM HEAD: the hook in TDVP.solve that read VMCPDE_KW and launched libkeepwarm.so's kernel was a prototype and was
+# removed with the negative result (spectral loop -2.6 %, nothing elsewhere); no code in the tree reads VMCPDE_KW any more, so every run
+# below now measures the same thing.  The script and profiles/r05_keep_warm_ab.txt are kept as the record of that removed experiment.
 R=${GRAFT_REPO_ROOT:-$PWD}
 run() { echo "== $ARGS $*"; env "$@" python3 $R/bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-beside ${ARGS} 2>/dev/null | python3 -c "
 import json,sys

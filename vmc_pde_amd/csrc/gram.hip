@@ -399,7 +399,10 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
   VMC_REQUIRE(!f32blocks || (ldj % 4) == 0, "jt_f32 = 2 needs ldj to be a multiple of 4 (16-byte rows)");
   // fp32 storage, fp64 products and sums, uncentred and unweighted: the DMA-staged loop over sample pairs (VMCPDE_GRAM_F32_DMA=0: the
   // register-staged loop, which orders its sums like the fp64 kernel and is bit-identical to it on fp32-valued data)
-  const bool w32 = jt_f32 == 1 && !c && !w && (ldj % 4) == 0 && (reinterpret_cast<uintptr_t>(JT) & 15) == 0 && env_int("VMCPDE_GRAM_F32_DMA", 1) != 0;
+  // (an odd sample count would let the pad float behind the last sample into the sums: vmcpde.h promises zero padding only for jt_f32 = 2,
+  // so those calls keep the register-staged loop, which reads exactly n_samples entries per row)
+  const bool w32 = jt_f32 == 1 && !c && !w && (ldj % 4) == 0 && (n_samples % 2) == 0 && (reinterpret_cast<uintptr_t>(JT) & 15) == 0 &&
+                   env_int("VMCPDE_GRAM_F32_DMA", 1) != 0;
   // in pairs of samples for the fp32-block variant (an odd N relies on the zero padding of the rows)
   GramPlan g = (f32blocks || w32) ? make_plan(P, (n_samples + 1) / 2, SLOTS_STAGED) : make_plan(P, n_samples, dma ? SLOTS_DMA : SLOTS_STAGED);
   const int64_t need = (int64_t)g.nsplit * g.ntiles * TILE * TILE * (int64_t)sizeof(double);

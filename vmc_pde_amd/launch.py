@@ -58,22 +58,40 @@ def _signal_rank(p, sig):
             pass
 
 
+def _peek(p):
+    """Exit status of rank `p` WITHOUT reaping it (None while it runs): a reaped leader frees its pid, and with it the id of its process group,
+    for re-use -- a later SIGKILL to that group could then hit an unrelated one.  Ranks stay zombies until `_reap_all` has signalled their
+    groups; only then are they waited for."""
+    if p.returncode is not None:
+        return p.returncode
+    try:
+        info = os.waitid(os.P_PID, p.pid, os.WEXITED | os.WNOHANG | os.WNOWAIT)
+    except ChildProcessError:                         # (reaped elsewhere: Popen knows the code)
+        return p.poll()
+    if info is None:
+        return None
+    return info.si_status if info.si_code == os.CLD_EXITED else -info.si_status
+
+
+def _reap_all(procs):
+    """SIGKILL to every rank's process group while its leader is still unreaped (the group id cannot have been recycled), then reap."""
+    for p in procs:
+        if p.returncode is None:
+            _signal_rank(p, signal.SIGKILL)
+    for p in procs:
+        p.wait()
+
+
 def _stop(procs, grace=10.0):
     """End the ranks still running: SIGTERM to each rank's process group, SIGKILL after `grace` seconds; the groups of ranks that have
-    already exited get the SIGKILL too (a helper process a rank left behind must not keep a GPU)."""
-    live = [p for p in procs if p.poll() is None]
+    already exited get the SIGKILL too (a helper process a rank left behind must not keep a GPU) -- all of it before any rank is reaped."""
+    live = [p for p in procs if _peek(p) is None]
     for p in live:
         _signal_rank(p, signal.SIGTERM)
     t_end = time.monotonic() + grace
-    for p in live:
-        try:
-            p.wait(max(0.0, t_end - time.monotonic()))
-        except subprocess.TimeoutExpired:
-            pass
-    for p in procs:
-        _signal_rank(p, signal.SIGKILL)
-    for p in live:
-        p.wait()
+    while any(_peek(p) is None for p in live) and time.monotonic() < t_end:
+        time.sleep(0.02)
+    _reap_all(procs)
 
 
 class LauncherSignalled(BaseException):
@@ -143,7 +161,7 @@ def run_ranks(argv, world: int, *, port=None, timeout=None, base_env=None, poll=
         reader.start()
         t_end = None if timeout is None else time.monotonic() + float(timeout)
         while True:
-            codes = [p.poll() for p in procs]
+            codes = [_peek(p) for p in procs]                                  # (no rank is reaped before its group has been signalled)
             bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
             if bad:
                 rc = bad[0][1] if bad[0][1] > 0 else 128 - bad[0][1]          # (a rank ended by signal s: 128 + s, as a shell reports it)
@@ -162,15 +180,25 @@ def run_ranks(argv, world: int, *, port=None, timeout=None, base_env=None, poll=
                 break
             time.sleep(poll)
     except LauncherSignalled as ex:
-        log(f"launch: signal {ex.signum} received; stopping {sum(p.poll() is None for p in procs)} running ranks")
+        log(f"launch: signal {ex.signum} received; stopping {sum(_peek(p) is None for p in procs)} running ranks")
         stop_grace = min(stop_grace, 5.0)
         raise
     finally:
         try:
             if not clean:
                 _stop(procs, stop_grace)
+            else:
+                _reap_all(procs)          # (every rank exited 0: what it may have left behind in its group goes, then the ranks are reaped)
             if reader is not None:
-                reader.join()             # (all ranks have exited, so the pipe is at end of file: the whole record is read before we return)
+                # all ranks have exited, so the pipe is normally at end of file and the whole record is read before we return; a helper that
+                # inherited rank 0's stdout and left its session (setsid) can still hold the pipe open -- do not wait for it for ever
+                reader.join(5.0)
+                if reader.is_alive():
+                    log("launch: rank 0's stdout is still held open by a process outside its group; returning what was read")
+                    try:
+                        procs[0].stdout.close()
+                    except Exception:
+                        pass
         finally:
             for s, h in previous.items():
                 signal.signal(s, h)

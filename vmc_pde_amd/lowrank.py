@@ -55,6 +55,7 @@ LOWRANK_CHOL_MIN_P = 4096   # choleskyEngine="auto": the low-rank solve from thi
                             #   read in the step; with one (planning mode) 2.5 ms.  P = 16 181: 7 against 38 ms
 LOWRANK_SOLVE_RHO = 1e-4    # low-rank Cholesky solve: largest trace(R) / min D accepted (the contraction factor of its iterative refinement)
 LOWRANK_RETRY_AFTER = 50    # "auto": calls on the dense path after one whose rank exceeded the cap, before the next attempt
+LOWRANK_GATE_RETRY_AFTER = 8 * LOWRANK_RETRY_AFTER   # ... after one the svdTol gate rejected (the spectrum moves along a trajectory, slowly)
 
 
 def _round_up(v, m):
@@ -352,9 +353,9 @@ class LowRankRoutes:
         if want in ("auto", "tridiag"):
             from . import rocsolver
             st = getattr(self, "_tridiag", None)
-            if st is not None and st["event"] is not None:          # the previous call's stedc status, read one call later
-                st["event"].synchronize()
-                st["event"] = None
+            if st is not None and st["event"] is not None and st.get("pending"):   # (a status nobody's guard has looked at yet, e.g. a direct
+                st["event"].synchronize()                                          # use of the engine without TDVP.solve: read it here)
+                st["event"], st["pending"] = None, False
                 if int(st["host"][0]) != 0:
                     import warnings
                     warnings.warn(f"stedc reported {int(st['host'][0])} unconverged block(s) on the core of the spectral solve; using the library "
@@ -367,7 +368,10 @@ class LowRankRoutes:
     def _core_eigh_tridiag(self, w, T, r, device):
         """(wv ascending, W) with T W = W diag(wv): T = Q tridiag(d, e) Q^T by `vmcpde_sytrd_small` (one workgroup, the lower triangle in
         registers), the tridiagonal eigenproblem by rocSOLVER's divide & conquer (a library call: vmc_pde_amd/rocsolver.py), W = Q Z by
-        `vmcpde_apply_reflectors`.  Nothing synchronises: stedc's status word is copied to the host and read by the next call."""
+        `vmcpde_apply_reflectors`.  Nothing synchronises here: stedc's status word is copied to the host behind the call and is part of the
+        step's health record -- `TDVP._check_guard` (run by `check()`, by `__call__` with observables, and at the top of the next right-hand
+        side) rejects the step with FloatingPointError when it is non-zero and switches the core to the library solver, as
+        torch.linalg.eigh raises on a non-zero info.  The returned W is backed by the workspace td["Z"] (overwritten by the next call)."""
         from . import rocsolver
         st = getattr(self, "_tridiag", None)
         if st is None:
@@ -388,7 +392,9 @@ class LowRankRoutes:
         st["host"].copy_(td["info"], non_blocking=True)
         st["event"] = torch.cuda.Event()
         st["event"].record()
+        st["pending"] = True                     # part of THIS step's acceptance: TDVP._check_guard reads the word with the solve's health record
         nat.call("vmcpde_apply_reflectors", nat.ptr(td["V"]), nmax, nat.ptr(td["tau"]), r, nat.ptr(Z), r, r, nat.stream())
+        # (W is a view of the reused workspace td["Z"]: valid until the next call of this method -- `_eigh_lowrank` consumes it at once, U = Q1 W)
         return td["D"][:r].clone(), Z.t()
 
     # ---- the r x r core: one-sided Jacobi on the triangular factor (csrc/jacobi.hip) ------------------------------------
@@ -487,7 +493,8 @@ class LowRankRoutes:
         """The static plan of the Cholesky route (rmax, block steps, refinements, the previous call's rank / done / step count) and the
         pivot list with its length -- the candidates of the next factorisation (`vmcpde_lowrank_hint`).  With them the first call of a
         resumed run IS the next static call of the interrupted one, bit for bit."""
-        out = {"last_rank": int(self._lowrank_last_rank), "chol_backoff": int(self._chol_backoff), "lowrank_backoff": int(self._lowrank_backoff)}
+        out = {"last_rank": int(self._lowrank_last_rank), "chol_backoff": int(self._chol_backoff), "lowrank_backoff": int(self._lowrank_backoff),
+               "gate_svdtol": getattr(self, "_lowrank_gate_svdtol", None), "gate_retry": int(getattr(self, "_lowrank_gate_retry", 0))}
         w = next(iter(self._buf_lr.values())) if getattr(self, "_buf_lr", None) else None
         if w is not None:
             torch.cuda.current_stream(w["piv"].device).synchronize()         # (the asynchronous host copies of the last call have landed)
@@ -504,6 +511,7 @@ class LowRankRoutes:
     def _lowrank_load_state(self, st):
         self._lowrank_last_rank = int(st.get("last_rank", 0))
         self._chol_backoff, self._lowrank_backoff = int(st.get("chol_backoff", 0)), int(st.get("lowrank_backoff", 0))
+        self._lowrank_gate_svdtol, self._lowrank_gate_retry = st.get("gate_svdtol"), int(st.get("gate_retry", 0))
         self._buf_lr = {}
         self._lr_restore = st.get("factor")
         plan = st.get("chol_static")

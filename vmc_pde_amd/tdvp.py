@@ -35,7 +35,7 @@ from . import mpi_wrapper as mpi
 from .gram_operator import GramOperator, _VecTimesGram  # noqa: F401
 from .lowrank import (LowRankRoutes, StaticPlanOutdated, _long_k_product, _round_up,  # noqa: F401
                       LOWRANK_MIN_P, LOWRANK_RANK_CAP, LOWRANK_RANK_DIVISOR, LOWRANK_TOL, LOWRANK_TRACE_BOUND, LOWRANK_SVDTOL_FRACTION,
-                      LOWRANK_CHOL_MIN_P, LOWRANK_SOLVE_RHO, LOWRANK_RETRY_AFTER)
+                      LOWRANK_CHOL_MIN_P, LOWRANK_SOLVE_RHO, LOWRANK_RETRY_AFTER, LOWRANK_GATE_RETRY_AFTER)
 
 
 F32_BLOCK_MIN_SHIFT = 1e-4   # smallest diagonalShift the fp32-block Gram is allowed with (see TDVP._gram)
@@ -613,6 +613,17 @@ class TDVP(LowRankRoutes):
         self._guard_pending = False
         resid, pinned = float(self._guard_host[0]), int(self._guard_host[2])
         if not self._guard_chol:
+            # the spectral core's stedc status (lowrank.py::_core_eigh_tridiag): its copy was queued before this record's, so it has landed.
+            # A non-zero word means (ev, U) -- hence VtF and the update -- came from an unconverged decomposition: finite but wrong, so the
+            # step is rejected like torch.linalg.eigh rejects a non-zero info, and the core falls back to the library solver
+            st = getattr(self, "_tridiag", None)
+            if st is not None and st.get("pending"):
+                st["pending"], st["event"] = False, None
+                code = int(st["host"][0])
+                if code != 0:
+                    st["off"] = True
+                    raise FloatingPointError(f"the spectral solve's tridiagonal eigensolver (stedc) reported {code} unconverged block(s) ({when}): "
+                                             f"the update of that call is not trustworthy; later calls use the library eigensolver")
             if math.isnan(resid):
                 raise FloatingPointError(f"nan encountered in the TDVP update ({when})")
             return
@@ -648,8 +659,15 @@ class TDVP(LowRankRoutes):
         self.spectralInfo = None
         self._ritz = None                # (set by the rank-revealing engine: what rhoVar / snr need of it)
         self._V = self._V_lazy = None
+        # (rejected by the svdTol gate before: a LARGER svdTol passes at once; with the same one the attempt is repeated only after
+        # LOWRANK_GATE_RETRY_AFTER calls -- the gate compares the factorisation's remainder with svdTol x lambda_max of the CURRENT S, whose
+        # spectrum moves along a trajectory, so the rejection is long-lived but not permanent)
         gated = self.spectralEngine == "auto" and getattr(self, "_lowrank_gate_svdtol", None) is not None and \
-            float(self.svdTol) <= self._lowrank_gate_svdtol      # (rejected by the svdTol gate before: only a LARGER svdTol can pass it)
+            float(self.svdTol) <= self._lowrank_gate_svdtol
+        if gated and on_device:
+            self._lowrank_gate_retry = getattr(self, "_lowrank_gate_retry", LOWRANK_GATE_RETRY_AFTER) - 1
+            if self._lowrank_gate_retry <= 0:
+                gated, self._lowrank_gate_svdtol = False, None
         lowrank = on_device and self.spectralEngine != "dense" and not (self.diagonalShift > 1e-10) and self._lowrank_tol() is not None and \
             (self.spectralEngine == "lowrank" or (P >= LOWRANK_MIN_P and self._lowrank_backoff == 0 and not gated))
         if on_device and self.spectralEngine == "auto" and self._lowrank_backoff > 0:
@@ -670,9 +688,10 @@ class TDVP(LowRankRoutes):
                 done = True
             elif self.spectralEngine == "auto":
                 if (self.spectralInfo or {}).get("rejected"):
-                    # the svdTol gate: a property of (svdTol, this model's spectrum), not of the call -- the wasted factorisation would recur
-                    # at every retry for a cause that cannot change, so the attempt stays off until svdTol does
+                    # the svdTol gate: a property of (svdTol, this model's spectrum) rather than of the call -- the wasted factorisation would
+                    # recur at every retry, so the attempt stays off until svdTol is raised or LOWRANK_GATE_RETRY_AFTER calls have passed
                     self._lowrank_gate_svdtol = float(self.svdTol)
+                    self._lowrank_gate_retry = LOWRANK_GATE_RETRY_AFTER
                 else:
                     self._lowrank_backoff = LOWRANK_RETRY_AFTER    # rank above the cap: dense for the next calls
         if on_device and not done:
