@@ -349,6 +349,23 @@ int vmcpde_woodbury_project(const double* LT, int64_t ldl, int32_t P, int32_t r,
                             const double* u, double* y, double* t1, void* stream);
 int vmcpde_woodbury_combine(const double* LT, int64_t ldl, int32_t P, int32_t r, const double* D, const double* y, const double* t2,
                             const double* u, double* out, void* stream);
+/* ABI 7: what surrounds that application in a call on a static plan, so that the replicated part of a step holds no library GEMM, no framework
+ * elementwise launch and one device-to-host copy (tdvp.py:91-94 are three array expressions in the reference).
+ * prepare: D[p] = shift * diagS[p] + floor_dev[0] (floor_dev NULL: 0) for p < P, invD[p] = 1 / D[p] and 0 on the pad [P, ldl); rows k in
+ *          [state[0], rmax) of LT are zeroed (state[0] = the rank the factorisation just reached, read on the device: those rows still hold
+ *          an earlier call's columns and must be an identity block of G).  D: [dev] >= P, invD: [dev] ldl, LT: [dev] >= rmax x ldl.
+ * gram:    G = I + LT[:r] diag(invD) LT[:r]^T (r x r, both triangles; r a multiple of 64, ldl a multiple of 32) on the fp64 matrix pipe: 64 x 64
+ *          blocks of the lower triangle x chunks of 256 parameters as independent workgroups, chunk sums added in a fixed order (the same
+ *          bits on every rank).  workspace: vmcpde_woodbury_gram_workspace_bytes(ldl, r).
+ * gather_words: dst = the concatenation of n_src (<= 8) device arrays of counts[s] 8-byte words -- the health records of a call (residual
+ *          and pinned pivots, the factorisation's state and step count, the mean^2 / var figure) as ONE buffer for ONE asynchronous copy.
+ *          srcs / counts are HOST arrays (read during the call). */
+int vmcpde_woodbury_prepare(const double* diagS, double shift, const double* floor_dev, int32_t P, int64_t ldl, double* D, double* invD,
+                            double* LT, const int32_t* state, int32_t rmax, void* stream);
+int64_t vmcpde_woodbury_gram_workspace_bytes(int64_t ldl, int32_t r);
+int vmcpde_woodbury_gram(const double* LT, int64_t ldl, int32_t r, const double* invD, double* G, int64_t ldg, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+int vmcpde_gather_words(const void* const* srcs, const int32_t* counts, int32_t n_src, void* dst, void* stream);
 /* ABI 5: the r x r core of that decomposition (tdvp.py:57-64 on range(L)) without a library eigensolver.  One-sided Jacobi on the columns
  * of an r x r matrix C (r <= 1024): on return the columns are mutually orthogonal, C_out = U diag(sigma) with U the left singular vectors and
  * sigma the singular values of the input -- for C = R1 (the triangular factor of L = Q1 R1) the eigenvectors and the square roots of the
@@ -371,6 +388,14 @@ int vmcpde_jacobi_columns(double* CT, int32_t r, int32_t n_sweeps, int32_t* coun
 int32_t vmcpde_sytrd_small_max_n(void);
 int vmcpde_sytrd_small(const double* T, int64_t ldt, int32_t n, double* D, double* E, double* tau, double* V, int64_t ldv, void* stream);
 int vmcpde_apply_reflectors(const double* V, int64_t ldv, const double* tau, int32_t n, double* Zt, int64_t ldz, int32_t nvec, void* stream);
+/* ABI 7: the same decomposition for 256 < n <= vmcpde_sytrd_medium_max_n() = 384 (BASELINE C3's core has rank 263): the leading n - 256 Householder
+ * steps run as two launches each on a full symmetric copy of T in `workspace` (vmcpde_sytrd_medium_workspace_bytes(n); 0 for n <= 256, where the
+ * call IS vmcpde_sytrd_small), the trailing 256 x 256 block goes through the one-workgroup kernel.  Same outputs, same conventions; deterministic.
+ * vmcpde_apply_reflectors takes n <= 384 since ABI 7. */
+int32_t vmcpde_sytrd_medium_max_n(void);
+int64_t vmcpde_sytrd_medium_workspace_bytes(int32_t n);
+int vmcpde_sytrd_medium(const double* T, int64_t ldt, int32_t n, double* D, double* E, double* tau, double* V, int64_t ldv, void* workspace,
+                        int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -772,7 +772,7 @@ def test_rhovar_from_the_ritz_vectors_is_the_dense_formula(headline_net, monkeyp
         assert torch.equal(u_fast, u_dense)
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 65, 128, 129, 206, 255, 256])
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 65, 128, 129, 206, 255, 256, 257, 263, 320, 384])
 def test_own_tridiagonalisation_and_back_transformation_against_numpy(n):
     """vmcpde_sytrd_small / vmcpde_apply_reflectors (csrc/tridiag.hip): T = Q tridiag(d, e) Q^T of a symmetric matrix graded over seven
     decades (like the core Q1^T S Q1 of the rank-revealing spectral solve) in one workgroup -- the reflectors give an orthogonal Q, Q^T T Q
@@ -784,16 +784,24 @@ def test_own_tridiagonalisation_and_back_transformation_against_numpy(n):
     lam = 2.0e4 * 10.0 ** (-np.arange(n) / max(n / 7.0, 1.0))
     A = (Q0 * lam) @ Q0.T
     A = 0.5 * (A + A.T)
-    ld = 264                                                          # a padded leading dimension (only the lower triangle is read)
+    ld = 264 if n <= 256 else 392                                     # a padded leading dimension (only the lower triangle is read)
     T = torch.full((n, ld), float("nan"), dtype=torch.float64, device="cuda")
     T[:, :n] = torch.from_numpy(np.tril(A) + np.triu(np.full((n, n), np.nan), 1))     # the strict upper triangle is never read
-    nmax = int(nat.lib().vmcpde_sytrd_small_max_n())
-    assert nmax == 256
+    assert int(nat.lib().vmcpde_sytrd_small_max_n()) == 256 and int(nat.lib().vmcpde_sytrd_medium_max_n()) == 384
+    # n <= 256: the one-workgroup kernel; 257 .. 384 (ABI 7; BASELINE C3's core has rank 263): n - 256 leading steps of two launches each on a
+    # symmetric copy in the workspace, then the same kernel on the trailing block -- through vmcpde_sytrd_medium, which IS the small entry below 257
+    nmax = 256 if n <= 256 else 384
+    nwork = max(int(nat.lib().vmcpde_sytrd_medium_workspace_bytes(n)) // 8, 1)
+    assert (nwork == 1) == (n <= 256)
     outs = []
-    for _ in range(2):
+    for rep in range(2):
         D, E, tau = (torch.full((nmax,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(3))
         Vr = torch.full((nmax, nmax), float("nan"), dtype=torch.float64, device="cuda")
-        nat.call("vmcpde_sytrd_small", nat.ptr(T), ld, n, nat.ptr(D), nat.ptr(E), nat.ptr(tau), nat.ptr(Vr), nmax, nat.stream())
+        work = torch.full((nwork,), float("nan"), dtype=torch.float64, device="cuda")
+        if n <= 256 and rep == 0:
+            nat.call("vmcpde_sytrd_small", nat.ptr(T), ld, n, nat.ptr(D), nat.ptr(E), nat.ptr(tau), nat.ptr(Vr), nmax, nat.stream())
+        else:
+            nat.call("vmcpde_sytrd_medium", nat.ptr(T), ld, n, nat.ptr(D), nat.ptr(E), nat.ptr(tau), nat.ptr(Vr), nmax, nat.ptr(work), nwork * 8, nat.stream())
         outs.append((D.cpu().numpy()[:n], E.cpu().numpy()[:n], tau.cpu().numpy()[:n], Vr.cpu().numpy()[:n, :n]))
     d, e, t, Vh = outs[0]
     for a, b in zip(outs[0], outs[1]):
@@ -822,9 +830,11 @@ def test_own_tridiagonalisation_and_back_transformation_against_numpy(n):
     assert np.linalg.norm(A @ W - W * wt) < 1e-12 * w_ref[-1] and np.abs(W.T @ W - np.eye(n)).max() < 1e-13
     with pytest.raises(nat.VmcpdeError, match="256"):
         nat.call("vmcpde_sytrd_small", nat.ptr(T), ld, 257, nat.ptr(D), nat.ptr(E), nat.ptr(tau), nat.ptr(Vr), nmax, nat.stream())
+    with pytest.raises(nat.VmcpdeError, match="384"):
+        nat.call("vmcpde_sytrd_medium", nat.ptr(T), ld, 385, nat.ptr(D), nat.ptr(E), nat.ptr(tau), nat.ptr(Vr), nmax, nat.ptr(work), nwork * 8, nat.stream())
 
 
-@pytest.mark.parametrize("n", [3, 65, 206, 256])
+@pytest.mark.parametrize("n", [3, 65, 206, 256, 263, 384])
 def test_tridiag_core_route_against_the_library_eigh(n):
     """The whole core route of `coreEigensolver="auto"` on a graded matrix: own tridiagonalisation, rocSOLVER's stedc through ctypes
     (vmc_pde_amd/rocsolver.py), own back-transformation -- against torch.linalg.eigh."""
@@ -849,7 +859,7 @@ def test_tridiag_core_route_against_the_library_eigh(n):
     assert float((W.T @ W - eye).abs().max()) < 1e-13
     assert float(torch.linalg.norm(A @ W - W * wv)) < 1e-12 * lmax
     assert tp._core_choice(n) == "tridiag" and int(tp._tridiag["host"][0]) == 0      # (reads the status word of the call before)
-    assert tp._core_choice(257) == "library" and tp._core_choice(2) == "library"
+    assert tp._core_choice(257) == "tridiag" and tp._core_choice(385) == "library" and tp._core_choice(2) == "library"
     assert V.TDVP(coreEigensolver="library")._core_choice(n) == "library"
 
 
@@ -926,3 +936,53 @@ def test_woodbury_application_against_numpy(P, r, ldl):
         assert np.linalg.norm(target.cpu().numpy() - ref) < 1e-9 * np.linalg.norm(ref)
     with pytest.raises(nat.VmcpdeError, match="come together"):
         nat.call("vmcpde_woodbury_project", nat.ptr(LT), ldl, P, r, nat.ptr(Dd), nat.ptr(Fd), None, nat.ptr(ud), nat.ptr(y), nat.ptr(t1), nat.stream())
+
+
+@pytest.mark.parametrize("P,r,rank", [(4213, 256, 207), (300, 64, 64), (1000, 128, 5), (16181, 384, 300)])
+def test_woodbury_prepare_and_gram_against_numpy(P, r, rank):
+    """ABI 7: vmcpde_woodbury_prepare (D, 1 / D with a zero pad, the rows of LT behind the device-side rank zeroed) and vmcpde_woodbury_gram
+    (G = I + L^T D^-1 L from 64 x 64 blocks x chunks of 256 parameters on the matrix pipe, deterministic) against numpy; and
+    vmcpde_gather_words, the one record a static call hands to the host."""
+    from vmc_pde_amd import _native as nat
+    rng = np.random.default_rng(P + r)
+    ldl = (P + 63) // 64 * 64
+    LTh = rng.standard_normal((r + 3, ldl)) * np.logspace(0, -4, r + 3)[:, None]       # (stale columns everywhere, pad columns included)
+    diagS = rng.uniform(0.1, 2.0, P)
+    shift, floor = 1e-3, 2e-5
+    LT = torch.from_numpy(LTh.copy()).cuda()
+    state = torch.tensor([rank, 1], dtype=torch.int32, device="cuda")
+    D = torch.full((P,), float("nan"), dtype=torch.float64, device="cuda")
+    invD = torch.full((ldl,), float("nan"), dtype=torch.float64, device="cuda")
+    fl = torch.tensor([floor], dtype=torch.float64, device="cuda")
+    nat.call("vmcpde_woodbury_prepare", nat.ptr(torch.from_numpy(diagS).cuda()), shift, nat.ptr(fl), P, ldl, nat.ptr(D), nat.ptr(invD), nat.ptr(LT), nat.ptr(state), r,
+             nat.stream())
+    Dref = shift * diagS + floor
+    assert np.allclose(D.cpu().numpy(), Dref, rtol=1e-15) and np.allclose(invD[:P].cpu().numpy(), 1.0 / Dref, rtol=1e-15)
+    assert not invD[P:].any()
+    L_after = LT.cpu().numpy()
+    assert np.array_equal(L_after[:rank], LTh[:rank]) and not L_after[rank:r].any() and np.array_equal(L_after[r:], LTh[r:])
+    need = nat.lib().vmcpde_woodbury_gram_workspace_bytes(ldl, r)
+    ws = torch.empty(need // 8, dtype=torch.float64, device="cuda")
+    outs = []
+    for _ in range(2):
+        G = torch.full((r, r), float("nan"), dtype=torch.float64, device="cuda")
+        nat.call("vmcpde_woodbury_gram", nat.ptr(LT), ldl, r, nat.ptr(invD), nat.ptr(G), r, nat.ptr(ws), need, nat.stream())
+        outs.append(G.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])                                  # fixed summation order
+    Lr = L_after[:r, :P]
+    Gref = np.eye(r) + (Lr / Dref) @ Lr.T
+    assert np.abs(outs[0] - Gref).max() < 1e-12 * np.abs(Gref).max() and np.array_equal(outs[0], outs[0].T)
+    with pytest.raises(nat.VmcpdeError, match="multiple of 64"):
+        nat.call("vmcpde_woodbury_gram", nat.ptr(LT), ldl, 65, nat.ptr(invD), nat.ptr(G), r, nat.ptr(ws), need, nat.stream())
+    # gather: four sources with a skipped one keep their slots
+    a = torch.arange(4, dtype=torch.float64, device="cuda") + 0.5
+    c = torch.tensor([7, -3], dtype=torch.int32, device="cuda")
+    d = torch.arange(4, dtype=torch.float64, device="cuda") * 3.0
+    dst = torch.full((16,), -1.0, dtype=torch.float64, device="cuda")
+    srcs, counts = (nat.C.c_void_p * 8)(), (nat.C.c_int32 * 8)()
+    for i, (src, n) in enumerate([(a, 4), (None, 1), (c, 1), (d, 4)]):
+        srcs[i] = None if src is None else src.data_ptr()
+        counts[i] = n
+    nat.call("vmcpde_gather_words", srcs, counts, 4, nat.ptr(dst), nat.stream())
+    h = dst.cpu()
+    assert torch.equal(h[:4], a.cpu()) and float(h[4]) == -1.0 and h[5:6].view(torch.int32).tolist() == [7, -3] and torch.equal(h[6:10], d.cpu())

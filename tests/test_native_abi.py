@@ -14,7 +14,7 @@ def test_library_exports_every_header_symbol(lib_built):
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
     assert set(nat._PROTOS) == set(syms)            # every entry point has a ctypes prototype and vice versa
-    assert nat.lib().vmcpde_abi_version() == 6
+    assert nat.lib().vmcpde_abi_version() == 7
     nm = subprocess.run(["nm", "-D", "--defined-only", str(lib_built)], capture_output=True, text=True).stdout
     exported = {l.split()[-1] for l in nm.splitlines() if " T " in l}
     assert set(syms) <= exported

@@ -11,12 +11,14 @@ if len(sys.argv) > 2 and sys.argv[2] == "C4":      # BASELINE C4: three damped o
     dim, offset, N, HID, T_END = 6, np.array([1.0, 0.0, 0.0, 1.0, 0.0, 0.0]), 32768, (19, 19), 2.0
 else:
     dim, offset, N, HID, T_END = 2, np.array([1.0, 1.0]), 65536, (21, 21), 5.0
+T_END = float(os.environ.get("T_END", T_END))          # (e.g. T_END=1.0 for the dense-engine run of round 6: 147 ms per right-hand side)
 sampler = V.Sampler(key=7, dim=dim, name="Gauss", mcmc_info={"offset": offset, "bound": 0.25})
 vs = V.VarState(sampler, dim, 1, 4, network_args={"intmediate": HID, "offset": offset, "latentSpaceName": "Gauss", "dim": dim})
 eq = V.EvolutionEquation(dim=dim, name="advection_hamiltonian_wDiss")
 from vmc_pde_amd.experimental import TDVP as XTDVP       # (= V.TDVP unless INT8_GRAM=1 / MATRIX_FREE=1 switch an experiment on)
 if os.environ.get("SOLVER", "cholesky") == "eigh":     # the reference's spectral solve (diagonalShift 0); ENGINE=dense|lowrank|auto picks how (ev, V) are obtained
     tdvp = XTDVP(svdTol=float(os.environ.get("SVD_TOL", "1e-6")), spectralEngine=os.environ.get("ENGINE", "auto"),
+                  useSNR=os.environ.get("USE_SNR", "0") == "1",         # USE_SNR=1: the reference's SNR soft cut-off on top (tdvp.py:87-89)
                   matrixFree=os.environ.get("MATRIX_FREE", "0") == "1")
 else:
     tdvp = XTDVP(diagonalShift=shift, svdTol=float(os.environ.get("SVD_TOL", "1e-6")), solver="cholesky",

@@ -110,11 +110,18 @@ _PROTOS = {
     "vmcpde_householder_rows": (_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "vmcpde_woodbury_project": (_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vmcpde_woodbury_combine": (_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vmcpde_woodbury_prepare": (_int, [_vp, _f64, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "vmcpde_woodbury_gram_workspace_bytes": (_i64, [_i64, _i32]),
+    "vmcpde_woodbury_gram": (_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "vmcpde_gather_words": (_int, [C.POINTER(_vp), C.POINTER(_i32), _i32, _vp, _vp]),
     "vmcpde_jacobi_shape": (_int, [_i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "vmcpde_jacobi_columns": (_int, [_vp, _i32, _i32, _vp, _vp]),
     "vmcpde_sytrd_small_max_n": (_i32, []),
     "vmcpde_sytrd_small": (_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "vmcpde_apply_reflectors": (_int, [_vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp]),
+    "vmcpde_sytrd_medium_max_n": (_i32, []),
+    "vmcpde_sytrd_medium_workspace_bytes": (_i64, [_i32]),
+    "vmcpde_sytrd_medium": (_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
 }
 
 _lib = None

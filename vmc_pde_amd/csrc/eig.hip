@@ -1617,6 +1617,175 @@ __global__ __launch_bounds__(64) void woodbury_combine_kernel(const double* __re
 
 }  // namespace
 
+// ---- ABI 7: what surrounds the Woodbury application in a static call, without a library GEMM or an elementwise launch ---------------------
+namespace {
+
+typedef double wg_double4 __attribute__((ext_vector_type(4)));
+// block index t of the lower triangle (row-major: (0,0), (1,0), (1,1), (2,0), ...) -> (bi, bj), bi >= bj
+__device__ __forceinline__ void wg_tri_decode(int t, int& bi, int& bj) {
+  int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((i + 1) * (i + 2) / 2 <= t) ++i;
+  while (i * (i + 1) / 2 > t) --i;
+  bi = i;
+  bj = t - i * (i + 1) / 2;
+}
+constexpr int WG_BLK = 64;      // G is formed in 64 x 64 blocks of its lower triangle ...
+constexpr int WG_KC = 256;      // ... from contraction chunks of this many parameters: (r / 64)(r / 64 + 1) / 2 x ceil(ldl / 256) workgroups
+
+// D[p] = shift * diagS[p] + floor and 1 / D[p] (zero on the pad [P, ldl): pad columns of LT never count), and -- behind the first
+// ceil(ldl / 256) workgroups -- one workgroup per row k of LT[:rmax] that zeroes the row when k >= rank (state[0], read on the device): the
+// factorisation rewrites rows [0, rank) in full, rows behind it still hold an earlier call's columns and must be an identity block of G.
+__global__ __launch_bounds__(256) void woodbury_prepare_kernel(const double* __restrict__ diagS, double shift, const double* __restrict__ floor_dev, int P,
+                                                               int ldl, double* __restrict__ D, double* __restrict__ invD, double* __restrict__ LT,
+                                                               const int32_t* __restrict__ state, int rmax, int nD) {
+  const int b = (int)blockIdx.x, t = (int)threadIdx.x;
+  if (b < nD) {
+    const int p = b * 256 + t;
+    if (p >= ldl) return;
+    if (p < P) {
+      const double d = fma(shift, diagS[p], floor_dev ? floor_dev[0] : 0.0);
+      D[p] = d;
+      invD[p] = 1.0 / d;
+    } else {
+      invD[p] = 0.0;
+    }
+    return;
+  }
+  const int k = b - nD;
+  if (k < state[0] || k >= rmax) return;
+  double* __restrict__ row = LT + (int64_t)k * ldl;
+  for (int i = t; i < ldl; i += 256) row[i] = 0.0;
+}
+
+// partial[chunk][blk] = LT[rows of bi][chunk] diag(invD[chunk]) LT[rows of bj][chunk]^T for the 64 x 64 block (bi >= bj) of G: operands straight from
+// global memory in the MFMA's own lane layout (lane l supplies row l & 15, k = k4 + (l >> 4)) -- the factor is 8.6 MB and was written by the launches
+// just before, and 170 workgroups of eight-deep unrolled loads hide the latency; no LDS image, no barrier.
+__global__ __launch_bounds__(256) void woodbury_gram_partial_kernel(const double* __restrict__ LT, int64_t ldl, const double* __restrict__ invD, int nblk,
+                                                                    double* __restrict__ slabs) {
+  int bi, bj;
+  wg_tri_decode((int)blockIdx.y, bi, bj);
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int k0 = (int)blockIdx.x * WG_KC;
+  const int kn = ((int)ldl - k0 < WG_KC) ? ((int)ldl - k0) : WG_KC;
+  const double* __restrict__ ap = LT + (int64_t)(bi * WG_BLK + wr * 32 + lr) * ldl + k0 + lk;
+  const double* __restrict__ bp = LT + (int64_t)(bj * WG_BLK + wc * 32 + lr) * ldl + k0 + lk;
+  const double* __restrict__ dp = invD + k0 + lk;
+  wg_double4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (wg_double4){0.0, 0.0, 0.0, 0.0};
+  for (int k32 = 0; k32 < kn; k32 += 32) {            // (ldl is a multiple of 32: eight MFMA steps' operands in flight together)
+    double w[8], a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k4 = k32 + 4 * u;
+      w[u] = dp[k4];
+      a0[u] = ap[k4];
+      a1[u] = ap[16 * ldl + k4];
+      b0[u] = bp[k4];
+      b1[u] = bp[16 * ldl + k4];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double x0 = a0[u] * w[u], x1 = a1[u] * w[u];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, b0[u], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, b1[u], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, b0[u], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, b1[u], acc[1][1], 0, 0, 0);
+    }
+  }
+  double* __restrict__ out = slabs + ((int64_t)blockIdx.x * nblk + blockIdx.y) * (WG_BLK * WG_BLK);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)          // C / D layout of the f64 MFMA: row = (lane >> 4) + 4 q, column = lane & 15
+        out[(wr * 32 + 16 * i + lk + 4 * q) * WG_BLK + wc * 32 + 16 * j + lr] = acc[i][j][q];
+}
+
+// G = I + sum over the chunks in a fixed order (deterministic: every rank forms the same bits), both triangles written
+__global__ __launch_bounds__(256) void woodbury_gram_reduce_kernel(const double* __restrict__ slabs, int nchunk, int nblk, double* __restrict__ G, int64_t ldg) {
+  int bi, bj;
+  wg_tri_decode((int)blockIdx.y, bi, bj);
+  const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;      // element of the 64 x 64 block
+  const int r = e >> 6, c = e & 63;
+  // (a diagonal block is computed in full, but (a w) b and (b w) a round differently: its upper triangle takes the lower one's sums, so G is symmetric to the bit)
+  const int es = (bi == bj && c > r) ? (c * WG_BLK + r) : e;
+  const double* __restrict__ src = slabs + (int64_t)blockIdx.y * (WG_BLK * WG_BLK) + es;
+  double s = 0.0;
+  for (int ch = 0; ch < nchunk; ++ch) s += src[(int64_t)ch * nblk * (WG_BLK * WG_BLK)];
+  const int gi = bi * WG_BLK + r, gj = bj * WG_BLK + c;
+  if (gi == gj) s += 1.0;
+  G[(int64_t)gi * ldg + gj] = s;
+  if (bi != bj) G[(int64_t)gj * ldg + gi] = s;
+}
+
+struct GatherArgs {
+  const unsigned long long* src[8];
+  int n[8];
+};
+// dst = the concatenation of up to eight small device arrays of 8-byte words: the ONE record a static call hands to the host
+__global__ __launch_bounds__(64) void gather_words_kernel(GatherArgs a, unsigned long long* __restrict__ dst) {
+  int off = 0;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int n = a.n[s];
+    if (n > 0 && a.src[s] != nullptr)
+      for (int i = (int)threadIdx.x; i < n; i += 64) dst[off + i] = a.src[s][i];
+    off += n > 0 ? n : 0;
+  }
+}
+
+}  // namespace
+
+extern "C" int vmcpde_woodbury_prepare(const double* diagS, double shift, const double* floor_dev, int32_t P, int64_t ldl, double* D, double* invD,
+                                       double* LT, const int32_t* state, int32_t rmax, void* stream) {
+  VMC_REQUIRE(diagS && D && invD && LT && state, "vmcpde_woodbury_prepare: null argument");
+  VMC_REQUIRE(P >= 1 && ldl >= P && ldl < (1 << 30) && rmax >= 1, "vmcpde_woodbury_prepare: bad shape");
+  const int nD = (int)((ldl + 255) / 256);
+  hipLaunchKernelGGL(woodbury_prepare_kernel, dim3((unsigned)(nD + rmax)), dim3(256), 0, (hipStream_t)stream, diagS, shift, floor_dev, P, (int)ldl, D, invD, LT,
+                     state, rmax, nD);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int64_t vmcpde_woodbury_gram_workspace_bytes(int64_t ldl, int32_t r) {
+  if (ldl <= 0 || r <= 0) return 0;
+  const int nside = (r + WG_BLK - 1) / WG_BLK;
+  return (int64_t)((ldl + WG_KC - 1) / WG_KC) * (nside * (nside + 1) / 2) * WG_BLK * WG_BLK * (int64_t)sizeof(double);
+}
+
+extern "C" int vmcpde_woodbury_gram(const double* LT, int64_t ldl, int32_t r, const double* invD, double* G, int64_t ldg, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+  VMC_REQUIRE(LT && invD && G && workspace, "vmcpde_woodbury_gram: null argument");
+  VMC_REQUIRE(r >= WG_BLK && (r % WG_BLK) == 0 && ldg >= r, "vmcpde_woodbury_gram: r must be a positive multiple of %d and ldg >= r", WG_BLK);
+  VMC_REQUIRE(ldl >= 32 && (ldl % 32) == 0 && ldl < (1 << 30), "vmcpde_woodbury_gram: ldl must be a multiple of 32");
+  VMC_REQUIRE(workspace_bytes >= vmcpde_woodbury_gram_workspace_bytes(ldl, r), "vmcpde_woodbury_gram: workspace too small");
+  const int nside = r / WG_BLK, nblk = nside * (nside + 1) / 2, nchunk = (int)((ldl + WG_KC - 1) / WG_KC);
+  hipStream_t st = (hipStream_t)stream;
+  double* slabs = static_cast<double*>(workspace);
+  hipLaunchKernelGGL(woodbury_gram_partial_kernel, dim3((unsigned)nchunk, (unsigned)nblk), dim3(256), 0, st, LT, ldl, invD, nblk, slabs);
+  hipLaunchKernelGGL(woodbury_gram_reduce_kernel, dim3(WG_BLK * WG_BLK / 256, (unsigned)nblk), dim3(256), 0, st, slabs, nchunk, nblk, G, ldg);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vmcpde_gather_words(const void* const* srcs, const int32_t* counts, int32_t n_src, void* dst, void* stream) {
+  VMC_REQUIRE(srcs && counts && dst && n_src >= 1 && n_src <= 8, "vmcpde_gather_words: 1..8 sources");
+  GatherArgs a;
+  for (int s = 0; s < 8; ++s) {
+    a.src[s] = s < n_src ? static_cast<const unsigned long long*>(srcs[s]) : nullptr;
+    a.n[s] = s < n_src ? counts[s] : 0;
+    VMC_REQUIRE(a.n[s] >= 0 && a.n[s] <= 4096, "vmcpde_gather_words: a source has %d words", a.n[s]);
+  }
+  hipLaunchKernelGGL(gather_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, static_cast<unsigned long long*>(dst));
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int vmcpde_woodbury_project(const double* LT, int64_t ldl, int32_t P, int32_t r, const double* D, const double* F, const double* Su,
                                        const double* u, double* y, double* t1, void* stream) {
   VMC_REQUIRE(LT && D && F && y && t1, "vmcpde_woodbury_project: null argument");

@@ -126,8 +126,18 @@ Regions make_regions(const FlowProgram& fp, int kdirs, int JB) {
 }
 
 #define LD(u) (c.lds[(u) * c.lanes + c.lane])
+// The waves of a workgroup talk to each other through LDS only (per-sample vectors, the weight stage); what they write to global memory -- the
+// Jacobian rows, logp, g, hv -- is never read back inside the kernel.  __syncthreads() is a workgroup-scope release + acquire around s_barrier,
+// i.e. it also waits for every outstanding GLOBAL store of the wave (s_waitcnt vmcnt(0)): each of the ~170 barriers of a sample group would stall
+// on the Jacobian stores issued just before it.  VMC_FLOW_LDS_BARRIER (default): wait for the wave's LDS traffic only, then s_barrier -- the row
+// stores drain behind the arithmetic that follows.  (The keep-activations path DOES read its own global stores back: it keeps the full fence.)
+#ifndef VMC_FLOW_LDS_BARRIER
+#define VMC_FLOW_LDS_BARRIER 1
+#endif
 #ifdef VMC_FLOW_DIAG_NO_SYNC       // timing diagnostics only (results are wrong): what the workgroup barriers cost
 #define SYNC() ((void)0)
+#elif VMC_FLOW_LDS_BARRIER
+#define SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #else
 #define SYNC() __syncthreads()
 #endif

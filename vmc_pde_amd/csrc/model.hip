@@ -50,7 +50,7 @@ int env_int(const char* name, int fallback) {
 using namespace vmcpde;
 
 extern "C" const char* vmcpde_last_error(void) { return vmcpde::g_err; }
-extern "C" int vmcpde_abi_version(void) { return 6; }
+extern "C" int vmcpde_abi_version(void) { return 7; }
 
 namespace {
 

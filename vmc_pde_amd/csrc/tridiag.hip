@@ -287,36 +287,135 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_small_kernel(const double* _
 
 // Zt[m][:] <- Q Zt[m][:] = H_0 H_1 ... H_{n-2} z for every row m of Zt (the eigenvectors of the tridiagonal matrix, one per row -- the
 // column-major matrix a LAPACK-style solver returns): one wave per vector, the reflectors streamed from V (L2 resident).
+template <int NCH>      // 64-column chunks a lane holds: 4 (n <= 256) or 6 (n <= 384)
 __global__ __launch_bounds__(256) void apply_reflectors_kernel(const double* __restrict__ V, int64_t ldv, const double* __restrict__ tau, int n,
                                                                double* __restrict__ Zt, int64_t ldz, int nvec) {
   const int lane = (int)threadIdx.x & 63;
   const int m = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
   if (m >= nvec) return;
-  double z[4], vk[4], vn[4];
+  double z[NCH], vk[NCH], vn[NCH];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) z[c] = (lane + 64 * c < n) ? Zt[(int64_t)m * ldz + lane + 64 * c] : 0.0;
+  for (int c = 0; c < NCH; ++c) z[c] = (lane + 64 * c < n) ? Zt[(int64_t)m * ldz + lane + 64 * c] : 0.0;
   if (n >= 2) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) vn[c] = (lane + 64 * c < n) ? V[(int64_t)(n - 2) * ldv + lane + 64 * c] : 0.0;
+    for (int c = 0; c < NCH; ++c) vn[c] = (lane + 64 * c < n) ? V[(int64_t)(n - 2) * ldv + lane + 64 * c] : 0.0;
   }
   for (int k = n - 2; k >= 0; --k) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) vk[c] = vn[c];
+    for (int c = 0; c < NCH; ++c) vk[c] = vn[c];
     if (k > 0) {                                          // the next reflector's loads fly under this one's reduction
 #pragma unroll
-      for (int c = 0; c < 4; ++c) vn[c] = (lane + 64 * c < n) ? V[(int64_t)(k - 1) * ldv + lane + 64 * c] : 0.0;
+      for (int c = 0; c < NCH; ++c) vn[c] = (lane + 64 * c < n) ? V[(int64_t)(k - 1) * ldv + lane + 64 * c] : 0.0;
     }
     const double t = tau[k];
     double part = 0.0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) part = fma(z[c], vk[c], part);
+    for (int c = 0; c < NCH; ++c) part = fma(z[c], vk[c], part);
     const double f = -t * wave_sum(part);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) z[c] = fma(f, vk[c], z[c]);
+    for (int c = 0; c < NCH; ++c) z[c] = fma(f, vk[c], z[c]);
   }
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int c = 0; c < NCH; ++c)
     if (lane + 64 * c < n) Zt[(int64_t)m * ldz + lane + 64 * c] = z[c];
+}
+
+// ---- ranks between 257 and 384: the leading n - 256 Householder steps on a full symmetric copy, the rest by sytrd_small_kernel --------------
+// The single-workgroup kernel holds a 256-frame (its four diagonal blocks fill the LDS); a core of rank 263 (BASELINE C3) needs seven more
+// steps than that.  Those steps (LAPACK's dsytd2 on the leading columns) run as two launches each on W = both triangles of T:
+//   A  every workgroup forms the reflector of column k from ROW k of W (contiguous; the same bits everywhere), workgroup 0 publishes it
+//      (D, E, tau, row k of V); p_i = sum_j W[i][j] v_j for the workgroup's rows -- whole rows, so no cross-workgroup sum;
+//   B  every workgroup forms p.v (all of p, a fixed order: the same bits everywhere), w = tau p - (tau^2 / 2)(p.v) v, and updates its rows.
+// The trailing 256 x 256 block of W is then the one-workgroup kernel's input.  No atomics; a pure function of the input bits.
+constexpr int TM_MAXN = 384, TM_ROWS = 16 /* rows of W per workgroup */, TM_THREADS = 256;
+
+__global__ __launch_bounds__(256) void sytd2_symmetrise_kernel(const double* __restrict__ T, int64_t ldt, int n, double* __restrict__ W) {
+  const int i = (int)blockIdx.x, t = (int)threadIdx.x;
+  for (int j = t; j < n; j += 256) W[(int64_t)i * n + j] = (j <= i) ? T[(int64_t)i * ldt + j] : T[(int64_t)j * ldt + i];
+}
+
+// the reflector of step k from row k of W (entries j > k), by all 256 threads of a workgroup: v -> sh_v[0 .. n), returns (tau, beta)
+__device__ __forceinline__ void tm_reflector(const double* __restrict__ W, int n, int k, double* __restrict__ sh_v, double* __restrict__ sh_red, double& tau,
+                                             double& beta) {
+  const int t = (int)threadIdx.x;
+  const double* __restrict__ row = W + (int64_t)k * n;
+  double part = 0.0;
+  for (int j = t; j < n; j += TM_THREADS) {
+    const double x = (j > k) ? row[j] : 0.0;
+    sh_v[j] = x;
+    part += (j > k + 1) ? x * x : 0.0;
+  }
+  part = wave_sum(part);
+  if ((t & 63) == 0) sh_red[t >> 6] = part;
+  __syncthreads();
+  const double xnorm2 = (sh_red[0] + sh_red[1]) + (sh_red[2] + sh_red[3]);
+  const double alpha = sh_v[k + 1];
+  __syncthreads();                                        // (alpha is read before sh_v[k + 1] becomes 1)
+  tau = 0.0;
+  beta = alpha;
+  double scale = 0.0;
+  if (xnorm2 > 0.0) {
+    beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
+    tau = (beta - alpha) / beta;
+    scale = 1.0 / (alpha - beta);
+  }
+  for (int j = t; j < n; j += TM_THREADS) sh_v[j] = (j == k + 1) ? 1.0 : ((j > k + 1) ? sh_v[j] * scale : 0.0);
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(TM_THREADS) void sytd2_step_a_kernel(const double* __restrict__ W, int n, int k, double* __restrict__ D, double* __restrict__ E,
+                                                                  double* __restrict__ tau_out, double* __restrict__ V, int64_t ldv, double* __restrict__ p) {
+  __shared__ double sh_v[TM_MAXN];
+  __shared__ double sh_red[4];
+  double tau, beta;
+  tm_reflector(W, n, k, sh_v, sh_red, tau, beta);
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (blockIdx.x == 0) {
+    for (int j = t; j < n; j += TM_THREADS) V[(int64_t)k * ldv + j] = sh_v[j];
+    if (t == 0) {
+      D[k] = W[(int64_t)k * n + k];
+      E[k] = beta;
+      tau_out[k] = tau;
+    }
+  }
+  // four rows per wave: p_i = tau * sum_j W[i][j] v_j (rows at or above the pivot: v_i = 0 and p_i is never used -- written as 0)
+  for (int q = 0; q < TM_ROWS / 4; ++q) {
+    const int i = (int)blockIdx.x * TM_ROWS + wave * (TM_ROWS / 4) + q;
+    if (i >= n) continue;
+    double s = 0.0;
+    if (i > k)
+      for (int j = lane; j < n; j += 64) s = fma(W[(int64_t)i * n + j], sh_v[j], s);
+    s = wave_sum(s);
+    if (lane == 0) p[i] = tau * s;
+  }
+}
+
+__global__ __launch_bounds__(TM_THREADS) void sytd2_step_b_kernel(double* __restrict__ W, int n, int k, const double* __restrict__ V, int64_t ldv,
+                                                                  const double* __restrict__ tau_in, const double* __restrict__ p) {
+  __shared__ double sh_v[TM_MAXN], sh_w[TM_MAXN];
+  __shared__ double sh_red[4];
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  const double tau = tau_in[k];
+  double part = 0.0;
+  for (int j = t; j < n; j += TM_THREADS) {
+    const double v = V[(int64_t)k * ldv + j], pj = p[j];
+    sh_v[j] = v;
+    sh_w[j] = pj;
+    part = fma(pj, v, part);
+  }
+  part = wave_sum(part);
+  if (lane == 0) sh_red[wave] = part;
+  __syncthreads();
+  const double half = -0.5 * tau * ((sh_red[0] + sh_red[1]) + (sh_red[2] + sh_red[3]));
+  for (int j = t; j < n; j += TM_THREADS) sh_w[j] = fma(half, sh_v[j], sh_w[j]);
+  __syncthreads();
+  for (int q = 0; q < TM_ROWS / 4; ++q) {
+    const int i = (int)blockIdx.x * TM_ROWS + wave * (TM_ROWS / 4) + q;
+    if (i >= n || i <= k) continue;
+    const double vi = sh_v[i], wi = sh_w[i];
+    for (int j = lane; j < n; j += 64)
+      if (j > k) W[(int64_t)i * n + j] = fma(-vi, sh_w[j], fma(-wi, sh_v[j], W[(int64_t)i * n + j]));
+  }
 }
 
 }  // namespace
@@ -347,9 +446,41 @@ extern "C" int vmcpde_sytrd_small(const double* T, int64_t ldt, int32_t n, doubl
 extern "C" int vmcpde_apply_reflectors(const double* V, int64_t ldv, const double* tau, int32_t n, double* Zt, int64_t ldz, int32_t nvec,
                                        void* stream) {
   VMC_REQUIRE(V && tau && Zt, "vmcpde_apply_reflectors: null argument");
-  VMC_REQUIRE(n >= 1 && n <= TD_MAXN && nvec >= 1, "vmcpde_apply_reflectors: bad shape (n = %d, nvec = %d)", n, nvec);
+  VMC_REQUIRE(n >= 1 && n <= TM_MAXN && nvec >= 1, "vmcpde_apply_reflectors: bad shape (n = %d, nvec = %d)", n, nvec);
   VMC_REQUIRE(ldv >= n && ldz >= n, "vmcpde_apply_reflectors: leading dimensions below n");
-  hipLaunchKernelGGL(apply_reflectors_kernel, dim3((unsigned)((nvec + 3) / 4)), dim3(256), 0, (hipStream_t)stream, V, ldv, tau, n, Zt, ldz, nvec);
+  if (n <= TD_MAXN)
+    hipLaunchKernelGGL(apply_reflectors_kernel<4>, dim3((unsigned)((nvec + 3) / 4)), dim3(256), 0, (hipStream_t)stream, V, ldv, tau, n, Zt, ldz, nvec);
+  else
+    hipLaunchKernelGGL(apply_reflectors_kernel<6>, dim3((unsigned)((nvec + 3) / 4)), dim3(256), 0, (hipStream_t)stream, V, ldv, tau, n, Zt, ldz, nvec);
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int32_t vmcpde_sytrd_medium_max_n(void) { return TM_MAXN; }
+
+extern "C" int64_t vmcpde_sytrd_medium_workspace_bytes(int32_t n) {
+  return (n <= TD_MAXN) ? 0 : ((int64_t)n * n + n) * (int64_t)sizeof(double);
+}
+
+extern "C" int vmcpde_sytrd_medium(const double* T, int64_t ldt, int32_t n, double* D, double* E, double* tau, double* V, int64_t ldv, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+  VMC_REQUIRE(n >= 1 && n <= TM_MAXN, "vmcpde_sytrd_medium: n = %d outside [1, %d]", n, TM_MAXN);
+  if (n <= TD_MAXN) return vmcpde_sytrd_small(T, ldt, n, D, E, tau, V, ldv, stream);
+  VMC_REQUIRE(T && D && E && tau && V && workspace, "vmcpde_sytrd_medium: null argument");
+  VMC_REQUIRE(ldt >= n && ldv >= n, "vmcpde_sytrd_medium: leading dimensions below n");
+  VMC_REQUIRE(workspace_bytes >= vmcpde_sytrd_medium_workspace_bytes(n), "vmcpde_sytrd_medium: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  double* W = static_cast<double*>(workspace);
+  double* p = W + (int64_t)n * n;
+  const int m = n - TD_MAXN;                                // leading steps taken here; the trailing 256 x 256 block goes to the one-workgroup kernel
+  const unsigned grid = (unsigned)((n + TM_ROWS - 1) / TM_ROWS);
+  hipLaunchKernelGGL(sytd2_symmetrise_kernel, dim3((unsigned)n), dim3(256), 0, st, T, ldt, n, W);
+  for (int k = 0; k < m; ++k) {
+    hipLaunchKernelGGL(sytd2_step_a_kernel, dim3(grid), dim3(TM_THREADS), 0, st, W, n, k, D, E, tau, V, ldv, p);
+    hipLaunchKernelGGL(sytd2_step_b_kernel, dim3(grid), dim3(TM_THREADS), 0, st, W, n, k, V, ldv, tau, p);
+  }
+  VMC_CHECK_HIP(hipGetLastError());
+  // rows m .. n-1 of V: the one-workgroup kernel writes columns m .. n-1 of them; the columns before are zeros of those reflectors
+  VMC_CHECK_HIP(hipMemset2DAsync(V + (int64_t)m * ldv, (size_t)ldv * sizeof(double), 0, (size_t)m * sizeof(double), (size_t)TD_MAXN, st));
+  return vmcpde_sytrd_small(W + (int64_t)m * n + m, n, TD_MAXN, D + m, E + m, tau + m, V + (int64_t)m * ldv + m, ldv, stream);
 }

@@ -179,9 +179,6 @@ class LowRankRoutes:
         S0 = b["S"][:P, :P]
         cap = P if self.choleskyEngine == "lowrank" else max(1, min(LOWRANK_RANK_CAP, P // LOWRANK_RANK_DIVISOR))
         w = self._lowrank_buffers(P, device, cap)
-        D = b["diagS"] * float(self.diagonalShift)
-        if self._floor is not None:
-            D = D + self._floor
         st = self._chol_static
         if st is not None and st["P"] == P and st["rmax"] <= w["LT"].shape[0]:
             if st["event"] is not None:                 # the previous static call's factorisation: finished, with room to spare?
@@ -193,8 +190,11 @@ class LowRankRoutes:
                     used = self._steps_used(st["head"])
                     st["nsteps"] = used + max(3, used // 3)
             if st is not None:
-                self._solve_lowrank_static(b, F, P, update, w, D, st)
+                self._solve_lowrank_static(b, F, P, update, w, st)
                 return True
+        D = b["diagS"] * float(self.diagonalShift)                 # (planning call: array expressions; a static call forms D in vmcpde_woodbury_prepare)
+        if self._floor is not None:
+            D = D + self._floor
         r, done, d0, left, dmin = self._pivoted_factor(S0, w, cap, extra=lambda: D.min())
         rho = left / dmin if dmin > 0 else float("inf")
         self.choleskyInfo = dict(engine="lowrank", mode="planning", rank=r, cap=cap, max_diag=d0, trace_left=left, min_shift=dmin, converged=done)
@@ -227,56 +227,55 @@ class LowRankRoutes:
                                      head=torch.zeros(4, dtype=global_defs.tReal).pin_memory())
         return True
 
-    def _solve_lowrank_static(self, b, F, P, update, w, D, st):
+    def _solve_lowrank_static(self, b, F, P, update, w, st):
+        """A call on the static plan: own launches only -- the hinted factorisation, `vmcpde_woodbury_prepare` (D, 1 / D, the zero rows behind the
+        rank), `vmcpde_woodbury_gram` (G = I + L^T D^-1 L on the matrix pipe), the blocked Cholesky of G, and per application of M^-1 a projection,
+        the r x r substitution in place and a combination -- no library GEMM, no framework elementwise kernel, and no copy: rank / done / step count
+        of the factorisation reach the host in the call's one health record (`TDVP._record_guard`)."""
         device, rmax = F.device, st["rmax"]
         S0 = b["S"][:P, :P]
+        ldl = w["ldl"]
         if w.get("G") is None or w["G"].shape[0] != rmax:
             need = nat.lib().vmcpde_chol_workspace_bytes(rmax)
             w["G"] = torch.zeros((rmax, rmax), dtype=global_defs.tReal, device=device)
             w["G_ws"] = torch.empty(need // 8, dtype=global_defs.tReal, device=device)
-            w["t2"] = torch.empty(rmax, dtype=global_defs.tReal, device=device)
+            w["G_part"] = torch.empty(nat.lib().vmcpde_woodbury_gram_workspace_bytes(ldl, rmax) // 8, dtype=global_defs.tReal, device=device)
             w["Su"] = torch.empty(P, dtype=global_defs.tReal, device=device)
-        G, gws, t2, Su = w["G"], w["G_ws"], w["t2"], w["Su"]
+        if w.get("D") is None or w["D"].numel() != P:
+            w["D"] = torch.empty(P, dtype=global_defs.tReal, device=device)
+            w["invD"] = torch.empty(ldl, dtype=global_defs.tReal, device=device)
+        G, gws, Su, D = w["G"], w["G_ws"], w["Su"], w["D"]
         need = gws.numel() * 8
-        w["LT"][:rmax].zero_()                                      # columns past the rank: zero, i.e. an identity block in G
         self._arm_hints(w, P)                                       # (rmax is the padded size of G; a small P caps the rank below it)
-        nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S0), S0.stride(0), P, self._lowrank_tol() or LOWRANK_TOL, 1, st["nsteps"], min(rmax, P), nat.ptr(w["LT"]), w["ldl"],
+        nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S0), S0.stride(0), P, self._lowrank_tol() or LOWRANK_TOL, 1, st["nsteps"], min(rmax, P), nat.ptr(w["LT"]), ldl,
                  nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), w["ws"].numel() * 8, nat.stream())
-        st["host"].copy_(w["state"], non_blocking=True)             # for the next call
-        st["head"].copy_(w["ws"][:4], non_blocking=True)
-        if st["event"] is None:
-            st["event"] = torch.cuda.Event()
-        st["event"].record()
-        # G = I + L^T D^-1 L, contraction length P, result only rmax x rmax: as ONE library GEMM the 256 x 256 x 4213 shape runs on 8
-        # workgroups (0.23 ms; the engine's own weighted syrk path 0.17 ms) -- as a batched GEMM over column chunks of 128 (the zero pad
-        # of the rows of LT included) it fills the chip, and the chunk sums are added up
-        ldl = w["ldl"]
-        ck = 128 if ldl % 128 == 0 else 64
-        if w.get("Dpad") is None:
-            w["Dpad"] = torch.ones(ldl, dtype=global_defs.tReal, device=device)
-        w["Dpad"][:P] = D
-        Lfull = w["LT"][:rmax]                                      # rmax x ldl, pad columns zero
-        A3 = (Lfull / w["Dpad"]).view(rmax, ldl // ck, ck).permute(1, 0, 2)
-        B3 = Lfull.view(rmax, ldl // ck, ck).permute(1, 2, 0)
-        torch.sum(torch.bmm(A3, B3), dim=0, out=G)
-        G.diagonal().add_(1.0)
+        self._static_queued = (w, st)                               # (rank, done) and the step count: for the next call, in this call's health record
+        # D = diagonalShift diag(S0) + floor, 1 / D; rows of LT past the rank: zero, i.e. an identity block in G (the factorisation rewrites rows
+        # below the rank in full -- pad columns included --, the rows behind it hold an earlier call's columns)
+        nat.call("vmcpde_woodbury_prepare", nat.ptr(b["diagS"]), float(self.diagonalShift), nat.ptr(self._floor) if self._floor is not None else None, P, ldl,
+                 nat.ptr(D), nat.ptr(w["invD"]), nat.ptr(w["LT"]), nat.ptr(w["state"]), rmax, nat.stream())
+        # G = I + L^T D^-1 L, contraction length P, result only rmax x rmax: 64 x 64 blocks x chunks of 256 parameters as independent workgroups,
+        # the scaling folded into the operand load (as ONE library GEMM the shape runs on 8 workgroups, 0.23 ms; round 5's batched GEMM + sum +
+        # division took three launches)
+        nat.call("vmcpde_woodbury_gram", nat.ptr(w["LT"]), ldl, rmax, nat.ptr(w["invD"]), nat.ptr(G), rmax, nat.ptr(w["G_part"]), w["G_part"].numel() * 8,
+                 nat.stream())
         # (its status word -- pinned pivots, i.e. a G that is not positive definite: a non-finite factor -- is the call's `info`, which
         # vmcpde_tdvp_diagnostics hands to the residual guard like the dense factorisation's)
         nat.call("vmcpde_cholesky", nat.ptr(G), rmax, rmax, nat.ptr(b["info"]), nat.ptr(gws), need, nat.stream())
 
         # u = M^-1 F, then u <- u + M^-1 (F - (S0 + D) u) against the TRUE matrix: per application two own launches around the r x r
-        # substitution (vmcpde_woodbury_project / _combine; the residual is formed inside the first)
+        # substitution (vmcpde_woodbury_project / _combine; the residual is formed inside the first; the substitution runs in place in t1)
         if w.get("wb_y") is None or w["wb_y"].numel() != P or w["wb_t1"].numel() != rmax:
             w["wb_y"] = torch.empty(P, dtype=global_defs.tReal, device=device)
             w["wb_t1"] = torch.empty(rmax, dtype=global_defs.tReal, device=device)
         yb, t1 = w["wb_y"], w["wb_t1"]
-        Dc, Fc = D.contiguous(), F.contiguous()
+        Fc = F if F.is_contiguous() else F.contiguous()
 
         def apply(u_in):
-            nat.call("vmcpde_woodbury_project", nat.ptr(w["LT"]), ldl, P, rmax, nat.ptr(Dc), nat.ptr(Fc), nat.ptr(Su) if u_in is not None else None,
+            nat.call("vmcpde_woodbury_project", nat.ptr(w["LT"]), ldl, P, rmax, nat.ptr(D), nat.ptr(Fc), nat.ptr(Su) if u_in is not None else None,
                      nat.ptr(u_in), nat.ptr(yb), nat.ptr(t1), nat.stream())
-            nat.call("vmcpde_chol_solve", nat.ptr(G), rmax, rmax, nat.ptr(t1), nat.ptr(t2), nat.ptr(gws), need, nat.stream())
-            nat.call("vmcpde_woodbury_combine", nat.ptr(w["LT"]), ldl, P, rmax, nat.ptr(Dc), nat.ptr(yb), nat.ptr(t2), nat.ptr(u_in), nat.ptr(update),
+            nat.call("vmcpde_chol_solve", nat.ptr(G), rmax, rmax, nat.ptr(t1), nat.ptr(t1), nat.ptr(gws), need, nat.stream())
+            nat.call("vmcpde_woodbury_combine", nat.ptr(w["LT"]), ldl, P, rmax, nat.ptr(D), nat.ptr(yb), nat.ptr(t1), nat.ptr(u_in), nat.ptr(update),
                      nat.stream())
 
         apply(None)
@@ -361,7 +360,7 @@ class LowRankRoutes:
                     warnings.warn(f"stedc reported {int(st['host'][0])} unconverged block(s) on the core of the spectral solve; using the library "
                                   f"eigensolver from now on", RuntimeWarning)
                     st["off"] = True
-            ok = 3 <= r <= int(nat.lib().vmcpde_sytrd_small_max_n()) and not (st is not None and st["off"]) and rocsolver.available()
+            ok = 3 <= r <= int(nat.lib().vmcpde_sytrd_medium_max_n()) and not (st is not None and st["off"]) and rocsolver.available()
             return "tridiag" if ok else "library"
         return "library"
 
@@ -376,17 +375,22 @@ class LowRankRoutes:
         st = getattr(self, "_tridiag", None)
         if st is None:
             st = self._tridiag = dict(off=False, event=None, host=torch.zeros(1, dtype=torch.int32).pin_memory())
-        nmax = int(nat.lib().vmcpde_sytrd_small_max_n())
+        # (sized for what THIS core needs: the 256-frame of the one-workgroup kernel, or -- ranks 257 .. 384, BASELINE C3 -- the frame of
+        # vmcpde_sytrd_medium with the workspace of its leading r - 256 two-launch steps)
+        nmax = int(nat.lib().vmcpde_sytrd_small_max_n()) if r <= int(nat.lib().vmcpde_sytrd_small_max_n()) else int(nat.lib().vmcpde_sytrd_medium_max_n())
         td = w.get("td")
-        if td is None:
-            td = w["td"] = dict(D=torch.empty(nmax, dtype=global_defs.tReal, device=device), E=torch.empty(nmax, dtype=global_defs.tReal, device=device),
+        if td is None or td["nmax"] < nmax:
+            nwork = max(int(nat.lib().vmcpde_sytrd_medium_workspace_bytes(nmax)) // 8, 1)
+            td = w["td"] = dict(nmax=nmax, D=torch.empty(nmax, dtype=global_defs.tReal, device=device), E=torch.empty(nmax, dtype=global_defs.tReal, device=device),
                                 tau=torch.empty(nmax, dtype=global_defs.tReal, device=device),
                                 V=torch.empty((nmax, nmax), dtype=global_defs.tReal, device=device),
                                 Z=torch.empty(nmax * nmax, dtype=global_defs.tReal, device=device),
+                                work=torch.empty(nwork, dtype=global_defs.tReal, device=device),
                                 info=torch.zeros(1, dtype=torch.int32, device=device))
+        nmax = td["nmax"]
         Tc = T if T.is_contiguous() else T.contiguous()
-        nat.call("vmcpde_sytrd_small", nat.ptr(Tc), Tc.stride(0), r, nat.ptr(td["D"]), nat.ptr(td["E"]), nat.ptr(td["tau"]), nat.ptr(td["V"]), nmax,
-                 nat.stream())
+        nat.call("vmcpde_sytrd_medium", nat.ptr(Tc), Tc.stride(0), r, nat.ptr(td["D"]), nat.ptr(td["E"]), nat.ptr(td["tau"]), nat.ptr(td["V"]), nmax,
+                 nat.ptr(td["work"]), td["work"].numel() * 8, nat.stream())
         Z = td["Z"][:r * r].view(r, r)
         rocsolver.stedc(td["D"][:r], td["E"][:r], Z, td["info"])
         st["host"].copy_(td["info"], non_blocking=True)

@@ -60,6 +60,7 @@ def _lapack_threads(P):
 _THREADPOOLS = None
 
 
+DENSE_EIGH_WARN_P = 2048    # from this many parameters on a call that ends in the dense syevd says so once (its cost is O(P^3), replicated per rank)
 DEVICE_EIGH_MIN_P = 640     # diagonalizeOnDevice=None: rocSOLVER's syevd overtakes thread-capped host LAPACK between P = 411 and 1024
 
 
@@ -156,6 +157,7 @@ class TDVP(LowRankRoutes):
         self._V = self._V_lazy = None
         self.ev = self.V = self.VtF = None
         self._ratio_host = self._ratio_event = None
+        self._ratio_queued = self._static_queued = None
         self._ratio_prev = None
         self.allreduceInfo = None
         self._uncentred_ok = False
@@ -391,12 +393,10 @@ class TDVP(LowRankRoutes):
                     b["A"][idx, idx] = scal[6]         # the floor alone: a positive pivot, update exactly 0 (F is 0 there)
                     if chol_border:
                         b["A"][P, idx] = 0.0
-            if self.gramShift == "auto":     # asynchronous safety check for the next call: no host sync here
-                if self._ratio_host is None:
-                    self._ratio_host = torch.empty(1, dtype=global_defs.tReal).pin_memory()
-                    self._ratio_event = torch.cuda.Event()
-                self._ratio_host.copy_(scal[4:5], non_blocking=True)
-                self._ratio_event.record()
+            if self.gramShift == "auto":     # asynchronous safety check for the next call: rides in the call's one health record (_record_guard)
+                if self._ratio_queued is not None:       # (a caller that never reached solve(): the figure of that call goes out on its own)
+                    self._record_guard(None, self._guard_chol, keep_guard=True)
+                self._ratio_queued = scal
         self.ElocMean, self.ElocMeanAbs, self.ElocVar = scal[0], scal[1], scal[2]     # tdvp.py:37-39
         self._scal = scal
         self._floor = scal[6] if (use_chol and self.svdTol > 0) else None
@@ -583,17 +583,43 @@ class TDVP(LowRankRoutes):
         return "eigh" if self.solver == "auto" else self.solver
 
     # ---- Cholesky health: pinned pivots and the solver residual ------------------------------------------------------
-    def _record_guard(self, out, chol):
-        """Queue (residual, pinned-pivot count) of this solve for the host without synchronising: checked by `_check_guard` at
-        the next host-side guard (the NaN check of `__call__`, `check()` -- called by the steppers before a step is accepted --, or
-        the start of the next right-hand side)."""
-        self._guard_chol = chol
-        if self._guard_host is None:
-            self._guard_host = torch.empty(4, dtype=global_defs.tReal).pin_memory()
-            self._guard_event = torch.cuda.Event()
-        self._guard_host.copy_(out, non_blocking=True)
-        self._guard_event.record()
-        self._guard_pending = True
+    # slots of the health record (8-byte words): [0:4] residual, TDVP error, pinned pivots, spare (vmcpde_tdvp_diagnostics) | [4] max_p mean_p^2 / var_p
+    # of this call's S-build | [5] (rank, done) of the low-rank factorisation (two int32) | [6:10] head of its workspace (d0, trace left, step counts)
+    _REC_WORDS = 16
+
+    def _record_guard(self, out, chol, keep_guard=False):
+        """Everything the host wants to know about this call without waiting for it -- (residual, pinned-pivot count) of the solve, the mean^2 / var
+        figure of the S-build, rank / done / step count of the low-rank factorisation on a static plan -- gathered into ONE device buffer by
+        `vmcpde_gather_words` and queued as ONE asynchronous copy into a pinned record; looked at by `_check_guard` at the next host-side guard (the
+        NaN check of `__call__`, `check()` -- called by the steppers before a step is accepted --, or the start of the next right-hand side) and by
+        the choices the next call makes (centred / uncentred operands, re-planning of the static route)."""
+        dev = (out if out is not None else self._ratio_queued).device
+        rec = getattr(self, "_rec", None)
+        if rec is None or rec["dev"].device != dev:
+            host = torch.zeros(self._REC_WORDS, dtype=global_defs.tReal).pin_memory()
+            rec = self._rec = dict(dev=torch.zeros(self._REC_WORDS, dtype=global_defs.tReal, device=dev), host=host, event=torch.cuda.Event(),
+                                   srcs=(nat.C.c_void_p * 8)(), counts=(nat.C.c_int32 * 8)())
+            self._guard_host, self._guard_event = host[0:4], rec["event"]
+        static = self._static_queued
+        parts = [(out, 4), (None if self._ratio_queued is None else self._ratio_queued[4:5], 1),
+                 (None if static is None else static[0]["state"], 1), (None if static is None else static[0]["ws"], 4)]
+        for i, (src, n) in enumerate(parts):
+            rec["srcs"][i] = None if src is None else src.data_ptr()
+            rec["counts"][i] = n
+        with torch.cuda.device(dev):
+            nat.call("vmcpde_gather_words", rec["srcs"], rec["counts"], len(parts), nat.ptr(rec["dev"]), nat.stream())
+            rec["host"].copy_(rec["dev"], non_blocking=True)
+            rec["event"].record()
+        if self._ratio_queued is not None:
+            self._ratio_host, self._ratio_event = rec["host"][4:5], rec["event"]
+            self._ratio_queued = None
+        if static is not None:           # the static plan reads (rank, done) and the step count of THIS factorisation at the next call
+            st = static[1]
+            st["host"], st["head"], st["event"] = rec["host"][5:6].view(torch.int32), rec["host"][6:10], rec["event"]
+            self._static_queued = None
+        if not keep_guard:
+            self._guard_chol = chol
+            self._guard_pending = True
 
     def check(self, when="this step"):
         """Wait for the health record of the last solve and raise if it failed (the reference's NaN exit, tdvp.py:136-141, and the
@@ -699,6 +725,15 @@ class TDVP(LowRankRoutes):
                 self.spectralInfo = dict(engine="dense")
             else:
                 self.spectralInfo = dict(self.spectralInfo, engine="dense", tried="lowrank")
+            if P >= DENSE_EIGH_WARN_P and not getattr(self, "_warned_dense_eigh", False):
+                import warnings
+                why = ("the rank-revealing engine was tried and does not apply to this S: full numerical rank, or rejected by the svdTol gate"
+                       if (self.spectralInfo or {}).get("tried") else "diagonalShift > 0, spectralEngine='dense', or the engine is backing off")
+                warnings.warn(f"spectral solve of a {P} x {P} S by the dense eigensolver (rocSOLVER syevd; {why}): about 150 ms per call at 4155 "
+                              f"parameters and 2.6 s at 16 181, replicated on every rank -- 13x the S-build's share of a sharded step "
+                              f"(profiles/r05_run2_bench_C4_eigh.json).  solver='cholesky' solves the regularised system in 2.3 / 36 ms instead; it has "
+                              f"no eigenbasis (no ev / snr).  This warning is issued once per TDVP object.", RuntimeWarning, stacklevel=3)
+                self._warned_dense_eigh = True
             try:
                 self.ev, self.V = torch.linalg.eigh(S)                        # tdvp.py:59 (rocSOLVER)
                 done = True
