@@ -366,6 +366,22 @@ int64_t vmcpde_woodbury_gram_workspace_bytes(int64_t ldl, int32_t r);
 int vmcpde_woodbury_gram(const double* LT, int64_t ldl, int32_t r, const double* invD, double* G, int64_t ldg, void* workspace,
                          int64_t workspace_bytes, void* stream);
 int vmcpde_gather_words(const void* const* srcs, const int32_t* counts, int32_t n_src, void* dst, void* stream);
+/* ABI 7: the factor of S on a FIXED pivot set, without the pivot search (what a call on a static plan runs while the previous factorisation's pivots
+ * still span S: consecutive S of a trajectory differ by sampling noise and a small step of theta).  With Pi = piv[0 .. r) in that order,
+ *   S = L L^T + R,  L = S[:, Pi] C^-T,  C C^T = S[Pi, Pi]   (the partial Cholesky on that pivot set; R = the Schur complement, positive semi-definite).
+ * gather:  T = [ S[Pi, Pi] ; S[:, Pi] ] as a tall (rmax + P) x rmax matrix (identity / zero columns beyond r); T: [dev] rows allocated to a multiple
+ *          of 128, ldt >= rmax.
+ * vmcpde_cholesky_tall(T, ldt, rmax + P, rmax, ...): Cholesky of the leading ncols x ncols block and the panel solve of all rows below it, with
+ *          the launches of vmcpde_cholesky (workspace: vmcpde_chol_workspace_bytes(ncols); info counts pinned pivots).
+ * finish:  LT[b][i] = T[rmax + i][b] (the layout every consumer of the factor reads; pad columns zero) and left[i] = S[i][i] - |L[i][:]|^2 = R_ii.
+ * check:   out = { trace(R) / min D, pinned pivots, max_i R_ii }, and the bookkeeping a pivoted run leaves: state = (r, 1), the trace in the head of the
+ *          factorisation's workspace.  The host reads it with the call's health record and decides ONE CALL LATER whether the set still holds. */
+int vmcpde_frozen_gather(const double* S, int64_t lds, int32_t P, const int32_t* piv, int32_t r, int32_t rmax, double* T, int64_t ldt, void* stream);
+int vmcpde_cholesky_tall(double* A, int64_t lda, int32_t nrows, int32_t ncols, int32_t* info, void* workspace, int64_t workspace_bytes, void* stream);
+int vmcpde_frozen_finish(const double* T, int64_t ldt, const double* S, int64_t lds, int32_t P, int32_t rmax, double* LT, int64_t ldl, double* left,
+                         void* stream);
+int vmcpde_frozen_check(const double* left, int32_t P, const double* D, int32_t r, const int32_t* chol_info, int32_t* state, void* workspace, double* out,
+                        void* stream);
 /* ABI 5: the r x r core of that decomposition (tdvp.py:57-64 on range(L)) without a library eigensolver.  One-sided Jacobi on the columns
  * of an r x r matrix C (r <= 1024): on return the columns are mutually orthogonal, C_out = U diag(sigma) with U the left singular vectors and
  * sigma the singular values of the input -- for C = R1 (the triangular factor of L = Q1 R1) the eigenvectors and the square roots of the

@@ -357,6 +357,64 @@ def test_engine_choice_and_fallbacks(headline_net):
     assert tl._eigh_lowrank(low) is None
 
 
+def test_static_calls_on_the_frozen_pivot_set(headline_net):
+    """Round 6: a call on a static plan factors S on the PREVIOUS factorisation's pivot set without searching (gather, one tall Cholesky, transpose)
+    -- the same regularised system solved to the same accuracy (fresh samples every call: S moves by sampling noise), the remainder measured and
+    reported one call later, a pivoted factorisation every FROZEN_REFRESH_AFTER + 1 calls, and a set that no longer spans S sends the next call back
+    to the pivoted factorisation while its own solve is still refined against the true matrix and guarded by the residual."""
+    import vmc_pde_amd as V
+    import vmc_pde_amd.lowrank as LR
+    from helpers import rel_err
+    _, ep, _ = headline_net
+    spec = make_spec(2, 4, (21, 21), latent="Gauss", coupling="no_add", offset=[1.0, 1.0], seed=4)
+    th = random_theta(spec, 4, out_scale=0.03)
+    N = 8192
+    vs, vs_d = make_varstate(spec, th), make_varstate(spec, th)            # the product's own sampler: fresh samples every call
+    kw = dict(nSamplesTDVP=N, nSamplesObs=N, timings=None, observables=False)
+    tp = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky")
+    td = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine="dense")
+    factors = []
+    for call in range(LR.FROZEN_REFRESH_AFTER + 4):
+        vs_d.sampler._calls = vs.sampler._calls                    # the twin draws the same samples
+        u, _ = tp(th.cuda(), 0.0, vs, ep, **kw)
+        tp.check()
+        ud, _ = td(th.cuda(), 0.0, vs_d, ep, **kw)
+        td.check()
+        assert rel_err(td.S0, tp.S0) < 1e-12
+        A = tp.S0 + torch.diag(1e-4 * torch.diag(tp.S0) + tp._floor)
+        assert float(torch.linalg.norm(A @ (u - ud)) / torch.linalg.norm(tp.F0)) < 1e-10 and float(tp.solverResidual) < 1e-11, (call, tp.choleskyInfo)
+        factors.append(tp.choleskyInfo.get("factor", tp.choleskyInfo["mode"]))
+        if factors[-1] == "frozen pivots":
+            assert tp.choleskyInfo["block_steps"] == 0
+            tp._chol_static["event"].synchronize()
+            rho, pinned, rmaxdiag = (float(v) for v in tp._chol_static["finfo"])
+            st = tp._chol_static
+            assert pinned == 0.0 and 0.0 <= rho < 1e-4 and int(st["host"][0]) == st["rank"] or int(st["host"][1]) == 1, (rho, pinned)
+    n = LR.FROZEN_REFRESH_AFTER
+    assert factors == ["planning"] + ["frozen pivots"] * n + ["pivoted"] + ["frozen pivots"] * 2, factors
+    # a pivot set that does not span S (made so by hand: the first r parameters instead of the pivots): the call's own solve still refines against
+    # the true matrix and its residual is judged by the guard; the measured remainder sends the NEXT call to the pivoted factorisation
+    w = next(iter(tp._buf_lr.values()))
+    r = tp._chol_static["rank"]
+    w["piv"][:r] = torch.arange(r, dtype=torch.int32, device="cuda")
+    tp(th.cuda(), 0.0, vs, ep, **kw)
+    assert tp.choleskyInfo["factor"] == "frozen pivots"
+    try:
+        tp.check()
+        ok = True
+    except FloatingPointError:                                        # (StaticPlanOutdated: the plan is dropped, the next call plans anew)
+        ok = False
+    tp(th.cuda(), 0.0, vs, ep, **kw)
+    tp.check()
+    assert tp.choleskyInfo.get("factor", tp.choleskyInfo["mode"]) in ("pivoted", "planning") and (ok or tp.choleskyInfo["mode"] == "planning")
+    assert float(tp.solverResidual) < 1e-11
+    # the switch
+    tn = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", frozenPivots=False)
+    for _ in range(3):
+        tn(th.cuda(), 0.0, vs, ep, **kw)
+    assert tn.choleskyInfo["factor"] == "pivoted"
+
+
 def test_lowrank_cholesky_solve_matches_the_dense_factorisation(headline_net, monkeypatch):
     """solver="cholesky" through the pivoted factor + Woodbury + refinement against the blocked factorisation of the full matrix: the
     same regularised system, so the same update to round-off -- and the fallbacks when the low-rank route does not apply."""
@@ -394,6 +452,7 @@ def test_lowrank_cholesky_solve_matches_the_dense_factorisation(headline_net, mo
     # the calls after the first run in static mode (no host read): same system, same solution; the plan is checked one call later
     tp = out["lowrank"][6]
     assert tp.choleskyInfo["mode"] == "planning" and tp._chol_static is not None and tp._chol_static["rmax"] % 128 == 0
+    tp.frozenPivots = False          # (this test is about the PIVOTED factorisation of a static call; test_static_calls_on_the_frozen_pivot_set has the other)
     steps_hinted = []
     steps_planned = tp._steps_used(tp._buf_lr[next(iter(tp._buf_lr))]["head_host"])      # the first call had no list
     for rep in range(3):
@@ -408,7 +467,7 @@ def test_lowrank_cholesky_solve_matches_the_dense_factorisation(headline_net, mo
             steps_hinted.append(tp._steps_used(tp._chol_static["head"]))
     assert steps_planned >= 12 and max(steps_hinted) <= (3 * steps_planned) // 4, (steps_planned, steps_hinted)
     # ... and without them (pivotHints=False) every call takes the unhinted count and returns the same solution
-    tn = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine="lowrank", pivotHints=False)
+    tn = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky", choleskyEngine="lowrank", pivotHints=False, frozenPivots=False)
     for rep in range(3):
         un, _ = tn(th.cuda(), 0.0, vs, ep, **kw)
         tn.check()
@@ -986,3 +1045,71 @@ def test_woodbury_prepare_and_gram_against_numpy(P, r, rank):
     nat.call("vmcpde_gather_words", srcs, counts, 4, nat.ptr(dst), nat.stream())
     h = dst.cpu()
     assert torch.equal(h[:4], a.cpu()) and float(h[4]) == -1.0 and h[5:6].view(torch.int32).tolist() == [7, -3] and torch.equal(h[6:10], d.cpu())
+
+
+@pytest.mark.parametrize("P,q,rmax", [(600, 40, 128), (4213, 200, 256), (1500, 300, 384)])
+def test_factor_on_a_frozen_pivot_set_against_numpy(P, q, rmax):
+    """ABI 7: vmcpde_frozen_gather / vmcpde_cholesky_tall / vmcpde_frozen_finish / vmcpde_frozen_check -- the partial Cholesky of S on a GIVEN
+    pivot set in a given order, S = L L^T + R with L = S[:, Pi] C^-T, C C^T = S[Pi, Pi]: against numpy's Cholesky of the pivot block and a
+    triangular solve, the remainder's diagonal against diag(S - L L^T), and the bookkeeping (state, trace) a pivoted run would leave."""
+    from vmc_pde_amd import _native as nat
+    rng = np.random.default_rng(P + q)
+    A = rng.standard_normal((P, q)) * np.logspace(0, -5, q)[None, :]
+    S = A @ A.T + 1e-13 * np.eye(P)
+    # a pivot set: greedy diagonal pivoting on S (numpy), r = q - 3 pivots, then the order slightly shuffled (a stale order)
+    d, Lg, piv = np.diag(S).copy(), np.zeros((P, q)), []
+    for k in range(q - 3):
+        p = int(np.argmax(d))
+        piv.append(p)
+        col = (S[:, p] - Lg[:, :k] @ Lg[p, :k]) / np.sqrt(d[p])
+        Lg[:, k] = col
+        d -= col * col
+        d[p] = -np.inf
+    r = len(piv)
+    for k in range(5, r - 1, 7):
+        piv[k], piv[k + 1] = piv[k + 1], piv[k]
+    piv = np.asarray(piv, dtype=np.int32)
+    lds, ldl = P + 11, (P + 63) // 64 * 64
+    Sd = torch.zeros((P, lds), dtype=torch.float64, device="cuda")
+    Sd[:, :P] = torch.from_numpy(S)
+    pivd = torch.zeros(rmax, dtype=torch.int32, device="cuda")
+    pivd[:r] = torch.from_numpy(piv)
+    rows = (rmax + P + 127) // 128 * 128
+    T = torch.zeros((rows, rmax), dtype=torch.float64, device="cuda")
+    T[:rmax + P].fill_(float("nan"))                       # every entry of the live rows is written by the gather
+    nat.call("vmcpde_frozen_gather", nat.ptr(Sd), lds, P, nat.ptr(pivd), r, rmax, nat.ptr(T), rmax, nat.stream())
+    Th = T.cpu().numpy()
+    Cref = np.eye(rmax)
+    Cref[:r, :r] = S[np.ix_(piv, piv)]
+    Bref = np.zeros((P, rmax))
+    Bref[:, :r] = S[:, piv]
+    assert np.array_equal(Th[:rmax], Cref) and np.array_equal(Th[rmax:rmax + P], Bref) and not Th[rmax + P:].any()
+    need = nat.lib().vmcpde_chol_workspace_bytes(rmax)
+    ws = torch.empty(need // 8, dtype=torch.float64, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    nat.call("vmcpde_cholesky_tall", nat.ptr(T), rmax, rmax + P, rmax, nat.ptr(info), nat.ptr(ws), need, nat.stream())
+    assert int(info.item()) == 0
+    LT = torch.full((rmax, ldl), float("nan"), dtype=torch.float64, device="cuda")
+    left = torch.full((P,), float("nan"), dtype=torch.float64, device="cuda")
+    nat.call("vmcpde_frozen_finish", nat.ptr(T), rmax, nat.ptr(Sd), lds, P, rmax, nat.ptr(LT), ldl, nat.ptr(left), nat.stream())
+    import scipy.linalg as sla
+    Cc = np.linalg.cholesky(S[np.ix_(piv, piv)])
+    Lref = sla.solve_triangular(Cc, S[:, piv].T, lower=True).T                 # P x r
+    Lh = LT.cpu().numpy()
+    assert not Lh[:, P:].any() and not Lh[r:].any()
+    scale = np.sqrt(np.abs(S).max())
+    assert np.abs(Lh[:r, :P].T - Lref).max() < 1e-9 * scale                    # (late columns: pivots of 1e-10 |S| amplify round-off)
+    Rdiag = np.diag(S) - (Lref * Lref).sum(1)
+    assert np.abs(left.cpu().numpy() - Rdiag).max() < 1e-12 * np.abs(S).max()
+    assert np.abs(Lh[:r, :P].T @ Lh[:r, :P] - Lref @ Lref.T).max() < 1e-12 * np.abs(S).max()
+    # check: the record of the call
+    D = torch.from_numpy(rng.uniform(1e-4, 1.0, P)).cuda()
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    head = torch.zeros(8, dtype=torch.float64, device="cuda")
+    out = torch.zeros(3, dtype=torch.float64, device="cuda")
+    nat.call("vmcpde_frozen_check", nat.ptr(left), P, nat.ptr(D), r, nat.ptr(info), nat.ptr(state), nat.ptr(head), nat.ptr(out), nat.stream())
+    lh = left.cpu().numpy()
+    tr = lh[lh > 0].sum()
+    assert state.tolist() == [r, 1] and float(head[1]) == pytest.approx(tr, rel=1e-12)
+    o = out.cpu().numpy()
+    assert o[0] == pytest.approx(tr / float(D.min()), rel=1e-12) and o[1] == 0.0 and o[2] == pytest.approx(lh.max(), rel=1e-14)

@@ -91,3 +91,53 @@ def test_spectral_trajectory_is_one_trajectory_on_both_engines_and_the_oracle():
     # and the regulariser matters: the Tikhonov-regularised Cholesky route is a different trajectory from the first steps on
     th_ch, cov_ch, _ = _product_leg(spec, th0, None, solver="cholesky")
     assert float(torch.linalg.norm(th_ch[-1] - th_or[-1])) / moved > 1e-3
+
+
+def test_headline_width_trajectory_against_the_committed_oracle_run():
+    """The full-width statement: 64 Heun steps of the headline network (P = 4213) at N = 4096, svdTol = 1e-3, with the draws of
+    tools/spectral_trajectory_attribution.py -- the product on its default spectral engine against the CPU oracle's run of the same steps
+    (tests/golden/oracle_headline_trajectory_N4096_svd1e-3.npz: theta after steps 16 / 32 / 48 / 64, cov_xx and the entropy of every step; 23 minutes
+    of the oracle on 8 cores, generated by that tool's --leg oracle).  Agreement is at round-off: 1e-11 of the distance travelled."""
+    import os
+    import sys
+    import vmc_pde_amd as V
+    from vmc_pde_amd import _native as nat
+    here = os.path.dirname(os.path.abspath(__file__))
+    gold = np.load(os.path.join(here, "golden", "oracle_headline_trajectory_N4096_svd1e-3.npz"), allow_pickle=True)
+    n, seed0 = int(gold["samples"]), int(gold["seed0"])
+    spec = make_spec(2, 4, (21, 21), latent="Gauss", coupling="no_add", offset=[1.0, 1.0], seed=1)
+    th0 = O.init_parameters(spec, 1)
+
+    class StageSampler:
+        key = 1
+
+        def __init__(self):
+            self.k = 0
+
+        def __call__(self, numSamples, dist_params, multipleOf=1):
+            z = torch.empty((n, 2), dtype=torch.float64, device="cuda")
+            nrm = torch.randn(n, 2, generator=torch.Generator().manual_seed(seed0 + self.k), dtype=torch.float64).cuda()
+            nat.call("vmcpde_latent_from_normals", dist_params["_model"].handle, nat.ptr(dist_params["_theta"]), nat.ptr(nrm), None, n, nat.ptr(z),
+                     nat.stream())
+            self.k += 1
+            return z[None]
+
+    vs = make_varstate(spec, th0, sampler=StageSampler())
+    eq = V.EvolutionEquation(dim=2, name=EQ)
+    tdvp = V.TDVP(svdTol=float(gold["svd_tol"]))                                     # spectralEngine="auto": the rank-revealing engine at this width
+    stepper = V.FixedStepper(timeStep=1e-4, mode="Heun", maxStep=1e-2, increase_fac=1.3)
+    marks = {int(k): i for i, k in enumerate(gold["steps"])}
+    t, worst = 0.0, 0.0
+    for k in range(64):
+        dp, dt, info = stepper.step(0, tdvp, vs.get_parameters(), evolutionEq=eq, psi=vs, nSamplesTDVP=n, nSamplesObs=n,
+                                    normFunction=lambda v, S: v @ S @ v, timings=None, integrals=None)
+        vs.set_parameters(dp)
+        t += dt
+        assert tdvp.spectralInfo["engine"] == "lowrank"
+        assert abs(t - float(gold["t"][k])) < 1e-12
+        assert abs(float(info["covar"][0, 0]) - float(gold["cov_xx"][k])) < 1e-10 and abs(float(info["entropy"]) - float(gold["entropy"][k])) < 1e-10
+        if k in marks:
+            ref = torch.from_numpy(gold["theta"][marks[k]])
+            dist = float(torch.linalg.norm(dp.cpu() - ref)) / float(torch.linalg.norm(ref - th0))
+            worst = max(worst, dist)
+    assert worst < 1e-11, worst

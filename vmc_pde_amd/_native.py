@@ -114,6 +114,10 @@ _PROTOS = {
     "vmcpde_woodbury_gram_workspace_bytes": (_i64, [_i64, _i32]),
     "vmcpde_woodbury_gram": (_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _i64, _vp]),
     "vmcpde_gather_words": (_int, [C.POINTER(_vp), C.POINTER(_i32), _i32, _vp, _vp]),
+    "vmcpde_frozen_gather": (_int, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _i64, _vp]),
+    "vmcpde_cholesky_tall": (_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
+    "vmcpde_frozen_finish": (_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "vmcpde_frozen_check": (_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "vmcpde_jacobi_shape": (_int, [_i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "vmcpde_jacobi_columns": (_int, [_vp, _i32, _i32, _vp, _vp]),
     "vmcpde_sytrd_small_max_n": (_i32, []),

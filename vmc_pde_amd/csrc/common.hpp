@@ -102,7 +102,7 @@ struct DeviceCtx {
   hipStream_t side_masked = nullptr;            // Cholesky lookahead at super-panel level: bulk updates on all but every eighth CU
   int side_masked_state = 0;                    // 0 not tried, 1 available, -1 the CU-masked stream could not be created
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool attr_chol = false, attr_gram = false, attr_gram_f32 = false, attr_gram_dma = false, attr_solve = false, attr_tridiag = false, attr_gram_w32 = false;
+  bool attr_chol = false, attr_gram = false, attr_gram_f32 = false, attr_gram_dma = false, attr_solve = false, attr_tridiag = false, attr_gram_w32 = false, attr_chol_tall = false;
   bool attr_gram_i8[4] = {false, false, false, false};   // (6 slices x 8 bits, 6 x 7, 7 x 7, 4 x 8) of the int8 experiment
   int flow_eval_lds_by[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // largest dynamic-LDS size flow_eval_kernel was raised to, by [block width variant][KD = 1, KD = 1 capped, 2, 4]
   int flow_sample_lds_by[2] = {0, 0};

@@ -1658,8 +1658,7 @@ __global__ __launch_bounds__(256) void woodbury_prepare_kernel(const double* __r
 }
 
 // partial[chunk][blk] = LT[rows of bi][chunk] diag(invD[chunk]) LT[rows of bj][chunk]^T for the 64 x 64 block (bi >= bj) of G: operands straight from
-// global memory in the MFMA's own lane layout (lane l supplies row l & 15, k = k4 + (l >> 4)) -- the factor is 8.6 MB and was written by the launches
-// just before, and 170 workgroups of eight-deep unrolled loads hide the latency; no LDS image, no barrier.
+// global memory -- the factor is 8.6 MB and was written by the launches just before, 170 workgroups hide the latency; no LDS image, no barrier.
 __global__ __launch_bounds__(256) void woodbury_gram_partial_kernel(const double* __restrict__ LT, int64_t ldl, const double* __restrict__ invD, int nblk,
                                                                     double* __restrict__ slabs) {
   int bi, bj;
@@ -1668,33 +1667,37 @@ __global__ __launch_bounds__(256) void woodbury_gram_partial_kernel(const double
   const int lr = lane & 15, lk = lane >> 4;
   const int k0 = (int)blockIdx.x * WG_KC;
   const int kn = ((int)ldl - k0 < WG_KC) ? ((int)ldl - k0) : WG_KC;
-  const double* __restrict__ ap = LT + (int64_t)(bi * WG_BLK + wr * 32 + lr) * ldl + k0 + lk;
-  const double* __restrict__ bp = LT + (int64_t)(bj * WG_BLK + wc * 32 + lr) * ldl + k0 + lk;
-  const double* __restrict__ dp = invD + k0 + lk;
+  // a lane loads FOUR consecutive parameters of its row (32 B; the 16 rows x 4 lanes of an operand fragment then read 128-B runs) and feeds
+  // element j of them to MFMA step j: the step contracts over the parameters 16 s + 4 (l >> 4) + j -- A, B and 1 / D agree on that assignment
+  const double* __restrict__ ap = LT + (int64_t)(bi * WG_BLK + wr * 32 + lr) * ldl + k0 + 4 * lk;
+  const double* __restrict__ bp = LT + (int64_t)(bj * WG_BLK + wc * 32 + lr) * ldl + k0 + 4 * lk;
+  const double* __restrict__ dp = invD + k0 + 4 * lk;
   wg_double4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (wg_double4){0.0, 0.0, 0.0, 0.0};
-  for (int k32 = 0; k32 < kn; k32 += 32) {            // (ldl is a multiple of 32: eight MFMA steps' operands in flight together)
-    double w[8], a0[8], a1[8], b0[8], b1[8];
+  for (int k32 = 0; k32 < kn; k32 += 32) {            // (ldl is a multiple of 32: two 16-parameter steps' operands in flight together)
+    wg_double4 w[2], a0[2], a1[2], b0[2], b1[2];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int k4 = k32 + 4 * u;
-      w[u] = dp[k4];
-      a0[u] = ap[k4];
-      a1[u] = ap[16 * ldl + k4];
-      b0[u] = bp[k4];
-      b1[u] = bp[16 * ldl + k4];
+    for (int u = 0; u < 2; ++u) {
+      const int k = k32 + 16 * u;
+      w[u] = *reinterpret_cast<const wg_double4*>(dp + k);
+      a0[u] = *reinterpret_cast<const wg_double4*>(ap + k);
+      a1[u] = *reinterpret_cast<const wg_double4*>(ap + 16 * ldl + k);
+      b0[u] = *reinterpret_cast<const wg_double4*>(bp + k);
+      b1[u] = *reinterpret_cast<const wg_double4*>(bp + 16 * ldl + k);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const double x0 = a0[u] * w[u], x1 = a1[u] * w[u];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, b0[u], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, b1[u], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, b0[u], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, b1[u], acc[1][1], 0, 0, 0);
-    }
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double x0 = a0[u][j] * w[u][j], x1 = a1[u][j] * w[u][j];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, b0[u][j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, b1[u][j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, b0[u][j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, b1[u][j], acc[1][1], 0, 0, 0);
+      }
   }
   double* __restrict__ out = slabs + ((int64_t)blockIdx.x * nblk + blockIdx.y) * (WG_BLK * WG_BLK);
 #pragma unroll
@@ -1740,6 +1743,137 @@ __global__ __launch_bounds__(64) void gather_words_kernel(GatherArgs a, unsigned
 }
 
 }  // namespace
+
+// ---- ABI 7: the factor of S on a FIXED pivot set (the previous factorisation's), without the pivot search ----------------------------------------
+// Consecutive S of a trajectory differ by sampling noise and a small step of theta: the parameters that spanned the numerical range of the last S
+// span this one's.  With Pi = the previous pivots in their order, S = L L^T + R with L = S[:, Pi] C^-T, C C^T = S[Pi, Pi] (the partial Cholesky on
+// that pivot set; R = the Schur complement, positive semi-definite) needs no search: gather, one tall Cholesky (vmcpde_cholesky_tall), transpose.
+// R is measured (trace, largest entry) and reported with the call's health record: the host decides one call later whether the set still holds.
+namespace {
+
+// T = [ C ; B^T ]: rows [0, rmax): C[a][b] = S[piv_a][piv_b] (identity beyond r); rows rmax + i: S[i][piv_b] = S[piv_b][i] (zero for b >= r).
+// blockIdx.y = 64-column block of T (pivot positions b); blockIdx.x < nI: the rows rmax + 64 it .. of the lower part, read as 64-long runs of the
+// rows piv_b of S (coalesced) and transposed through the LDS; blockIdx.x >= nI: a 64 x 64 block of C, gathered entry by entry.
+__global__ __launch_bounds__(256) void frozen_gather_kernel(const double* __restrict__ S, int64_t lds, int P, const int32_t* __restrict__ piv, int r, int rmax,
+                                                            double* __restrict__ T, int64_t ldt, int nI) {
+  __shared__ double tile[64][65];
+  __shared__ int rows[64];
+  const int t = (int)threadIdx.x, bt = (int)blockIdx.y;
+  if (t < 64) rows[t] = (bt * 64 + t < r) ? piv[bt * 64 + t] : -1;
+  __syncthreads();
+  if ((int)blockIdx.x < nI) {
+    const int i0 = (int)blockIdx.x * 64;
+    const int ii = t & 63;
+    for (int bb = t >> 6; bb < 64; bb += 4) {
+      const int row = rows[bb];
+      tile[bb][ii] = (row >= 0 && i0 + ii < P) ? S[(int64_t)row * lds + i0 + ii] : 0.0;
+    }
+    __syncthreads();
+    const int b = t & 63;
+    for (int q = t >> 6; q < 64; q += 4)
+      if (i0 + q < P) T[(int64_t)(rmax + i0 + q) * ldt + bt * 64 + b] = tile[b][q];
+    return;
+  }
+  const int a0 = ((int)blockIdx.x - nI) * 64;
+  const int b = t & 63;
+  for (int q = t >> 6; q < 64; q += 4) {
+    const int a = a0 + q, gb = bt * 64 + b;
+    const int ra = (a < r) ? piv[a] : -1, rb = rows[b];
+    T[(int64_t)a * ldt + gb] = (ra >= 0 && rb >= 0) ? S[(int64_t)ra * lds + rb] : ((a == gb) ? 1.0 : 0.0);
+  }
+}
+
+// LT[b][i] = T[rmax + i][b] (pad columns [P, ldl) zero) and left[i] = S[i][i] - sum_b T[rmax + i][b]^2, the diagonal of the remainder R.
+// One workgroup per 64 parameters i, all rmax columns: the row sums of squares are complete inside the workgroup (fixed order).
+__global__ __launch_bounds__(256) void frozen_finish_kernel(const double* __restrict__ T, int64_t ldt, const double* __restrict__ S, int64_t lds, int P,
+                                                            int rmax, double* __restrict__ LT, int64_t ldl, double* __restrict__ left) {
+  __shared__ double tile[64][65];
+  __shared__ double part[64][5];
+  const int t = (int)threadIdx.x, i0 = (int)blockIdx.x * 64;
+  const int row = t >> 2, seg = (t & 3) * 16;
+  double sq = 0.0;
+  for (int b0 = 0; b0 < rmax; b0 += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const double v = (i0 + row < P) ? T[(int64_t)(rmax + i0 + row) * ldt + b0 + seg + c] : 0.0;
+      tile[row][seg + c] = v;
+      sq = fma(v, v, sq);
+    }
+    __syncthreads();
+    // thread (b = t >> 2, 16 parameters from seg): row b0 + b of LT
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (i0 + seg + c < ldl) LT[(int64_t)(b0 + row) * ldl + i0 + seg + c] = tile[seg + c][row];
+  }
+  part[row][t & 3] = sq;
+  __syncthreads();
+  if (t < 64) {
+    const int i = i0 + t;
+    if (i < P) left[i] = S[(int64_t)i * lds + i] - ((part[t][0] + part[t][1]) + (part[t][2] + part[t][3]));
+  }
+}
+
+// trace and maximum of the remainder's diagonal, min D; the factorisation's bookkeeping as a pivoted run would leave it: state = (r, done),
+// PivWork::trace_left.  out = { trace(R) / min D, pinned pivots of the tall Cholesky, max_i R_ii }.  One workgroup, fixed order.
+__global__ __launch_bounds__(1024) void frozen_check_kernel(const double* __restrict__ left, int P, const double* __restrict__ D, int r,
+                                                            const int32_t* __restrict__ chol_info, int32_t* __restrict__ state, PivWork* __restrict__ work,
+                                                            double* __restrict__ out) {
+  __shared__ double s_sum[16], s_max[16], s_min[16];
+  const int t = (int)threadIdx.x;
+  double sum = 0.0, mx = 0.0, mn = __builtin_huge_val();
+  for (int i = t; i < P; i += 1024) {
+    const double v = left[i];
+    sum += (v > 0.0) ? v : 0.0;
+    mx = fmax(mx, v);
+    mn = fmin(mn, D[i]);
+  }
+  sum = wave_sum(sum);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { mx = fmax(mx, __shfl_xor(mx, o)); mn = fmin(mn, __shfl_xor(mn, o)); }
+  if ((t & 63) == 0) { s_sum[t >> 6] = sum; s_max[t >> 6] = mx; s_min[t >> 6] = mn; }
+  __syncthreads();
+  if (t == 0) {
+    double a = 0.0, b = 0.0, c = __builtin_huge_val();
+    for (int k = 0; k < 16; ++k) { a += s_sum[k]; b = fmax(b, s_max[k]); c = fmin(c, s_min[k]); }
+    state[0] = r;
+    state[1] = 1;
+    work->trace_left = a;
+    out[0] = (c > 0.0) ? a / c : __builtin_huge_val();
+    out[1] = (double)chol_info[0];
+    out[2] = b;
+  }
+}
+
+}  // namespace
+
+extern "C" int vmcpde_frozen_gather(const double* S, int64_t lds, int32_t P, const int32_t* piv, int32_t r, int32_t rmax, double* T, int64_t ldt,
+                                    void* stream) {
+  VMC_REQUIRE(S && piv && T, "vmcpde_frozen_gather: null argument");
+  VMC_REQUIRE(P >= 1 && lds >= P && r >= 1 && r <= rmax && r <= P && (rmax % 64) == 0 && ldt >= rmax, "vmcpde_frozen_gather: bad shape");
+  const int nI = (P + 63) / 64;
+  hipLaunchKernelGGL(frozen_gather_kernel, dim3((unsigned)(nI + rmax / 64), (unsigned)(rmax / 64)), dim3(256), 0, (hipStream_t)stream, S, lds, P, piv, r, rmax,
+                     T, ldt, nI);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vmcpde_frozen_finish(const double* T, int64_t ldt, const double* S, int64_t lds, int32_t P, int32_t rmax, double* LT, int64_t ldl,
+                                    double* left, void* stream) {
+  VMC_REQUIRE(T && S && LT && left, "vmcpde_frozen_finish: null argument");
+  VMC_REQUIRE(P >= 1 && lds >= P && (rmax % 64) == 0 && rmax >= 64 && ldt >= rmax && ldl >= P && (ldl % 64) == 0, "vmcpde_frozen_finish: bad shape");
+  hipLaunchKernelGGL(frozen_finish_kernel, dim3((unsigned)(ldl / 64)), dim3(256), 0, (hipStream_t)stream, T, ldt, S, lds, P, rmax, LT, ldl, left);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vmcpde_frozen_check(const double* left, int32_t P, const double* D, int32_t r, const int32_t* chol_info, int32_t* state, void* workspace,
+                                   double* out, void* stream) {
+  VMC_REQUIRE(left && D && chol_info && state && workspace && out && P >= 1, "vmcpde_frozen_check: bad argument");
+  hipLaunchKernelGGL(frozen_check_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, left, P, D, r, chol_info, state, static_cast<PivWork*>(workspace), out);
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 extern "C" int vmcpde_woodbury_prepare(const double* diagS, double shift, const double* floor_dev, int32_t P, int64_t ldl, double* D, double* invD,
                                        double* LT, const int32_t* state, int32_t rmax, void* stream) {

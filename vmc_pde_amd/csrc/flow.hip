@@ -128,11 +128,11 @@ Regions make_regions(const FlowProgram& fp, int kdirs, int JB) {
 #define LD(u) (c.lds[(u) * c.lanes + c.lane])
 // The waves of a workgroup talk to each other through LDS only (per-sample vectors, the weight stage); what they write to global memory -- the
 // Jacobian rows, logp, g, hv -- is never read back inside the kernel.  __syncthreads() is a workgroup-scope release + acquire around s_barrier,
-// i.e. it also waits for every outstanding GLOBAL store of the wave (s_waitcnt vmcnt(0)): each of the ~170 barriers of a sample group would stall
-// on the Jacobian stores issued just before it.  VMC_FLOW_LDS_BARRIER (default): wait for the wave's LDS traffic only, then s_barrier -- the row
-// stores drain behind the arithmetic that follows.  (The keep-activations path DOES read its own global stores back: it keeps the full fence.)
+// i.e. it also waits for every outstanding GLOBAL store of the wave.  -DVMC_FLOW_LDS_BARRIER=1 waits for the wave's LDS traffic only, then
+// s_barrier -- MEASURED NEUTRAL in round 6 (Eloc + J at C2 0.617 against 0.612 ms, C4 0.511 / 0.505, C3 2.22 / 2.19: profiles/r06_flow_barrier_ab.txt):
+// the kernel is not waiting for its stores at the barriers.  Kept as an A/B knob; the default is the plain barrier.
 #ifndef VMC_FLOW_LDS_BARRIER
-#define VMC_FLOW_LDS_BARRIER 1
+#define VMC_FLOW_LDS_BARRIER 0
 #endif
 #ifdef VMC_FLOW_DIAG_NO_SYNC       // timing diagnostics only (results are wrong): what the workgroup barriers cost
 #define SYNC() ((void)0)

@@ -1377,6 +1377,63 @@ extern "C" int vmcpde_cholesky(double* A, int64_t lda, int32_t P, int32_t* info,
   return 0;
 }
 
+// ABI 7: Cholesky of the leading ncols x ncols block of a TALL matrix and the panel solve of everything below it,
+//   A = [ A11 ; A21 ]  (nrows x ncols, row-major, lda >= ncols)   ->   [ L11 ; A21 L11^-T ],
+// with the launches of vmcpde_cholesky (16-wide diagonal block riding in the update launch, 16- / 32-row strips): the block columns behind
+// ncols do not exist, so a panel's update stops at the last block column.  What it is for: the factor of S on a FIXED pivot set Pi --
+// A11 = S[Pi, Pi], A21 = S[:, Pi] -- i.e. the columns L = S[:, Pi] L11^-T of the low-rank solve without the pivot search (lowrank.py).
+extern "C" int vmcpde_cholesky_tall(double* A, int64_t lda, int32_t nrows, int32_t ncols, int32_t* info, void* workspace, int64_t workspace_bytes,
+                                    void* stream) {
+  VMC_REQUIRE(A && info && workspace, "vmcpde_cholesky_tall: null argument");
+  VMC_REQUIRE(ncols >= NB && (ncols % NB) == 0 && nrows >= ncols, "vmcpde_cholesky_tall: ncols must be a positive multiple of %d and <= nrows", NB);
+  VMC_REQUIRE(lda >= ncols && (lda % 2) == 0 && lda < (1 << 22), "lda must be even, >= ncols and < 2^22");
+  VMC_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0, "A must be 16-byte aligned");
+  VMC_REQUIRE(workspace_bytes >= vmcpde_chol_workspace_bytes(ncols), "cholesky workspace too small (vmcpde_chol_workspace_bytes(ncols))");
+  hipStream_t st = (hipStream_t)stream;
+  double* Linv = static_cast<double*>(workspace);
+  const int nbc = ncols / NB, nb = (nrows + NB - 1) / NB;
+  const size_t diag_lds = ((size_t)NB * DP + 4 * SB * 17 + 2 * SB) * sizeof(double);
+  const size_t strip_lds = (size_t)(NB + 32) * SP * sizeof(double);
+  DeviceCtx* ctx = device_ctx();
+  if (!ctx) return -2;
+  {
+    DeviceCtxLock lock;
+    if (!ctx->attr_chol_tall) {
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_strip_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds));
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_strip_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds));
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_diag16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
+      VMC_CHECK_HIP(hipFuncSetAttribute((const void*)chol_update_diag16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
+      ctx->attr_chol_tall = true;
+    }
+  }
+  VMC_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), st));
+  hipLaunchKernelGGL(chol_diag16_kernel, dim3(1), dim3(D16_THREADS), diag_lds, st, A, lda, 0, NB, Linv, info);
+  for (int k = 0; k < nbc; ++k) {
+    const int k0 = k * NB, c0 = k0 + NB;
+    const int nrem = nb - (k + 1);                                     // block rows below the panel (all of A21 included)
+    if (nrem <= 0) break;
+    const double* Lk = Linv + (int64_t)k * NB * NB;
+    const bool last = (k + 1 == nbc);
+    if (8 * nrem <= 256) {
+      hipLaunchKernelGGL(chol_strip_kernel<16>, dim3(8 * nrem), dim3(256), strip_lds, st, A, lda, nrows, k0, 1, c0, 0, Lk);
+      if (!last) hipLaunchKernelGGL(chol_strip_kernel<16>, dim3(8 * nrem), dim3(256), strip_lds, st, A, lda, nrows, k0, 1, c0, 1, Lk);
+    } else {
+      hipLaunchKernelGGL(chol_strip_kernel<32>, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, nrows, k0, 1, c0, 0, Lk);
+      if (!last) hipLaunchKernelGGL(chol_strip_kernel<32>, dim3(4 * nrem), dim3(256), strip_lds, st, A, lda, nrows, k0, 1, c0, 1, Lk);
+    }
+    if (last) break;
+    // the other block columns up to ncols (rows j .. nb-1 of column j), and the next diagonal block as workgroup 0
+    const int jlo = k + 2, jhi = nbc;
+    int64_t ntiles = 0;
+    for (int j = jlo; j < jhi; ++j) ntiles += nb - j;
+    const int tpw = (ntiles <= 255) ? 1 : 2;
+    hipLaunchKernelGGL(chol_update_diag16_kernel, dim3(1u + (unsigned)((ntiles + tpw - 1) / tpw)), dim3(D16_THREADS), diag_lds, st, A, lda, nrows, k0, NB,
+                       jlo, jhi > jlo ? jhi : jlo, nb, (int)ntiles, tpw, c0, Linv + (int64_t)(k + 1) * NB * NB, info);
+  }
+  VMC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int vmcpde_chol_solve(const double* L, int64_t lda, int32_t P, const double* F, double* u, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
   VMC_REQUIRE(L && F && u && workspace, "vmcpde_chol_solve: null argument");

@@ -55,6 +55,8 @@ LOWRANK_CHOL_MIN_P = 4096   # choleskyEngine="auto": the low-rank solve from thi
                             #   read in the step; with one (planning mode) 2.5 ms.  P = 16 181: 7 against 38 ms
 LOWRANK_SOLVE_RHO = 1e-4    # low-rank Cholesky solve: largest trace(R) / min D accepted (the contraction factor of its iterative refinement)
 LOWRANK_RETRY_AFTER = 50    # "auto": calls on the dense path after one whose rank exceeded the cap, before the next attempt
+FROZEN_REFRESH_AFTER = 7    # static plan: consecutive calls that factor S on the PREVIOUS pivot set (no search) before a pivoted factorisation refreshes
+                            #   the set -- earlier when the remainder it measures (trace(R) / min D, reported one call later) outgrows LOWRANK_SOLVE_RHO
 LOWRANK_GATE_RETRY_AFTER = 8 * LOWRANK_RETRY_AFTER   # ... after one the svdTol gate rejected (the spectrum moves along a trajectory, slowly)
 
 
@@ -95,6 +97,9 @@ class LowRankRoutes:
                 w["piv"][:saved["piv"].numel()] = saved["piv"].to(device)
                 w["state"].copy_(saved["state"].to(device))
                 w["head_host"].copy_(saved["head"])
+                # (the head of the device workspace too -- d0, trace left, step counts: a call on the frozen pivot set does not rewrite it, and the
+                # record it sends to the host must carry the last pivoted factorisation's step count as in the uninterrupted run)
+                w["ws"][:4].copy_(saved.get("ws_head", saved["head"]).to(device))
             self._lr_restore = None
         return w
 
@@ -181,6 +186,7 @@ class LowRankRoutes:
         w = self._lowrank_buffers(P, device, cap)
         st = self._chol_static
         if st is not None and st["P"] == P and st["rmax"] <= w["LT"].shape[0]:
+            prev_rank = st["rank"]
             if st["event"] is not None:                 # the previous static call's factorisation: finished, with room to spare?
                 st["event"].synchronize()
                 prev_rank, prev_done = int(st["host"][0]), int(st["host"][1])
@@ -190,7 +196,17 @@ class LowRankRoutes:
                     used = self._steps_used(st["head"])
                     st["nsteps"] = used + max(3, used // 3)
             if st is not None:
-                self._solve_lowrank_static(b, F, P, update, w, st)
+                # Factor on the previous pivot set, without the search (vmcpde_frozen_gather / vmcpde_cholesky_tall / vmcpde_frozen_finish)?  Yes while
+                # the set is fresh -- at most FROZEN_REFRESH_AFTER calls since the last pivoted factorisation -- and the last such call's remainder,
+                # read here one call later, was small (trace(R) / min D within the refinement's contraction bound, no pinned pivot).  A function of
+                # host values every rank holds identically.
+                frozen = bool(getattr(self, "frozenPivots", True)) and os.environ.get("VMCPDE_FROZEN_PIVOTS", "1") != "0" and prev_rank >= 1 and \
+                    st.get("frozen_run", 0) < FROZEN_REFRESH_AFTER
+                if frozen and st.get("frozen_last"):
+                    rho, pinned = float(st["finfo"][0]), float(st["finfo"][1])
+                    frozen = pinned == 0.0 and rho <= LOWRANK_SOLVE_RHO          # (a NaN fails the comparison)
+                st["frozen_run"] = st.get("frozen_run", 0) + 1 if frozen else 0
+                self._solve_lowrank_static(b, F, P, update, w, st, frozen_rank=prev_rank if frozen else None)
                 return True
         D = b["diagS"] * float(self.diagonalShift)                 # (planning call: array expressions; a static call forms D in vmcpde_woodbury_prepare)
         if self._floor is not None:
@@ -227,7 +243,7 @@ class LowRankRoutes:
                                      head=torch.zeros(4, dtype=global_defs.tReal).pin_memory())
         return True
 
-    def _solve_lowrank_static(self, b, F, P, update, w, st):
+    def _solve_lowrank_static(self, b, F, P, update, w, st, frozen_rank=None):
         """A call on the static plan: own launches only -- the hinted factorisation, `vmcpde_woodbury_prepare` (D, 1 / D, the zero rows behind the
         rank), `vmcpde_woodbury_gram` (G = I + L^T D^-1 L on the matrix pipe), the blocked Cholesky of G, and per application of M^-1 a projection,
         the r x r substitution in place and a combination -- no library GEMM, no framework elementwise kernel, and no copy: rank / done / step count
@@ -246,14 +262,33 @@ class LowRankRoutes:
             w["invD"] = torch.empty(ldl, dtype=global_defs.tReal, device=device)
         G, gws, Su, D = w["G"], w["G_ws"], w["Su"], w["D"]
         need = gws.numel() * 8
-        self._arm_hints(w, P)                                       # (rmax is the padded size of G; a small P caps the rank below it)
-        nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S0), S0.stride(0), P, self._lowrank_tol() or LOWRANK_TOL, 1, st["nsteps"], min(rmax, P), nat.ptr(w["LT"]), ldl,
-                 nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), w["ws"].numel() * 8, nat.stream())
-        self._static_queued = (w, st)                               # (rank, done) and the step count: for the next call, in this call's health record
+        if frozen_rank is not None:
+            # S = L L^T + R on the previous factorisation's pivot set (w["piv"][:r], in its order): gather [S[Pi, Pi]; S[:, Pi]], one tall Cholesky (two
+            # panels at the headline size instead of ~10 block steps of two launches with their arg-max searches), transpose into the factor's layout
+            r = int(frozen_rank)
+            if w.get("T") is None or w["T"].shape[1] != rmax:
+                w["T"] = torch.zeros((_round_up(rmax + P, 128), rmax), dtype=global_defs.tReal, device=device)     # (pad rows: read by the strips, never written)
+                w["T_ws"] = torch.empty(nat.lib().vmcpde_chol_workspace_bytes(rmax) // 8, dtype=global_defs.tReal, device=device)
+                w["left"] = torch.empty(P, dtype=global_defs.tReal, device=device)
+                w["finfo"] = torch.zeros(3, dtype=global_defs.tReal, device=device)
+                w["T_info"] = torch.zeros(1, dtype=torch.int32, device=device)
+            T = w["T"]
+            nat.call("vmcpde_frozen_gather", nat.ptr(S0), S0.stride(0), P, nat.ptr(w["piv"]), r, rmax, nat.ptr(T), rmax, nat.stream())
+            nat.call("vmcpde_cholesky_tall", nat.ptr(T), rmax, rmax + P, rmax, nat.ptr(w["T_info"]), nat.ptr(w["T_ws"]), w["T_ws"].numel() * 8, nat.stream())
+            nat.call("vmcpde_frozen_finish", nat.ptr(T), rmax, nat.ptr(S0), S0.stride(0), P, rmax, nat.ptr(w["LT"]), ldl, nat.ptr(w["left"]), nat.stream())
+        else:
+            self._arm_hints(w, P)                                   # (rmax is the padded size of G; a small P caps the rank below it)
+            nat.call("vmcpde_pivoted_cholesky_blocked", nat.ptr(S0), S0.stride(0), P, self._lowrank_tol() or LOWRANK_TOL, 1, st["nsteps"], min(rmax, P), nat.ptr(w["LT"]), ldl,
+                     nat.ptr(w["piv"]), nat.ptr(w["state"]), nat.ptr(w["ws"]), w["ws"].numel() * 8, nat.stream())
+        # (rank, done), the step count and -- frozen set -- the measured remainder: for the next call, in this call's health record
+        self._static_queued = (w, st, frozen_rank is not None)
         # D = diagonalShift diag(S0) + floor, 1 / D; rows of LT past the rank: zero, i.e. an identity block in G (the factorisation rewrites rows
         # below the rank in full -- pad columns included --, the rows behind it hold an earlier call's columns)
         nat.call("vmcpde_woodbury_prepare", nat.ptr(b["diagS"]), float(self.diagonalShift), nat.ptr(self._floor) if self._floor is not None else None, P, ldl,
                  nat.ptr(D), nat.ptr(w["invD"]), nat.ptr(w["LT"]), nat.ptr(w["state"]), rmax, nat.stream())
+        if frozen_rank is not None:                                 # trace(R) / min D, pinned pivots, max R_ii; state = (r, done) as a pivoted run leaves it
+            nat.call("vmcpde_frozen_check", nat.ptr(w["left"]), P, nat.ptr(D), int(frozen_rank), nat.ptr(w["T_info"]), nat.ptr(w["state"]), nat.ptr(w["ws"]),
+                     nat.ptr(w["finfo"]), nat.stream())
         # G = I + L^T D^-1 L, contraction length P, result only rmax x rmax: 64 x 64 blocks x chunks of 256 parameters as independent workgroups,
         # the scaling folded into the operand load (as ONE library GEMM the shape runs on 8 workgroups, 0.23 ms; round 5's batched GEMM + sum +
         # division took three launches)
@@ -282,8 +317,8 @@ class LowRankRoutes:
         for _ in range(st["nref"]):
             nat.call("vmcpde_gemv", nat.ptr(b["S"]), b["Ppad"], P, P, 0, nat.ptr(update), nat.ptr(Su), nat.stream())
             apply(update)
-        self.choleskyInfo = dict(engine="lowrank", mode="static", rmax=rmax, block_steps=st["nsteps"], refinements=st["nref"],
-                                 planned_rank=st["rank"])
+        self.choleskyInfo = dict(engine="lowrank", mode="static", rmax=rmax, block_steps=0 if frozen_rank is not None else st["nsteps"], refinements=st["nref"],
+                                 planned_rank=st["rank"], factor="frozen pivots" if frozen_rank is not None else "pivoted")
 
     # ---- tdvp.py:57-64 for a numerically rank-deficient S -----------------------------------------------------------
     def _eigh_lowrank(self, S):
@@ -509,7 +544,9 @@ class LowRankRoutes:
             if st["event"] is not None:
                 st["event"].synchronize()
             out["chol_static"] = {k: st[k] for k in ("P", "rmax", "nsteps", "nref", "rank")}
-            out["chol_static"].update(host=st["host"].clone(), head=st["head"].clone(), called=st["event"] is not None)
+            out["chol_static"].update(host=st["host"].clone(), head=st["head"].clone(), called=st["event"] is not None,
+                                      frozen_run=int(st.get("frozen_run", 0)), frozen_last=bool(st.get("frozen_last", False)),
+                                      finfo=None if st.get("finfo") is None else st["finfo"].clone())
         return out
 
     def _lowrank_load_state(self, st):
@@ -519,6 +556,8 @@ class LowRankRoutes:
         self._buf_lr = {}
         self._lr_restore = st.get("factor")
         plan = st.get("chol_static")
+        if self._lr_restore is not None and plan is not None and plan.get("called"):
+            self._lr_restore = dict(self._lr_restore, ws_head=plan["head"].clone())        # (what the last static call left in the workspace head)
         self._chol_static = None
         if plan is not None:
             ev = None
@@ -526,4 +565,6 @@ class LowRankRoutes:
                 ev = torch.cuda.Event()
                 ev.record()
             self._chol_static = dict(P=plan["P"], rmax=plan["rmax"], nsteps=plan["nsteps"], nref=plan["nref"], rank=plan["rank"], event=ev,
-                                     host=plan["host"].clone().pin_memory(), head=plan["head"].clone().pin_memory())
+                                     host=plan["host"].clone().pin_memory(), head=plan["head"].clone().pin_memory(),
+                                     frozen_run=int(plan.get("frozen_run", 0)), frozen_last=bool(plan.get("frozen_last", False)),
+                                     finfo=None if plan.get("finfo") is None else plan["finfo"].clone())
