@@ -118,6 +118,14 @@ def test_gram_fp32_dma_variant(P, N, monkeypatch):
     assert torch.equal(a, _gram(JT32, ldj, P, N, f32=1))                                # deterministic
     monkeypatch.setenv("VMCPDE_GRAM_F32_DMA", "0")
     b = _gram(JT32, ldj, P, N, f32=1)
+    if N % 2:
+        # an odd sample count keeps the register-staged loop (round 6): the pair loop would read the float BEHIND the last sample, and vmcpde.h
+        # promises a zero pad only for jt_f32 = 2 -- a caller's garbage there must not enter the sums
+        assert torch.equal(a, b)
+        monkeypatch.delenv("VMCPDE_GRAM_F32_DMA")
+        JT32[:P, N] = 7.0
+        assert torch.equal(_gram(JT32, ldj, P, N, f32=1), a)
+        return
     assert not torch.equal(a, b)                                                         # (it really is another loop)
     S1, S0 = _unpack(a, P), _unpack(b, P)
     assert np.array_equal(S1, S1.T)
