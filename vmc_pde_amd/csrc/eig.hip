@@ -1596,23 +1596,31 @@ __global__ __launch_bounds__(256) void woodbury_project_kernel(const double* __r
   if (t == 0) t1[k] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
-// out[p] = (u ? u[p] : 0) + y[p] - (sum_k LT[k][p] t2[k]) / D[p]: one thread per parameter, the r rows of LT read coalesced
-__global__ __launch_bounds__(64) void woodbury_combine_kernel(const double* __restrict__ LT, int64_t ldl, int P, int r, const double* __restrict__ D,
-                                                              const double* __restrict__ y, const double* __restrict__ t2,
-                                                              const double* u, double* out /* may alias u: no __restrict__ on the pair */) {
-  const int p = (int)blockIdx.x * 64 + (int)threadIdx.x;
-  if (p >= P) return;
+// out[p] = (u ? u[p] : 0) + y[p] - (sum_k LT[k][p] t2[k]) / D[p]: 64 parameters per workgroup, the r rows of LT (read coalesced) dealt to the four
+// waves, wave partials added in a fixed order (round 5 ran ONE wave per 64 parameters over all r rows: 21 us for 8.6 MB; this form has 4x the loads in flight)
+__global__ __launch_bounds__(256) void woodbury_combine_kernel(const double* __restrict__ LT, int64_t ldl, int P, int r, const double* __restrict__ D,
+                                                               const double* __restrict__ y, const double* __restrict__ t2,
+                                                               const double* u, double* out /* may alias u: no __restrict__ on the pair */) {
+  __shared__ double part[4][64];
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+  const int p = (int)blockIdx.x * 64 + lane;
+  const bool in = p < P;
+  const int pp = in ? p : P - 1;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int k = 0;
-  for (; k + 4 <= r; k += 4) {
-    a0 = fma(LT[(int64_t)k * ldl + p], t2[k], a0);
-    a1 = fma(LT[(int64_t)(k + 1) * ldl + p], t2[k + 1], a1);
-    a2 = fma(LT[(int64_t)(k + 2) * ldl + p], t2[k + 2], a2);
-    a3 = fma(LT[(int64_t)(k + 3) * ldl + p], t2[k + 3], a3);
+  int k = wave;
+  for (; k + 12 < r; k += 16) {
+    a0 = fma(LT[(int64_t)k * ldl + pp], t2[k], a0);
+    a1 = fma(LT[(int64_t)(k + 4) * ldl + pp], t2[k + 4], a1);
+    a2 = fma(LT[(int64_t)(k + 8) * ldl + pp], t2[k + 8], a2);
+    a3 = fma(LT[(int64_t)(k + 12) * ldl + pp], t2[k + 12], a3);
   }
-  for (; k < r; ++k) a0 = fma(LT[(int64_t)k * ldl + p], t2[k], a0);
-  const double corr = ((a0 + a1) + (a2 + a3)) / D[p];
-  out[p] = (u ? u[p] : 0.0) + y[p] - corr;
+  for (; k < r; k += 4) a0 = fma(LT[(int64_t)k * ldl + pp], t2[k], a0);
+  part[wave][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (wave == 0 && in) {
+    const double corr = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) / D[p];
+    out[p] = (u ? u[p] : 0.0) + y[p] - corr;
+  }
 }
 
 }  // namespace
@@ -1934,7 +1942,7 @@ extern "C" int vmcpde_woodbury_combine(const double* LT, int64_t ldl, int32_t P,
                                        const double* u, double* out, void* stream) {
   VMC_REQUIRE(LT && D && y && t2 && out, "vmcpde_woodbury_combine: null argument");
   VMC_REQUIRE(P >= 1 && r >= 1 && ldl >= P, "vmcpde_woodbury_combine: bad shape");
-  hipLaunchKernelGGL(woodbury_combine_kernel, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, (hipStream_t)stream, LT, ldl, P, r, D, y, t2, u, out);
+  hipLaunchKernelGGL(woodbury_combine_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, (hipStream_t)stream, LT, ldl, P, r, D, y, t2, u, out);
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -162,6 +162,12 @@ namespace jbA { constexpr int JB = VMC_FLOW_JB;
 #include "flow_kernels.inc"
 }
 namespace jbB = jbA;
+#define VMC_FLOW_FAST_PATH 1
+namespace jbAf { constexpr int JB = VMC_FLOW_JB;
+#include "flow_kernels.inc"
+}
+#undef VMC_FLOW_FAST_PATH
+namespace jbBf = jbAf;
 constexpr int JB_A = VMC_FLOW_JB, JB_B = VMC_FLOW_JB;
 #else
 namespace jbA { constexpr int JB = 6;
@@ -170,8 +176,22 @@ namespace jbA { constexpr int JB = 6;
 namespace jbB { constexpr int JB = 5;
 #include "flow_kernels.inc"
 }
+// the same device code with the model's switches fixed to the common model (no_add, Gauss, fp64 rows, no global_change): see flow_kernels.inc
+#define VMC_FLOW_FAST_PATH 1
+namespace jbAf { constexpr int JB = 6;
+#include "flow_kernels.inc"
+}
+namespace jbBf { constexpr int JB = 5;
+#include "flow_kernels.inc"
+}
+#undef VMC_FLOW_FAST_PATH
 constexpr int JB_A = 6, JB_B = 5;
 #endif
+
+// the common model: every run-time switch of the device code at the value the fast namespaces fix (VMCPDE_FLOW_FAST=0: the general code, for an A/B)
+bool flow_fast_path(const FlowProgram& fp, int jt_f32) {
+  return fp.coupling == VMCPDE_COUPLING_NO_ADD && fp.latent == VMCPDE_LATENT_GAUSS && !fp.global_change && !jt_f32 && env_int("VMCPDE_FLOW_FAST", 1) != 0;
+}
 
 #ifdef VMC_FLOW_STAMPS
 extern "C" int vmcpde_debug_read_flow_stamps(unsigned long long* out_host, int reset) {
@@ -418,16 +438,17 @@ extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const doub
   const int wg_lds = (160 * 1024) / bytes, wg_cap = 16 / waves;
   const bool cap = (kd == 1) && ((wg_lds < wg_cap ? wg_lds : wg_cap) * waves > 12) && env_int("VMCPDE_FLOW_CAP", 1);
   const int variant = (kd == 4) ? 3 : (kd == 2) ? 2 : cap ? 1 : 0;
+  const bool fast = flow_fast_path(m->host, (int)jt_f32);
 #define VMC_FLOW_EVAL_KERNEL(NS_)                                                                                            \
   ((kd == 4) ? (const void*)NS_::flow_eval_kernel<4> : (kd == 2) ? (const void*)NS_::flow_eval_kernel<2>                     \
    : cap ? (const void*)NS_::flow_eval_kernel<1, true> : (const void*)NS_::flow_eval_kernel<1>)
-  const void* kern = useB ? VMC_FLOW_EVAL_KERNEL(jbB) : VMC_FLOW_EVAL_KERNEL(jbA);
+  const void* kern = fast ? (useB ? VMC_FLOW_EVAL_KERNEL(jbBf) : VMC_FLOW_EVAL_KERNEL(jbAf)) : (useB ? VMC_FLOW_EVAL_KERNEL(jbB) : VMC_FLOW_EVAL_KERNEL(jbA));
 #undef VMC_FLOW_EVAL_KERNEL
   if (bytes > 64 * 1024) {
     DeviceCtx* ctx = device_ctx();
     if (!ctx) return -2;
     DeviceCtxLock lock;
-    int& have = ctx->flow_eval_lds_by[useB ? 1 : 0][variant];
+    int& have = ctx->flow_eval_lds_by[(useB ? 1 : 0) + (fast ? 2 : 0)][variant];
     if (bytes > have) {
       VMC_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       have = bytes;
@@ -447,8 +468,13 @@ extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const doub
     else if (cap) VMC_LAUNCH_FLOW_EVAL(NS_, 1, true);  \
     else VMC_LAUNCH_FLOW_EVAL(NS_, 1);                 \
   } while (0)
-  if (useB) VMC_LAUNCH_FLOW_EVAL_NS(jbB);
-  else VMC_LAUNCH_FLOW_EVAL_NS(jbA);
+  if (fast) {
+    if (useB) VMC_LAUNCH_FLOW_EVAL_NS(jbBf);
+    else VMC_LAUNCH_FLOW_EVAL_NS(jbAf);
+  } else {
+    if (useB) VMC_LAUNCH_FLOW_EVAL_NS(jbB);
+    else VMC_LAUNCH_FLOW_EVAL_NS(jbA);
+  }
 #undef VMC_LAUNCH_FLOW_EVAL_NS
 #undef VMC_LAUNCH_FLOW_EVAL
   VMC_CHECK_HIP(hipGetLastError());
@@ -468,24 +494,30 @@ extern "C" int vmcpde_flow_sample(vmcpde_model* m, const double* theta, const do
   int bytes = 0;
   const int lanes = pick_lanes(r.total, r.wgt, waves, &bytes);
   VMC_REQUIRE(bytes <= 160 * 1024, "network too wide for the LDS-resident flow kernel");
+  const bool fast = flow_fast_path(m->host, 0);
+  const void* kern = fast ? (useB ? (const void*)jbBf::flow_sample_kernel : (const void*)jbAf::flow_sample_kernel)
+                          : (useB ? (const void*)jbB::flow_sample_kernel : (const void*)jbA::flow_sample_kernel);
   if (bytes > 64 * 1024) {
     DeviceCtx* ctx = device_ctx();
     if (!ctx) return -2;
     DeviceCtxLock lock;
-    int& have = ctx->flow_sample_lds_by[useB ? 1 : 0];
+    int& have = ctx->flow_sample_lds_by[(useB ? 1 : 0) + (fast ? 2 : 0)];
     if (bytes > have) {
-      VMC_CHECK_HIP(hipFuncSetAttribute(useB ? (const void*)jbB::flow_sample_kernel : (const void*)jbA::flow_sample_kernel,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      VMC_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       have = bytes;
     }
   }
   const int64_t grid = (n_samples + lanes - 1) / lanes;
-  if (useB)
-    hipLaunchKernelGGL(jbB::flow_sample_kernel, dim3((unsigned)grid), dim3(64 * waves), bytes, st, m->dev, m->cache, theta, z, n_samples, inv, x, logp,
-                       lanes, r);
-  else
-    hipLaunchKernelGGL(jbA::flow_sample_kernel, dim3((unsigned)grid), dim3(64 * waves), bytes, st, m->dev, m->cache, theta, z, n_samples, inv, x, logp,
-                       lanes, r);
+#define VMC_LAUNCH_FLOW_SAMPLE(NS_) \
+  hipLaunchKernelGGL(NS_::flow_sample_kernel, dim3((unsigned)grid), dim3(64 * waves), bytes, st, m->dev, m->cache, theta, z, n_samples, inv, x, logp, lanes, r)
+  if (fast) {
+    if (useB) VMC_LAUNCH_FLOW_SAMPLE(jbBf);
+    else VMC_LAUNCH_FLOW_SAMPLE(jbAf);
+  } else {
+    if (useB) VMC_LAUNCH_FLOW_SAMPLE(jbB);
+    else VMC_LAUNCH_FLOW_SAMPLE(jbA);
+  }
+#undef VMC_LAUNCH_FLOW_SAMPLE
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
 }
