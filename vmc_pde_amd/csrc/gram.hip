@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const TIn* __restrict__ JT
 // vmcpde_gram_rows, whose perm holds the global indices of the tiles of a few tile rows)
 __global__ __launch_bounds__(256, GRAM_BKD == 8 ? 3 : 2) void gram_dma_kernel(const double* __restrict__ JT, int64_t ldj, int64_t N, int ntiles, int nsplit,
                                                           int64_t chunk, int total_units, int units_per_xcd, int order,
-                                                          const int* __restrict__ perm, double* __restrict__ out, int ntiles_out) {
+                                                          const int* __restrict__ perm, double* __restrict__ out, int ntiles_out, int P) {
   extern __shared__ double lds[];
   int split, tile;
   if (!gram_unit(ntiles, nsplit, total_units, units_per_xcd, order, perm, split, tile)) return;
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256, GRAM_BKD == 8 ? 3 : 2) void gram_dma_kernel(co
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  tile_mainloop_dma<GRAM_BKD>(acc, JT, ldj, ti * TILE, JT, ldj, tj * TILE, ti == tj, k0, k1, lds);
+  // (rows of the tile's A block below P are zero padding: a wave that holds nothing else idles -- the last tile row when P ends in the first half of a tile)
+  tile_mainloop_dma<GRAM_BKD>(acc, JT, ldj, ti * TILE, JT, ldj, tj * TILE, ti == tj, k0, k1, lds, -1, P - ti * TILE);
   tile_store(acc, out + ((int64_t)split * ntiles_out + tile) * (TILE * TILE));
 }
 
@@ -468,7 +469,7 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
       ctx->attr_gram_dma = true;
     }
     hipLaunchKernelGGL(gram_dma_kernel, dim3(grid), dim3(256), dma_lds, st, static_cast<const double*>(JT), ldj, n_samples, g.ntiles,
-                       g.nsplit, g.chunk, total, per_xcd, order, perm, out, g.ntiles);
+                       g.nsplit, g.chunk, total, per_xcd, order, perm, out, g.ntiles, (int)P);
   } else if (jt_f32) VMC_LAUNCH_GRAM_T(float);
   else VMC_LAUNCH_GRAM_T(double);
 #undef VMC_LAUNCH_GRAM_T
@@ -538,7 +539,7 @@ extern "C" int vmcpde_gram_rows(const double* JT, int64_t ldj, int32_t P, int64_
     ctx->attr_gram_dma = true;
   }
   hipLaunchKernelGGL(gram_dma_kernel, dim3(per_xcd * 8), dim3(256), dma_lds, st, JT, ldj, n_samples, nsub, g.nsplit, g.chunk, nsub * g.nsplit,
-                     per_xcd, 2, it->second, out, g.ntiles);
+                     per_xcd, 2, it->second, out, g.ntiles, (int)P);
   VMC_CHECK_HIP(hipGetLastError());
   if (g.nsplit > 1) {
     const int64_t count = (int64_t)nsub * TILE * TILE, pitch = (int64_t)g.ntiles * TILE * TILE, off = (int64_t)t0 * TILE * TILE;

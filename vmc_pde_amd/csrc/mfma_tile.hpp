@@ -421,7 +421,10 @@ constexpr int F32_BLOCK_STEPS = 4;
 template <int BKD, int MODE = 0>
 __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const double* __restrict__ A, int64_t lda, int rowA0,
                                                   const double* __restrict__ B, int64_t ldb, int rowB0, bool alias, int64_t k0,
-                                                  int64_t k1, double* __restrict__ lds, int tid = -1) {
+                                                  int64_t k1, double* __restrict__ lds, int tid = -1, int rows_valid_a = TILE) {
+  // rows_valid_a: rows of the A block that hold data (the rest is zero padding).  A wave whose 64 rows are ALL padding forms no products
+  // (round 6): the last tile row of a P that ends in the first half of a tile -- P + 2 = 4157 = 32 x 128 + 61 at BASELINE C4 -- is 33 tiles of
+  // which the lower half is zeros; its accumulators stay zero, which is what the products would have been.
   using G = DmaGeom<BKD>;
   constexpr int DTB = G::DT;
   // tid: index of this thread among the 256 that form the tile (default threadIdx.x; workgroups that carry two tiles pass
@@ -454,7 +457,7 @@ __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const 
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc32[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
   }
-  const bool active = !alias || wr >= wc;      // the quadrant above the diagonal of a diagonal tile forms no products
+  const bool active = (!alias || wr >= wc) && (64 * wr < rows_valid_a);      // the quadrant above the diagonal of a diagonal tile forms no products; nor do rows of padding
   const int boff = alias ? 0 : DTB;
   const int64_t nfull = (k1 - k0) / BKD;
   const int64_t tail = (k1 - k0) - nfull * BKD;
@@ -490,7 +493,7 @@ __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const 
     } else if constexpr (MODE == 2) {
       if (active) mma_kstep_swz_w32<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff);
     } else {
-      mma_kstep_sym<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff, alias);
+      if (active) mma_kstep_swz<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff);
     }
     VMC_STAMP(1)
 #ifndef VMC_GRAM_DIAG_NO_WAIT        // timing diagnostics only (results are wrong): what the DMA wait / the K-step barrier cost
@@ -531,7 +534,7 @@ __device__ __forceinline__ void tile_mainloop_dma(double4_t (&acc)[4][4], const 
     } else if constexpr (MODE == 2) {
       if (active) mma_kstep_swz_w32<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff);
     } else {
-      mma_kstep_sym<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff, alias);
+      if (active) mma_kstep_swz<BKD>(acc, lds, cur * 2 * DTB, cur * 2 * DTB + boff, wr, wc, koff);
     }
     __syncthreads();
   }
