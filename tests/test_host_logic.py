@@ -313,3 +313,24 @@ def test_rhovar_from_ritz_vectors_positions_and_values_on_cpu():
     assert np.abs(rho[pos] - rho_dense[pos]).max() < 1e-12 * top
     nullpos = np.setdiff1d(np.arange(P), pos)
     assert not rho[nullpos].any() and np.abs(rho_dense[nullpos]).max() < 1e-12 * top
+
+
+def test_frozen_pivot_set_decision():
+    """The host-side rule of the static low-rank route (round 6): which calls factor S on the previous pivot set -- a pure function of values
+    every rank holds (lowrank.frozen_set_decision)."""
+    from vmc_pde_amd import lowrank as LR
+    f = LR.frozen_set_decision
+    n = LR.FROZEN_REFRESH_AFTER
+    assert f(True, 206, 0, False, None) and f(True, 206, n - 1, True, (1e-6, 0.0))
+    assert not f(True, 206, n, True, (1e-6, 0.0))                       # the set is refreshed after n calls in a row
+    assert not f(False, 206, 0, False, None) and not f(True, 0, 0, False, None)
+    assert not f(True, 206, 2, True, (2 * LR.LOWRANK_SOLVE_RHO, 0.0))   # the remainder outgrew the refinement's contraction bound
+    assert not f(True, 206, 2, True, (1e-6, 1.0))                       # a pinned pivot
+    assert not f(True, 206, 2, True, (float("nan"), 0.0)) and not f(True, 206, 2, True, (float("inf"), 0.0))
+    # the cadence it produces: n frozen calls, one pivoted, n frozen ...
+    run, seq = 0, []
+    for _ in range(2 * n + 3):
+        d = f(True, 206, run, bool(seq) and seq[-1], (1e-7, 0.0))
+        run = run + 1 if d else 0
+        seq.append(d)
+    assert seq == [True] * n + [False] + [True] * n + [False] + [True]

@@ -64,6 +64,19 @@ def _round_up(v, m):
     return (v + m - 1) // m * m
 
 
+def frozen_set_decision(enabled, prev_rank, frozen_run, last_was_frozen, last_record):
+    """Does THIS call on a static plan factor S on the previous pivot set (True) or run the pivoted factorisation (False)?  A pure function of host
+    values every rank holds identically: the switch, the rank the last factorisation reported, how many calls in a row have already used the set
+    (at most FROZEN_REFRESH_AFTER), and -- when the last call was such a call -- the remainder it measured, `last_record` = (trace(R) / min D, pinned
+    pivots): above the refinement's contraction bound LOWRANK_SOLVE_RHO, not finite, or with a pinned pivot, the set no longer spans S."""
+    if not enabled or prev_rank < 1 or frozen_run >= FROZEN_REFRESH_AFTER:
+        return False
+    if last_was_frozen:
+        rho, pinned = last_record
+        return bool(pinned == 0.0 and rho <= LOWRANK_SOLVE_RHO)          # (a NaN fails the comparison)
+    return True
+
+
 class StaticPlanOutdated(FloatingPointError):
     """The numerical rank of S outgrew the static plan of the low-rank solve within one call, so that call's update failed the residual
     guard.  The plan has been dropped: repeating the step (the steppers do, once: `retry_step`) runs a planning call."""
@@ -200,11 +213,9 @@ class LowRankRoutes:
                 # the set is fresh -- at most FROZEN_REFRESH_AFTER calls since the last pivoted factorisation -- and the last such call's remainder,
                 # read here one call later, was small (trace(R) / min D within the refinement's contraction bound, no pinned pivot).  A function of
                 # host values every rank holds identically.
-                frozen = bool(getattr(self, "frozenPivots", True)) and os.environ.get("VMCPDE_FROZEN_PIVOTS", "1") != "0" and prev_rank >= 1 and \
-                    st.get("frozen_run", 0) < FROZEN_REFRESH_AFTER
-                if frozen and st.get("frozen_last"):
-                    rho, pinned = float(st["finfo"][0]), float(st["finfo"][1])
-                    frozen = pinned == 0.0 and rho <= LOWRANK_SOLVE_RHO          # (a NaN fails the comparison)
+                enabled = bool(getattr(self, "frozenPivots", True)) and os.environ.get("VMCPDE_FROZEN_PIVOTS", "1") != "0"
+                frozen = frozen_set_decision(enabled, prev_rank, st.get("frozen_run", 0), bool(st.get("frozen_last")),
+                                             None if not st.get("frozen_last") else (float(st["finfo"][0]), float(st["finfo"][1])))
                 st["frozen_run"] = st.get("frozen_run", 0) + 1 if frozen else 0
                 self._solve_lowrank_static(b, F, P, update, w, st, frozen_rank=prev_rank if frozen else None)
                 return True
