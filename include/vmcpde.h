@@ -123,6 +123,12 @@ int64_t vmcpde_flow_eval_workspace_bytes(const vmcpde_model* m, int64_t n_sample
 int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const double* x, int64_t n_samples,
                      const double* dirs, int32_t n_dirs, double* logp, double* g, double* hv,
                      void* JT, int64_t ldj, int32_t jt_f32, void* workspace, int64_t workspace_bytes, void* stream);
+/* ABI 7: the same evaluation for a batch given by its LATENT points z (what the samplers draw, sampler.py:72-86): x_out ([dev] n_samples * dim) is an
+ * OUTPUT -- the inverse flow of z (var_state.py:76-79), produced by the reverse sweep as it walks back from the latent end, where the adjoint of the
+ * latent density is known -- and the Taylor pass then runs forward from that x.  One launch instead of vmcpde_flow_sample(inv = 1) + vmcpde_flow_eval;
+ * the same numbers to round-off (the sweep divides by exp(s) where the inverse flow multiplies by exp(-s)). */
+int vmcpde_flow_eval_from_latent(vmcpde_model* m, const double* theta, const double* z, int64_t n_samples, const double* dirs, int32_t n_dirs,
+                                 double* x_out, double* logp, double* g, double* hv, void* JT, int64_t ldj, int32_t jt_f32, void* stream);
 
 /* ---- evolutionEq.py ------------------------------------------------------------------------------------ */
 /* evolutionEq.py:84-119 epilogue: Eloc_n from x, g and the directional second derivatives (J14 + eager einsums).

@@ -63,6 +63,7 @@ _PROTOS = {
     "vmcpde_flow_sample": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp]),
     "vmcpde_flow_eval_workspace_bytes": (_i64, [_vp, _i64]),
     "vmcpde_flow_eval": (_int, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "vmcpde_flow_eval_from_latent": (_int, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "vmcpde_rhs": (_int, [C.POINTER(EqConsts), _i32, _vp, _vp, _vp, _i32, _vp, _f64, _i64, _vp, _vp]),
     "vmcpde_eloc_stats": (_int, [_vp, _i64, _vp, _vp]),
     "vmcpde_row_moments": (_int, [_vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -104,7 +104,7 @@ struct DeviceCtx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool attr_chol = false, attr_gram = false, attr_gram_f32 = false, attr_gram_dma = false, attr_solve = false, attr_tridiag = false, attr_gram_w32 = false, attr_chol_tall = false;
   bool attr_gram_i8[4] = {false, false, false, false};   // (6 slices x 8 bits, 6 x 7, 7 x 7, 4 x 8) of the int8 experiment
-  int flow_eval_lds_by[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // largest dynamic-LDS size flow_eval_kernel was raised to, by [block width variant + 2 x fast path][KD = 1, KD = 1 capped, 2, 4]
+  int flow_eval_lds_by[8][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // largest dynamic-LDS size flow_eval_kernel was raised to, by [block width variant + 2 x fast path + 4 x from-latent][KD = 1, KD = 1 capped, 2, 4]
   int flow_sample_lds_by[4] = {0, 0, 0, 0};
   int jacobi_lds[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // dynamic-LDS size jacobi_step_kernel<rows / 64> was raised to
   std::map<int64_t, int*> gram_perms;           // [dev] Gram tile orders (position -> lower-triangle tile index): key = number of row blocks (whole triangle, built once)

@@ -398,16 +398,17 @@ extern "C" int64_t vmcpde_flow_eval_workspace_bytes(const vmcpde_model* m, int64
   return (int64_t)m->host.act_units * ldw * (int64_t)sizeof(double);
 }
 
-extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const double* x, int64_t n_samples,
-                                const double* dirs, int32_t n_dirs, double* logp, double* g, double* hv,
-                                void* JT, int64_t ldj, int32_t jt_f32, void* workspace, int64_t workspace_bytes, void* stream) {
+// x given (zin == NULL): the batch by its points.  zin given: the batch by its LATENT points; x (= xout) is then an output (flow_eval_kernel<.., true>).
+static int flow_eval_impl(vmcpde_model* m, const double* theta, const double* x, const double* zin, double* xout, int64_t n_samples,
+                          const double* dirs, int32_t n_dirs, double* logp, double* g, double* hv,
+                          void* JT, int64_t ldj, int32_t jt_f32, void* workspace, int64_t workspace_bytes, void* stream) {
   VMC_REQUIRE(n_samples >= 0, "negative sample count");
   if (n_samples == 0) return 0;   // empty batch (torch gives a NULL data pointer for it)
-  VMC_REQUIRE(m && theta && x, "vmcpde_flow_eval: null argument");
+  VMC_REQUIRE(m && theta && (x || (zin && xout)), "vmcpde_flow_eval: null argument");
   VMC_REQUIRE(n_dirs >= 0 && n_dirs <= VMCPDE_MAX_DIRS, "n_dirs %d outside [0,%d]", n_dirs, VMCPDE_MAX_DIRS);
   VMC_REQUIRE(n_dirs == 0 || (dirs && hv), "directions given without dirs/hv buffers");
   VMC_REQUIRE(JT == nullptr || ldj >= n_samples, "ldj %lld < n_samples %lld", (long long)ldj, (long long)n_samples);
-  if (n_samples == 0) return 0;
+  const bool from_latent = zin != nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (int rc = vmcpde_prepare_latent_internal(m, theta, st)) return rc;
   // Hessian directions per forward pass: 4 or 2 when every workgroup of the launch is still resident at once with the larger
@@ -439,16 +440,18 @@ extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const doub
   const bool cap = (kd == 1) && ((wg_lds < wg_cap ? wg_lds : wg_cap) * waves > 12) && env_int("VMCPDE_FLOW_CAP", 1);
   const int variant = (kd == 4) ? 3 : (kd == 2) ? 2 : cap ? 1 : 0;
   const bool fast = flow_fast_path(m->host, (int)jt_f32);
-#define VMC_FLOW_EVAL_KERNEL(NS_)                                                                                            \
-  ((kd == 4) ? (const void*)NS_::flow_eval_kernel<4> : (kd == 2) ? (const void*)NS_::flow_eval_kernel<2>                     \
-   : cap ? (const void*)NS_::flow_eval_kernel<1, true> : (const void*)NS_::flow_eval_kernel<1>)
+#define VMC_FLOW_EVAL_KERNEL_FL(NS_, FL_)                                                                                                  \
+  ((kd == 4) ? (const void*)NS_::flow_eval_kernel<4, false, FL_> : (kd == 2) ? (const void*)NS_::flow_eval_kernel<2, false, FL_>           \
+   : cap ? (const void*)NS_::flow_eval_kernel<1, true, FL_> : (const void*)NS_::flow_eval_kernel<1, false, FL_>)
+#define VMC_FLOW_EVAL_KERNEL(NS_) (from_latent ? VMC_FLOW_EVAL_KERNEL_FL(NS_, true) : VMC_FLOW_EVAL_KERNEL_FL(NS_, false))
   const void* kern = fast ? (useB ? VMC_FLOW_EVAL_KERNEL(jbBf) : VMC_FLOW_EVAL_KERNEL(jbAf)) : (useB ? VMC_FLOW_EVAL_KERNEL(jbB) : VMC_FLOW_EVAL_KERNEL(jbA));
 #undef VMC_FLOW_EVAL_KERNEL
+#undef VMC_FLOW_EVAL_KERNEL_FL
   if (bytes > 64 * 1024) {
     DeviceCtx* ctx = device_ctx();
     if (!ctx) return -2;
     DeviceCtxLock lock;
-    int& have = ctx->flow_eval_lds_by[(useB ? 1 : 0) + (fast ? 2 : 0)][variant];
+    int& have = ctx->flow_eval_lds_by[(useB ? 1 : 0) + (fast ? 2 : 0) + (from_latent ? 4 : 0)][variant];
     if (bytes > have) {
       VMC_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       have = bytes;
@@ -460,13 +463,18 @@ extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const doub
 #define VMC_LAUNCH_FLOW_EVAL(NS_, ...)                                                                                                   \
   hipLaunchKernelGGL((NS_::flow_eval_kernel<__VA_ARGS__>), dim3((unsigned)grid), dim3(64 * waves), bytes, st, m->dev, m->cache, theta, x, \
                      n_samples, dirs, (hv ? n_dirs : 0), logp, g, hv, JT, ldj, (int)jt_f32, static_cast<double*>(workspace),             \
-                     (int64_t)((n_samples + 63) / 64 * 64), lanes, r)
-#define VMC_LAUNCH_FLOW_EVAL_NS(NS_)                   \
-  do {                                                 \
-    if (kd == 4) VMC_LAUNCH_FLOW_EVAL(NS_, 4);         \
-    else if (kd == 2) VMC_LAUNCH_FLOW_EVAL(NS_, 2);    \
-    else if (cap) VMC_LAUNCH_FLOW_EVAL(NS_, 1, true);  \
-    else VMC_LAUNCH_FLOW_EVAL(NS_, 1);                 \
+                     (int64_t)((n_samples + 63) / 64 * 64), lanes, r, zin, xout)
+#define VMC_LAUNCH_FLOW_EVAL_FL(NS_, FL_)                   \
+  do {                                                      \
+    if (kd == 4) VMC_LAUNCH_FLOW_EVAL(NS_, 4, false, FL_);  \
+    else if (kd == 2) VMC_LAUNCH_FLOW_EVAL(NS_, 2, false, FL_); \
+    else if (cap) VMC_LAUNCH_FLOW_EVAL(NS_, 1, true, FL_);  \
+    else VMC_LAUNCH_FLOW_EVAL(NS_, 1, false, FL_);          \
+  } while (0)
+#define VMC_LAUNCH_FLOW_EVAL_NS(NS_)                        \
+  do {                                                      \
+    if (from_latent) VMC_LAUNCH_FLOW_EVAL_FL(NS_, true);    \
+    else VMC_LAUNCH_FLOW_EVAL_FL(NS_, false);               \
   } while (0)
   if (fast) {
     if (useB) VMC_LAUNCH_FLOW_EVAL_NS(jbBf);
@@ -476,9 +484,27 @@ extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const doub
     else VMC_LAUNCH_FLOW_EVAL_NS(jbA);
   }
 #undef VMC_LAUNCH_FLOW_EVAL_NS
+#undef VMC_LAUNCH_FLOW_EVAL_FL
 #undef VMC_LAUNCH_FLOW_EVAL
   VMC_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const double* x, int64_t n_samples,
+                                const double* dirs, int32_t n_dirs, double* logp, double* g, double* hv,
+                                void* JT, int64_t ldj, int32_t jt_f32, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (n_samples > 0) VMC_REQUIRE(x, "vmcpde_flow_eval: null argument");
+  return flow_eval_impl(m, theta, x, nullptr, nullptr, n_samples, dirs, n_dirs, logp, g, hv, JT, ldj, jt_f32, workspace, workspace_bytes, stream);
+}
+
+// ABI 7: the same evaluation for a batch given by its LATENT points z (what vmcpde_sample_latent / the MCMC sampler draw): x = inverse flow of z is
+// an OUTPUT, produced by the reverse sweep on its way from the latent end (var_state.py:76-79 + :55-67 in one launch: the separate inverse-flow
+// launch of a TDVP call is gone).  Same outputs as vmcpde_flow_sample(inv = 1) followed by vmcpde_flow_eval at its x -- to round-off, not bit for bit:
+// the sweep divides by exp(s) where the inverse flow multiplies by exp(-s).
+extern "C" int vmcpde_flow_eval_from_latent(vmcpde_model* m, const double* theta, const double* z, int64_t n_samples, const double* dirs, int32_t n_dirs,
+                                            double* x_out, double* logp, double* g, double* hv, void* JT, int64_t ldj, int32_t jt_f32, void* stream) {
+  if (n_samples > 0) VMC_REQUIRE(z && x_out, "vmcpde_flow_eval_from_latent: null argument");
+  return flow_eval_impl(m, theta, nullptr, z, x_out, n_samples, dirs, n_dirs, logp, g, hv, JT, ldj, jt_f32, nullptr, 0, stream);
 }
 
 extern "C" int vmcpde_flow_sample(vmcpde_model* m, const double* theta, const double* z, int64_t n_samples, int inv,
