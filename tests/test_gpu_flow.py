@@ -291,3 +291,63 @@ def test_model_descriptor_limits_fail_loudly(kw, msg):
         V.VarState(sampler, dim, 1, depth, network_args=dict(intmediate=hidden, offset=off, latentSpaceName="Gauss", dim=dim),
                    inds_up=ups, inds_down=dns)
     assert msg in str(err.value), str(err.value)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+@pytest.mark.parametrize("jdtype", [None, "f32"])
+def test_evaluate_from_latent_matches_sample_then_evaluate(cfg, jdtype):
+    """ABI 7, vmcpde_flow_eval_from_latent: one launch from the LATENT points -- the reverse sweep starts at z and produces x on its way, the Taylor
+    pass runs forward from that x -- against the two launches it replaces (inverse flow, then the evaluation at its x) and against the oracle's
+    inverse flow: x, log p, grad_x, every directional second derivative (more directions than one pass carries where d allows) and the Jacobian.
+    Ragged sample counts: idle and shadow lanes take part in the barriers and must not disturb their neighbours."""
+    dim = cfg[0]
+    for n in ((70, 1) if cfg[2] != (21, 21) else (40,)):
+        spec, th, z = _setup(cfg, n)
+        kw = {} if jdtype is None else {"jacobian_dtype": torch.float32}
+        vs, vs2 = make_varstate(spec, th, **kw), make_varstate(spec, th, **kw)
+        if cfg[4].endswith("+global"):
+            # net.py:150-151: the reference's inverse direction with global_change is not the inverse of its forward map (restated as written in
+            # the oracle and in vmcpde_flow_sample), so the sweep's x would not be the reference's samples: the entry point refuses such a model
+            from vmc_pde_amd import _native as nat
+            with pytest.raises(nat.VmcpdeError, match="global_change"):
+                vs2.evaluate_from_latent(z, dirs=np.eye(dim))
+            return
+        dirs = np.eye(dim) if dim <= 8 else np.eye(dim)[::3]
+        x1, _ = vs.flow_sample(z)
+        r1 = vs.evaluate(x1, dirs=dirs)
+        ref = {k: r1[k].clone() for k in ("logp", "g", "hv")}
+        J1 = r1["J"].clone()
+        r2 = vs2.evaluate_from_latent(z, dirs=dirs)
+        x_o, _ = O.VarStateOracle(spec, th).flow_sample(z)
+        assert rel_err(r2["x"], x_o[0]) < 1e-12 and rel_err(r2["x"], x1[0]) < 1e-13
+        assert rel_err(r2["logp"], ref["logp"]) < 1e-12 and rel_err(r2["g"], ref["g"]) < 1e-10 and rel_err(r2["hv"], ref["hv"]) < 1e-9
+        tolJ = 1e-11 if jdtype is None else 1e-6
+        assert float((r2["J"].double() - J1.double()).abs().max()) < tolJ * float(J1.double().abs().max())
+        assert torch.isfinite(r2["J"]).all() and r2["J"].shape == J1.shape
+
+
+def test_tdvp_call_with_and_without_the_fused_sample_evaluation(monkeypatch):
+    """TDVP.__call__ draws the latent points and evaluates them in one flow launch (`evolutionEq.from_latent`); VMCPDE_FUSED_SAMPLE_EVAL=0 keeps the
+    reference's two calls (psi.sample, then evolutionEq(psi, x, t)).  Same samples, same S, F, update to round-off; a psi whose `sample` was
+    replaced by the caller is never bypassed."""
+    import vmc_pde_amd as V
+    dim, N = 6, 2000
+    off = np.array([1.0, 0.0, 0.0, 1.0, 0.0, 0.0])
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("VMCPDE_FUSED_SAMPLE_EVAL", fused)
+        sampler = V.Sampler(key=3, dim=dim, name="Gauss", mcmc_info={"offset": off, "bound": 0.25})
+        vs = V.VarState(sampler, dim, 1, 4, network_args={"intmediate": (5, 5), "offset": off, "latentSpaceName": "Gauss", "dim": dim})
+        th = vs.get_parameters().clone()
+        th += 0.05 * torch.randn(th.shape, dtype=th.dtype, device=th.device, generator=torch.Generator(device=th.device).manual_seed(2))
+        eq = V.EvolutionEquation(dim=dim, name="advection_hamiltonian_wDiss")
+        tp = V.TDVP(diagonalShift=1e-4, svdTol=1e-6, solver="cholesky")
+        u, info = tp(th, 0.0, vs, eq, nSamplesTDVP=N, nSamplesObs=N, timings=None, integrals=False)
+        out[fused] = (u.clone(), tp.S0.clone(), tp.F0.clone(), info["x1"].clone(), info["covar"].clone(), float(info["entropy"]))
+    a, b = out["1"], out["0"]
+    assert rel_err(a[1], b[1]) < 1e-11 and rel_err(a[2], b[2]) < 1e-10 and rel_err(a[0], b[0]) < 1e-7
+    assert rel_err(a[3], b[3]) < 1e-12 and rel_err(a[4], b[4]) < 1e-12 and abs(a[5] - b[5]) < 1e-12
+    monkeypatch.setenv("VMCPDE_FUSED_SAMPLE_EVAL", "1")
+    assert V.TDVP._fused_sample_eval(vs, eq)
+    vs.sample = lambda numSamples: V.VarState.sample(vs, numSamples)
+    assert not V.TDVP._fused_sample_eval(vs, eq)

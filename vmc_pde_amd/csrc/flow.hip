@@ -504,6 +504,10 @@ extern "C" int vmcpde_flow_eval(vmcpde_model* m, const double* theta, const doub
 extern "C" int vmcpde_flow_eval_from_latent(vmcpde_model* m, const double* theta, const double* z, int64_t n_samples, const double* dirs, int32_t n_dirs,
                                             double* x_out, double* logp, double* g, double* hv, void* JT, int64_t ldj, int32_t jt_f32, void* stream) {
   if (n_samples > 0) VMC_REQUIRE(z && x_out, "vmcpde_flow_eval_from_latent: null argument");
+  // net.py:150-151: with global_change the reference's inverse direction applies the block's affine step AFTER its inverse couplings -- as written
+  // it is not the inverse of the forward map (the oracle restates it as written), so the samples of var_state.py:79 are not the points the
+  // reverse sweep arrives at.  Such a model keeps the two launches (vmcpde_flow_sample, then vmcpde_flow_eval at its x).
+  VMC_REQUIRE(!m || !m->host.global_change, "vmcpde_flow_eval_from_latent: a model with global_change samples through vmcpde_flow_sample (net.py:150-151 is not the inverse map)");
   return flow_eval_impl(m, theta, nullptr, z, x_out, n_samples, dirs, n_dirs, logp, g, hv, JT, ldj, jt_f32, nullptr, 0, stream);
 }
 

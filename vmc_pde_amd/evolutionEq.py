@@ -76,6 +76,17 @@ class EvolutionEquation:
         """evolutionEq.py:81-82."""
         c, dirs, Dmat = self._consts_and_dirs(vState.device)
         r = vState.evaluate(configs, dirs=dirs)
+        return self._rhs(vState, r, c, Dmat, t)
+
+    def from_latent(self, vState, latent_space_samples, t):
+        """The same for a batch given by its LATENT points (what `vState.sampler` draws): one launch produces the points x themselves (the inverse
+        flow, var_state.py:79), log p, grad_x, the directional second derivatives and the Jacobian (`VarState.evaluate_from_latent`).
+        Returns (configs (1,N,d), Eloc (1,N), param_grads (1,N,P), logProbs (1,N))."""
+        c, dirs, Dmat = self._consts_and_dirs(vState.device)
+        r = vState.evaluate_from_latent(latent_space_samples, dirs=dirs)
+        return (r["x"][None, ...], *self._rhs(vState, r, c, Dmat, t))
+
+    def _rhs(self, vState, r, c, Dmat, t):
         n = r["n"]
         eloc = torch.empty(n, dtype=global_defs.tReal, device=vState.device)
         hv = r["hv"]

@@ -913,6 +913,23 @@ class TDVP(LowRankRoutes):
         radius = torch.rand((1, n), generator=g, dtype=global_defs.tReal, device=psi.device)
         return samples / torch.linalg.norm(samples, dim=-1, keepdim=True) * radius[..., None] ** (1 / dim)
 
+    @staticmethod
+    def _fused_sample_eval(psi, evolutionEq):
+        """Sampling + evaluation in one flow launch (`evolutionEq.from_latent`)?  Only for the package's own objects used as they come: a `psi` whose
+        `sample` / `evaluate` a caller has replaced (tests record what was drawn; a driver may hand its own samples) or an `evolutionEq` of another
+        type keeps the reference's two calls.  VMCPDE_FUSED_SAMPLE_EVAL=0: the two launches (A/B)."""
+        if os.environ.get("VMCPDE_FUSED_SAMPLE_EVAL", "1") == "0":
+            return False
+        from .var_state import VarState
+        from .evolutionEq import EvolutionEquation
+        if type(evolutionEq) is not EvolutionEquation or not isinstance(psi, VarState) or getattr(psi, "keep_activations", False):
+            return False
+        if getattr(psi.net, "global_change", False):      # (net.py:150-151: the reference's inverse direction is not the inverse map there)
+            return False
+        overridden = {"sample", "evaluate", "flow_sample", "draw_latent", "evaluate_from_latent", "__call__"} & set(vars(psi))
+        same_class = all(getattr(type(psi), name) is getattr(VarState, name) for name in ("sample", "evaluate", "flow_sample", "draw_latent", "evaluate_from_latent"))
+        return not overridden and same_class
+
     # ---- tdvp.py:96-164 ------------------------------------------------------------------------------------------
     def __call__(self, netParameters, t, psi, evolutionEq, **rhsArgs):
         nSamplesTDVP = rhsArgs["nSamplesTDVP"]
@@ -932,13 +949,23 @@ class TDVP(LowRankRoutes):
                 timings.stop_timing(name)
 
         with self._Section(self, "sample+flow"):
-            start_timing("sampling")
-            sampleConfigs, logProbs = psi.sample(numSamples=nSamplesTDVP)         # tdvp.py:117
-            stop_timing("sampling")
+            if self._fused_sample_eval(psi, evolutionEq):
+                # tdvp.py:117 + :122 with ONE flow launch: the sampler's latent points go straight to the evaluation, whose reverse sweep produces
+                # the samples x on its way from the latent end (VarState.evaluate_from_latent) -- no separate inverse-flow launch
+                start_timing("sampling")
+                latent = psi.draw_latent(nSamplesTDVP)
+                stop_timing("sampling")
+                start_timing("compute Eloc")
+                sampleConfigs, Eloc, sampleGradients, logProbs = evolutionEq.from_latent(psi, latent, t)
+                stop_timing("compute Eloc")
+            else:
+                start_timing("sampling")
+                sampleConfigs, logProbs = psi.sample(numSamples=nSamplesTDVP)         # tdvp.py:117
+                stop_timing("sampling")
 
-            start_timing("compute Eloc")
-            Eloc, sampleGradients, logProbs = evolutionEq(psi, sampleConfigs, t)  # tdvp.py:122
-            stop_timing("compute Eloc")
+                start_timing("compute Eloc")
+                Eloc, sampleGradients, logProbs = evolutionEq(psi, sampleConfigs, t)  # tdvp.py:122
+                stop_timing("compute Eloc")
 
         start_timing("solve TDVP eqn.")
         update, self.solverResidual, self.tdvp_error = self.solve(Eloc, sampleGradients, logProbs, psi=psi)   # tdvp.py:127

@@ -190,6 +190,34 @@ class VarState:
         z = self.sampler(numSamples, dist_params)
         return self.flow_sample(z)
 
+    def draw_latent(self, numSamples):
+        """The first half of `sample` (var_state.py:77-78): the sampler's latent points (1, n, d), shifted by the offset."""
+        dist_params = _LatentParams(self, self.dim, self.net, self._theta)
+        return self.sampler(numSamples, dist_params)
+
+    def evaluate_from_latent(self, latent_space_samples, dirs=None):
+        """`flow_sample` + `evaluate` in ONE launch for a batch given by its latent points (`vmcpde_flow_eval_from_latent`): the reverse sweep of
+        csrc/flow.hip walks the flow backwards from the latent end with the exact inverse of every coupling half-step -- that IS the inverse flow
+        z -> x of var_state.py:79 -- so it starts at z, produces x on its way, and the Taylor pass then runs forward from that x.  Returns
+        `evaluate`'s dict; `x` is a fresh tensor the caller may keep.  Same numbers as the two launches to round-off (not bit for bit)."""
+        z = torch.as_tensor(latent_space_samples, dtype=global_defs.tReal, device=self.device).reshape(-1, self.dim).contiguous()
+        n = z.shape[0]
+        ws = self._workspace(n)
+        ws["gen"] += 1
+        D = 0
+        hv = dirs_t = None
+        if dirs is not None and len(dirs):
+            dirs_t = self._dirs(dirs)
+            D = dirs_t.shape[0]
+            hv = torch.empty((n, D), dtype=global_defs.tReal, device=self.device)
+        x = torch.empty((n, self.dim), dtype=global_defs.tReal, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.call("vmcpde_flow_eval_from_latent", self.net.handle, nat.ptr(self._theta), nat.ptr(z), n, nat.ptr(dirs_t), D, nat.ptr(x),
+                     nat.ptr(ws["logp"]), nat.ptr(ws["g"]), nat.ptr(hv), nat.ptr(ws["JT"]), ws["ldj"],
+                     1 if self.jacobian_dtype == torch.float32 else 0, nat.stream())
+        P = self.numParameters
+        return dict(x=x, logp=ws["logp"], g=ws["g"], hv=hv, JT=ws["JT"], ldj=ws["ldj"], n=n, J=ws["JT"][:P, :n].T[None, ...])
+
     def flow_sample(self, latent_space_samples):
         """var_state.py:33,79 (J5) for injected latent samples (1,n,d)."""
         z = torch.as_tensor(latent_space_samples, dtype=global_defs.tReal, device=self.device).reshape(-1, self.dim).contiguous()
