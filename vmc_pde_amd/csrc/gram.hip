@@ -35,6 +35,7 @@ namespace {
 // Measured equal (18.7 ms both on the same box): the kernel sits on the chip's power-managed fp64 MFMA rate, not on issue
 // slots, so the smaller split count and workspace of 16 win.
 constexpr int GRAM_BKD = VMC_GRAM_BKD;
+constexpr int GRAM_FUSED_REDUCE_DEFAULT = 0;      // (round 6 A/B: see the fused split reduction in gram_dma_kernel)
 
 struct GramPlan {
   int nb;          // row blocks of 128
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const TIn* __restrict__ JT
 // vmcpde_gram_rows, whose perm holds the global indices of the tiles of a few tile rows)
 __global__ __launch_bounds__(256, GRAM_BKD == 8 ? 3 : 2) void gram_dma_kernel(const double* __restrict__ JT, int64_t ldj, int64_t N, int ntiles, int nsplit,
                                                           int64_t chunk, int total_units, int units_per_xcd, int order,
-                                                          const int* __restrict__ perm, double* __restrict__ out, int ntiles_out, int P) {
+                                                          const int* __restrict__ perm, double* __restrict__ out, int ntiles_out, int P,
+                                                          unsigned int* __restrict__ counters, double* __restrict__ packed) {
   extern __shared__ double lds[];
   int split, tile;
   if (!gram_unit(ntiles, nsplit, total_units, units_per_xcd, order, perm, split, tile)) return;
@@ -130,6 +132,31 @@ __global__ __launch_bounds__(256, GRAM_BKD == 8 ? 3 : 2) void gram_dma_kernel(co
   // (rows of the tile's A block below P are zero padding: a wave that holds nothing else idles -- the last tile row when P ends in the first half of a tile)
   tile_mainloop_dma<GRAM_BKD>(acc, JT, ldj, ti * TILE, JT, ldj, tj * TILE, ti == tj, k0, k1, lds, -1, P - ti * TILE);
   tile_store(acc, out + ((int64_t)split * ntiles_out + tile) * (TILE * TILE));
+  if (counters == nullptr) return;
+  // Fused split reduction (round 6, VMCPDE_GRAM_FUSED_REDUCE): the unit that finishes LAST among the nsplit units of a tile adds the tile's slabs in
+  // the fixed order 0 .. nsplit-1 -- the sums reduce_splits_kernel forms, bit for bit, whoever is last -- while the other workgroups are still on the
+  // matrix pipe.  Release (this unit's slab is visible device-wide) -> count -> acquire (the others' slabs are).
+  __shared__ int s_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(&counters[tile], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nsplit - 1)) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (threadIdx.x == 0) counters[tile] = 0u;                       // (ready for the next launch)
+  const double* __restrict__ src = out + (int64_t)tile * (TILE * TILE);
+  double* __restrict__ dst = packed + (int64_t)tile * (TILE * TILE);
+  const int64_t pitch = (int64_t)ntiles_out * (TILE * TILE);
+#pragma unroll 4
+  for (int e = (int)threadIdx.x * 2; e < TILE * TILE; e += 512) {
+    double2_t v = __builtin_nontemporal_load(reinterpret_cast<const double2_t*>(src + e));
+    for (int k = 1; k < nsplit; ++k) {
+      const double2_t w = __builtin_nontemporal_load(reinterpret_cast<const double2_t*>(src + (int64_t)k * pitch + e));
+      v.x += w.x;
+      v.y += w.y;
+    }
+    *reinterpret_cast<double2_t*>(dst + e) = v;
+  }
 }
 
 // BASELINE config 5, fast variant ("f32 blocks"): fp32 Jacobian, products summed in fp32 by v_mfma_f32_16x16x4_f32 over blocks of
@@ -354,7 +381,8 @@ extern "C" int64_t vmcpde_gram_workspace_bytes(int32_t P, int64_t n_samples) {
   const GramPlan a = make_plan(P, n_samples, SLOTS_STAGED), b = make_plan(P, n_samples, SLOTS_DMA), c = make_plan(P, (n_samples + 1) / 2, SLOTS_STAGED);
   int ns = a.nsplit > b.nsplit ? a.nsplit : b.nsplit;
   if (c.nsplit > ns) ns = c.nsplit;
-  return (int64_t)ns * a.ntiles * TILE * TILE * (int64_t)sizeof(double);
+  // (+ one counter per tile behind the slabs: the fused split reduction of the DMA kernel)
+  return (int64_t)ns * a.ntiles * TILE * TILE * (int64_t)sizeof(double) + (((int64_t)a.ntiles * 4 + 255) / 256) * 256;
 }
 
 extern "C" int vmcpde_eloc_stats(const double* eloc, int64_t n_samples, double* sums, void* stream) {
@@ -468,8 +496,17 @@ extern "C" int vmcpde_gram(const void* JT, int64_t ldj, int32_t jt_f32, int32_t 
       VMC_CHECK_HIP(hipFuncSetAttribute((const void*)gram_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds));
       ctx->attr_gram_dma = true;
     }
+    // fused split reduction: the counters live behind the slabs (zero before the first launch on this workspace: cleared here, left at zero by the kernel)
+    const bool fused_reduce = g.nsplit > 1 && env_int("VMCPDE_GRAM_FUSED_REDUCE", GRAM_FUSED_REDUCE_DEFAULT) != 0 &&
+                              workspace_bytes >= need + (int64_t)g.ntiles * 4;
+    unsigned int* counters = fused_reduce ? reinterpret_cast<unsigned int*>(static_cast<char*>(workspace) + need) : nullptr;
+    if (fused_reduce) VMC_CHECK_HIP(hipMemsetAsync(counters, 0, (size_t)g.ntiles * 4, st));
     hipLaunchKernelGGL(gram_dma_kernel, dim3(grid), dim3(256), dma_lds, st, static_cast<const double*>(JT), ldj, n_samples, g.ntiles,
-                       g.nsplit, g.chunk, total, per_xcd, order, perm, out, g.ntiles, (int)P);
+                       g.nsplit, g.chunk, total, per_xcd, order, perm, out, g.ntiles, (int)P, counters, packed);
+    if (fused_reduce) {
+      VMC_CHECK_HIP(hipGetLastError());
+      return 0;
+    }
   } else if (jt_f32) VMC_LAUNCH_GRAM_T(float);
   else VMC_LAUNCH_GRAM_T(double);
 #undef VMC_LAUNCH_GRAM_T
@@ -539,7 +576,7 @@ extern "C" int vmcpde_gram_rows(const double* JT, int64_t ldj, int32_t P, int64_
     ctx->attr_gram_dma = true;
   }
   hipLaunchKernelGGL(gram_dma_kernel, dim3(per_xcd * 8), dim3(256), dma_lds, st, JT, ldj, n_samples, nsub, g.nsplit, g.chunk, nsub * g.nsplit,
-                     per_xcd, 2, it->second, out, g.ntiles, (int)P);
+                     per_xcd, 2, it->second, out, g.ntiles, (int)P, (unsigned int*)nullptr, (double*)nullptr);
   VMC_CHECK_HIP(hipGetLastError());
   if (g.nsplit > 1) {
     const int64_t count = (int64_t)nsub * TILE * TILE, pitch = (int64_t)g.ntiles * TILE * TILE, off = (int64_t)t0 * TILE * TILE;
