@@ -27,7 +27,8 @@ def test_argument_validation_needs_no_gpu(lib_built):
     assert L.vmcpde_gram_packed_doubles(4213) == (33 * 34 // 2) * 128 * 128
     assert L.vmcpde_gram_packed_doubles(128) == 128 * 128
     ws = L.vmcpde_gram_workspace_bytes(4213, 65536)
-    assert ws % ((33 * 34 // 2) * 128 * 128 * 8) == 0 and 8 <= ws // ((33 * 34 // 2) * 128 * 128 * 8) <= 12   # split-K factor
+    slab, counters = (33 * 34 // 2) * 128 * 128 * 8, ((33 * 34 // 2) * 4 + 255) // 256 * 256     # (round 6: one counter per tile behind the slabs)
+    assert (ws - counters) % slab == 0 and 8 <= (ws - counters) // slab <= 12                        # split-K factor
     assert L.vmcpde_chol_workspace_bytes(129) == 2 * 128 * 128 * 8 + 256      # two inverse blocks + the counters of the chained launches
     assert L.vmcpde_num_parameters(None) == -1
     rc = L.vmcpde_gram(None, 0, 0, 0, 0, None, None, None, None, 0, None)
