@@ -132,3 +132,33 @@ def test_bordered_factorisation_carries_the_forward_substitution(P):
     F_d = torch.as_tensor(F).to(DEV)
     nat.call("vmcpde_chol_solve", nat.ptr(A2), Pp2, P, nat.ptr(F_d), nat.ptr(u2), nat.ptr(ws2), need2, nat.stream())
     assert np.linalg.norm((u - u2).cpu().numpy()) / np.linalg.norm(uref) < 1e-9
+
+
+@pytest.mark.parametrize("P", [1, 5, 128, 129, 206, 256, 300, 384, 500, 512])
+def test_small_systems_substitute_in_one_launch(P, monkeypatch):
+    """Round 6: both substitutions of a system of <= 4 blocks (the r x r matrix G of the Woodbury application) run as ONE workgroup with the right-hand
+    side in LDS -- the arithmetic of the block-row chain in the same order, so the same bits (VMCPDE_SOLVE_SMALL=0), in place or not; and the right answer."""
+    from vmc_pde_amd import _native as nat
+    Ppad = (P + 127) // 128 * 128
+    g = torch.Generator().manual_seed(P)
+    M = torch.randn(P, 2 * P + 3, generator=g, dtype=torch.float64)
+    A = torch.zeros((Ppad, Ppad), dtype=torch.float64)
+    A[:P, :P] = M @ M.T / (2 * P + 3) + 0.1 * torch.eye(P, dtype=torch.float64)
+    A[range(P, Ppad), range(P, Ppad)] = 1.0
+    F = torch.randn(P, generator=g, dtype=torch.float64)
+    Ad, Fd = A.cuda(), F.cuda()
+    need = nat.lib().vmcpde_chol_workspace_bytes(P)
+    ws = torch.empty(need // 8, dtype=torch.float64, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    nat.call("vmcpde_cholesky", nat.ptr(Ad), Ppad, P, nat.ptr(info), nat.ptr(ws), need, nat.stream())
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VMCPDE_SOLVE_SMALL", mode)
+        u = torch.full((P,), float("nan"), dtype=torch.float64, device="cuda")
+        nat.call("vmcpde_chol_solve", nat.ptr(Ad), Ppad, P, nat.ptr(Fd), nat.ptr(u), nat.ptr(ws), need, nat.stream())
+        v = Fd.clone()
+        nat.call("vmcpde_chol_solve", nat.ptr(Ad), Ppad, P, nat.ptr(v), nat.ptr(v), nat.ptr(ws), need, nat.stream())
+        assert torch.equal(u, v)
+        outs.append(u.cpu())
+    ref = torch.linalg.solve(A[:P, :P], F)
+    assert torch.equal(outs[0], outs[1]) and float((outs[0] - ref).abs().max() / ref.abs().max()) < 1e-10

@@ -1095,6 +1095,61 @@ __global__ __launch_bounds__(256, 1) void solve_bwd_persistent(const double* __r
   }
 }
 
+// Both substitutions L y = b, L^T u = y of a SMALL system (nb <= 4 blocks, P <= 512: the r x r matrix G of the Woodbury application) as ONE workgroup:
+// the right-hand side lives in LDS, the block updates and the diagonal-block inverses are the arithmetic of solve_fwd_step / solve_bwd_step /
+// diag_apply in the same order -- the same bits -- without the six launch boundaries of the block-row chain (round 6).
+constexpr int SOLVE_SMALL_MAX_BLOCKS = 4;
+__global__ __launch_bounds__(256) void solve_small_kernel(const double* __restrict__ L, int64_t lda, int P, int nb, const double* __restrict__ rhs,
+                                                         double* __restrict__ u, const double* __restrict__ Linv_all) {
+  __shared__ double rs[SOLVE_SMALL_MAX_BLOCKS * NB];
+  __shared__ double sh[NB];
+  __shared__ double part[2 * NB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int i = t; i < nb * NB; i += 256) rs[i] = (i < P) ? rhs[i] : 0.0;
+  __syncthreads();
+  auto nrows = [&](int b) { return (P - b * NB < NB) ? (P - b * NB) : NB; };
+  // ---- L y = b
+  diag_apply(Linv_all, rs, nrows(0), 0, sh, part);
+  for (int k = 0; k + 1 < nb; ++k) {
+    const int k0 = k * NB;
+    const double y0 = rs[k0 + 2 * lane], y1 = rs[k0 + 2 * lane + 1];
+    for (int b = k + 1; b < nb; ++b) {
+      const int b0 = b * NB, nbk = nrows(b);
+      double2_t v[32];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) v[q] = *reinterpret_cast<const double2_t*>(L + (int64_t)(b0 + wave * 32 + q) * lda + k0 + 2 * lane);
+      const double rold = (lane < 32 && wave * 32 + lane < nbk) ? rs[b0 + wave * 32 + lane] : 0.0;
+      double mine = 0.0;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const double su = wave_sum(v[q].x * y0 + v[q].y * y1);
+        if (lane == q) mine = su;
+      }
+      if (lane < 32 && wave * 32 + lane < nbk) rs[b0 + wave * 32 + lane] = rold - mine;
+    }
+    __syncthreads();
+    diag_apply(Linv_all + (int64_t)(k + 1) * NB * NB, rs + (k + 1) * NB, nrows(k + 1), 0, sh, part);
+  }
+  // ---- L^T u = y
+  diag_apply(Linv_all + (int64_t)(nb - 1) * NB * NB, rs + (nb - 1) * NB, nrows(nb - 1), 1, sh, part);
+  const int j = t & (NB - 1), half = t >> 7;
+  for (int k = nb - 1; k >= 1; --k) {
+    const int k0 = k * NB;
+    for (int b = 0; b < k; ++b) {
+      const int b0 = b * NB;
+      double sacc = 0.0;
+#pragma unroll 8
+      for (int i = half; i < NB; i += 2) sacc = fma(L[(int64_t)(k0 + i) * lda + b0 + j], rs[k0 + i], sacc);   // rows >= P: zero padding, rs zero there
+      part[half * NB + j] = sacc;
+      __syncthreads();
+      if (t < NB) rs[b0 + t] -= part[t] + part[NB + t];
+      __syncthreads();
+    }
+    diag_apply(Linv_all + (int64_t)(k - 1) * NB * NB, rs + (k - 1) * NB, NB, 1, sh, part);
+  }
+  for (int i = t; i < P; i += 256) u[i] = rs[i];
+}
+
 __global__ __launch_bounds__(256) void solve_diag_only(double* __restrict__ r, int P, int k, int trans, const double* __restrict__ Linv_all) {
   __shared__ double sh[NB];
   __shared__ double part[2 * NB];
@@ -1442,6 +1497,11 @@ extern "C" int vmcpde_chol_solve(const double* L, int64_t lda, int32_t P, const 
   hipStream_t st = (hipStream_t)stream;
   const double* Linv = static_cast<const double*>(workspace);
   const int nb = (P + NB - 1) / NB;
+  if (nb <= SOLVE_SMALL_MAX_BLOCKS && env_int("VMCPDE_SOLVE_SMALL", 1) != 0) {      // one workgroup, one launch (the r x r system of the Woodbury application)
+    hipLaunchKernelGGL(solve_small_kernel, dim3(1), dim3(256), 0, st, L, lda, P, nb, F, u, Linv);
+    VMC_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   if (u != F) VMC_CHECK_HIP(hipMemcpyAsync(u, F, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, st));
   // L y = F
   hipLaunchKernelGGL(solve_diag_only, dim3(1), dim3(256), 0, st, u, P, 0, 0, Linv);
