@@ -3,12 +3,12 @@
 # call counts is exactly S steps' worth -- the planning call, the warm-up and the set-up cancel.  Prints calls per step and mean duration of every kernel
 # (library GEMMs `Cijk_*`, framework kernels `at::native::*` and copies `__amd_rocclr_copyBuffer` are what VERDICT round 5, item 4 counts).
 R=${GRAFT_REPO_ROOT:-$PWD}
-S=${1:-40}
+S=${1:-40}          # BENCH_ARGS="--solver eigh": the census of another route
 OUT=$R/gpurun_out/per_step_launches
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for n in $S $((2 * S)); do
-  timeout -k 10 400 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $OUT/s$n -- python3 $R/bench.py --steps $n --warmup 5 --no-cpu-baseline --no-beside > $OUT/s$n.log 2>&1 || { tail -5 $OUT/s$n.log; exit 1; }
+  timeout -k 10 400 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $OUT/s$n -- python3 $R/bench.py --steps $n --warmup 5 --no-cpu-baseline --no-beside $BENCH_ARGS > $OUT/s$n.log 2>&1 || { tail -5 $OUT/s$n.log; exit 1; }
 done
 python3 - $OUT $S <<'PY'
 import csv, glob, sys, os
